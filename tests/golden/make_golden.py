@@ -1,0 +1,272 @@
+#!/usr/bin/env python
+"""Generate the golden input/output vectors under tests/golden/ from the *reference itself*.
+
+Runs ONLY in the build container (needs /root/reference, CPU torch).  Nothing here travels to the
+GPU box except the .npz files it writes: they hold inputs and the reference's outputs, no source.
+
+The reference's packages cannot be imported wholesale (torchvision / pytorch_lightning / cv2 are
+absent), so the hot-path modules are imported one by one underneath empty package shells, which
+keeps the heavy ``__init__.py`` files from executing.
+
+Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
+
+  g1_msda_optest.npz     reference ops/test.py case (seed 3; N1 M2 D2 Lq2 L2 P2; shapes (6,4),(3,2))
+                         fwd in fp64 and fp32 through ms_deform_attn_core_pytorch
+  g2_msda_grad_D{30,32,64,71}.npz   same generator, D in the reference's gradcheck set; fwd + autograd
+                         grads (value / loc / attn) in fp64
+  g3_msda_medium.npz     N2 M8 D32 Lq64 L4 P4, loc in [-0.25,1.25] (border + out-of-range), fwd+bwd fp64
+  g4_msda_module.npz     MSDeformAttn module (d_model 64, 4 heads): state-dict + inputs + outputs for 2-d
+                         and 4-d reference points with a padding mask
+  g6_corr.npz            CorrBlock: fmaps (1,256,16,20) -> 4 pyramid levels + lookups (in-range, integer and
+                         far out-of-frame coords); plus an odd-sized batched case (2,32,17,18), radius 3
+  g8_known_answers.npz   hand-checkable micro cases (pixel-centre sample, corner sample)
+
+Usage:  python tests/golden/make_golden.py            (from the repo root)
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _shell(name, path=None, **attrs):
+    mod = types.ModuleType(name)
+    if path is not None:
+        mod.__path__ = [path]
+    for k, v in attrs.items():
+        setattr(mod, k, v)
+    sys.modules[name] = mod
+    return mod
+
+
+def load_reference():
+    """Import the reference's pure-torch hot-path modules; returns a namespace of them."""
+    root = _shell("alonet", REF + "/alonet", ALONET_ROOT=REF + "/alonet")
+    for sub in (
+        "deformable_detr",
+        "deformable_detr/ops",
+        "deformable_detr/ops/functions",
+        "deformable_detr/ops/modules",
+        "raft",
+        "raft/utils",
+        "common",
+        "transformers",
+    ):
+        _shell("alonet." + sub.replace("/", "."), REF + "/alonet/" + sub)
+    root.common = sys.modules["alonet.common"]
+
+    class _Frame:  # the five attributes RAFTBase.forward touches
+        def __init__(self, t, normalization):
+            self.t, self.normalization, self.shape = t, normalization, t.shape
+
+        def as_tensor(self):
+            return self.t
+
+    _shell("aloscene", None, Frame=_Frame, Flow=lambda x, names=None: x)
+
+    ns = types.SimpleNamespace()
+    ns.func = importlib.import_module("alonet.deformable_detr.ops.functions.ms_deform_attn_func")
+    fpkg = sys.modules["alonet.deformable_detr.ops.functions"]
+    fpkg.MSDeformAttnFunction = ns.func.MSDeformAttnFunction
+    fpkg.load_MultiScaleDeformableAttention = lambda: None
+    ns.mod = importlib.import_module("alonet.deformable_detr.ops.modules.ms_deform_attn")
+    sys.modules["alonet.deformable_detr.ops.modules"].MSDeformAttn = ns.mod.MSDeformAttn
+    ns.corr = importlib.import_module("alonet.raft.corr")
+    ns.rutils = importlib.import_module("alonet.raft.utils.utils")
+    ns.Frame = _Frame
+    return ns
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _level_start(shapes):
+    return torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1])).to(torch.int32)
+
+
+def _optest_inputs(N, M, D, Lq, L, P, shapes):
+    """Input generator of the reference's ops/test.py (same call order after the seed)."""
+    S = int(shapes.prod(1).sum())
+    value = torch.rand(N, S, M, D) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    attn = torch.rand(N, Lq, M, L, P) + 1e-5
+    attn /= attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    return value, loc, attn
+
+
+def g1(ref):
+    N, M, D, Lq, L, P = 1, 2, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.int32)
+    torch.manual_seed(3)
+    value, loc, attn = _optest_inputs(N, M, D, Lq, L, P, shapes)
+    out64 = ref.func.ms_deform_attn_core_pytorch(value.double(), shapes, loc.double(), attn.double())
+    value2, loc2, attn2 = _optest_inputs(N, M, D, Lq, L, P, shapes)  # second draw, as check_..._float does
+    out32 = ref.func.ms_deform_attn_core_pytorch(value2, shapes, loc2, attn2)
+    np.savez_compressed(
+        os.path.join(OUT, "g1_msda_optest.npz"),
+        shapes=_np(shapes), level_start=_np(_level_start(shapes)),
+        value=_np(value), loc=_np(loc), attn=_np(attn), out_f64=_np(out64),
+        value_b=_np(value2), loc_b=_np(loc2), attn_b=_np(attn2), out_f32=_np(out32),
+    )
+
+
+def _fwd_bwd_f64(ref, value, shapes, loc, attn, gout):
+    value = value.double().requires_grad_(True)
+    loc = loc.double().requires_grad_(True)
+    attn = attn.double().requires_grad_(True)
+    out = ref.func.ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+    out.backward(gout.double())
+    return out, value.grad, loc.grad, attn.grad
+
+
+def g2(ref):
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.int32)
+    for D in (30, 32, 64, 71):
+        torch.manual_seed(3 + D)
+        value, loc, attn = _optest_inputs(N, M, D, Lq, L, P, shapes)
+        gout = torch.randn(N, Lq, M * D)
+        out, gv, gl, ga = _fwd_bwd_f64(ref, value, shapes, loc, attn, gout)
+        np.savez_compressed(
+            os.path.join(OUT, f"g2_msda_grad_D{D}.npz"),
+            shapes=_np(shapes), level_start=_np(_level_start(shapes)),
+            value=_np(value), loc=_np(loc), attn=_np(attn), grad_out=_np(gout),
+            out=_np(out), grad_value=_np(gv), grad_loc=_np(gl), grad_attn=_np(ga),
+        )
+
+
+def g3(ref):
+    N, M, D, Lq, L, P = 2, 8, 32, 64, 4, 4
+    shapes = torch.as_tensor([(16, 21), (8, 11), (4, 6), (2, 3)], dtype=torch.int32)
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(33)
+    value = torch.randn(N, S, M, D)
+    loc = torch.rand(N, Lq, M, L, P, 2) * 1.5 - 0.25
+    # a few exact special positions: pixel centres, the -1 / H boundaries of the validity test
+    loc[0, 0, 0, 0, 0] = torch.tensor([0.5 / 21, 0.5 / 16])  # centre of pixel (0,0) of level 0
+    loc[0, 0, 0, 0, 1] = torch.tensor([0.0, 0.0])  # corner of the map
+    loc[0, 0, 0, 0, 2] = torch.tensor([1.0, 1.0])
+    loc[0, 0, 0, 0, 3] = torch.tensor([-0.5 / 21, 0.25])  # w_im == -1 exactly -> skipped
+    loc[0, 1, 0, 0, 0] = torch.tensor([1.0 + 0.5 / 21, 0.25])  # w_im == W exactly -> skipped
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    gout = torch.randn(N, Lq, M * D)
+    out, gv, gl, ga = _fwd_bwd_f64(ref, value, shapes, loc, attn, gout)
+    np.savez_compressed(
+        os.path.join(OUT, "g3_msda_medium.npz"),
+        shapes=_np(shapes), level_start=_np(_level_start(shapes)),
+        value=_np(value), loc=_np(loc), attn=_np(attn), grad_out=_np(gout),
+        out=_np(out).astype(np.float64), grad_value=_np(gv).astype(np.float32),
+        grad_loc=_np(gl).astype(np.float32), grad_attn=_np(ga).astype(np.float32),
+    )
+
+
+def g4(ref):
+    d_model, n_levels, n_heads, n_points = 64, 3, 4, 2
+    shapes = torch.as_tensor([(7, 9), (4, 5), (2, 3)], dtype=torch.int64)
+    S = int(shapes.prod(1).sum())
+    N, Lq = 2, 11
+    torch.manual_seed(44)
+    m = ref.mod.MSDeformAttn(d_model, n_levels, n_heads, n_points).double()
+    with torch.no_grad():  # the default init zeroes two of the four linears: perturb them
+        m.sampling_offsets.weight.normal_(0, 0.05)
+        m.attention_weights.weight.normal_(0, 0.3)
+        m.attention_weights.bias.normal_(0, 0.3)
+    query = torch.randn(N, Lq, d_model).double()
+    src = torch.randn(N, S, d_model).double()
+    ref2 = torch.rand(N, Lq, n_levels, 2).double()
+    ref4 = torch.cat([ref2, torch.rand(N, Lq, n_levels, 2).double() * 0.5], -1)
+    mask = torch.zeros(N, S, dtype=torch.bool)
+    mask[1, -7:] = True
+    mask[0, 5:9] = True
+    lsi = _level_start(shapes.to(torch.int32))
+    with torch.no_grad():
+        out2 = m(query, ref2, src, shapes, lsi, mask, is_tracing=None)
+        out4 = m(query, ref4, src, shapes, lsi, mask, is_tracing=None)
+        out2_nomask = m(query, ref2, src, shapes, lsi, None, is_tracing=None)
+    sd = {"sd." + k: _np(v) for k, v in m.state_dict().items()}
+    np.savez_compressed(
+        os.path.join(OUT, "g4_msda_module.npz"),
+        cfg=np.array([d_model, n_levels, n_heads, n_points]), shapes=_np(shapes), level_start=_np(lsi),
+        query=_np(query), src=_np(src), ref2=_np(ref2), ref4=_np(ref4), mask=_np(mask),
+        out2=_np(out2), out4=_np(out4), out2_nomask=_np(out2_nomask), **sd,
+    )
+
+
+def g6(ref):
+    # every pyramid level must keep h,w >= 2: with h == 1 the reference divides by (h-1) == 0 and
+    # returns NaN (utils.py:8-9) -- a degenerate case we do not pin.
+    B, C, H, W = 1, 256, 16, 20
+    torch.manual_seed(66)
+    f1 = torch.randn(B, C, H, W)
+    f2 = torch.randn(B, C, H, W)
+    blk = ref.corr.CorrBlock(f1, f2, radius=4)
+    grid = ref.rutils.coords_grid(B, H, W)
+    coords_a = grid + torch.randn(B, 2, H, W) * 2.5  # typical flow magnitudes at 1/8 res
+    coords_b = grid.clone()  # first RAFT iteration: exact integer coordinates
+    coords_c = grid + torch.randn(B, 2, H, W) * 40.0  # mostly out of frame
+    out = {k: _np(blk(c)) for k, c in (("a", coords_a), ("b", coords_b), ("c", coords_c))}
+    assert all(np.isfinite(v).all() for v in out.values())
+    # an odd-sized, batched map exercises avg_pool2d's floor (dropped last row/col), rows that are not
+    # 16-byte aligned, and a different radius
+    f1o = torch.randn(2, 32, 17, 18)
+    f2o = torch.randn(2, 32, 17, 18)
+    blko = ref.corr.CorrBlock(f1o, f2o, radius=3)
+    coords_o = ref.rutils.coords_grid(2, 17, 18) + torch.randn(2, 2, 17, 18) * 2.0
+    out_o = _np(blko(coords_o))
+    assert np.isfinite(out_o).all()
+    np.savez_compressed(
+        os.path.join(OUT, "g6_corr.npz"),
+        f1=_np(f1), f2=_np(f2),
+        lvl0=_np(blk.corr_pyramid[0]), lvl1=_np(blk.corr_pyramid[1]),
+        lvl2=_np(blk.corr_pyramid[2]), lvl3=_np(blk.corr_pyramid[3]),
+        coords_a=_np(coords_a), coords_b=_np(coords_b), coords_c=_np(coords_c),
+        out_a=out["a"], out_b=out["b"], out_c=out["c"],
+        f1o=_np(f1o), f2o=_np(f2o), coords_o=_np(coords_o), out_o=out_o,
+        lvl0o=_np(blko.corr_pyramid[0]), lvl1o=_np(blko.corr_pyramid[1]),
+        lvl2o=_np(blko.corr_pyramid[2]), lvl3o=_np(blko.corr_pyramid[3]),
+    )
+
+
+def g8(ref):
+    """Known-answer micro cases; expected values are also derivable by hand (see tests)."""
+    shapes = torch.as_tensor([(2, 3)], dtype=torch.int32)
+    value = torch.arange(1.0, 7.0, dtype=torch.float64).view(1, 6, 1, 1)  # pixel (y,x) holds 1 + 3y + x
+    loc = torch.tensor(
+        [
+            [(0.5 / 3, 0.5 / 2)],  # centre of pixel (0,0)  -> 1
+            [(2.5 / 3, 1.5 / 2)],  # centre of pixel (1,2)  -> 6
+            [(0.0, 0.0)],  # map corner: 1/4 of pixel (0,0) -> 0.25
+            [(1.0 / 3, 0.5)],  # between four pixels (0,0),(0,1),(1,0),(1,1) -> (1+2+4+5)/4 = 3
+        ],
+        dtype=torch.float64,
+    ).view(1, 4, 1, 1, 1, 2)
+    attn = torch.ones(1, 4, 1, 1, 1, dtype=torch.float64)
+    out = ref.func.ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+    np.savez_compressed(
+        os.path.join(OUT, "g8_known_answers.npz"),
+        shapes=_np(shapes), level_start=np.zeros(1, np.int32), value=_np(value), loc=_np(loc), attn=_np(attn),
+        out=_np(out), expected=np.array([1.0, 6.0, 0.25, 3.0]),
+    )
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
+    torch.set_num_threads(4)
+    ref = load_reference()
+    for fn in (g1, g2, g3, g4, g6, g8):
+        fn(ref)
+        print("wrote", fn.__name__)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
+    print(f"total fixture bytes: {total}")
+
+
+if __name__ == "__main__":
+    main()
