@@ -1,0 +1,224 @@
+"""ctypes binding of ``libalo_hotpath.so`` (the C ABI declared in ``include/alo_hotpath.h``).
+
+This is the only place the host code touches the native library.  PyTorch is used for what it is good at here —
+device memory, streams, dtypes — and nothing else: every function below takes torch tensors, validates them the way
+the reference op validates its ``at::Tensor`` arguments (alonet/deformable_detr/ops/src/cuda/ms_deform_attn_cuda.cu:28-52),
+allocates the outputs (so torch owns the memory, as with the reference op) and enqueues the HIP kernels on the
+current torch stream.
+
+There is NO fallback: if the library is missing or a tensor lives on the CPU these functions raise ``RuntimeError``.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libalo_hotpath.so")
+CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
+
+ALO_F32, ALO_F64, ALO_BF16 = 0, 1, 2
+_DTYPE_CODE = {torch.float32: ALO_F32, torch.float64: ALO_F64, torch.bfloat16: ALO_BF16}
+
+_lib = None
+
+
+class HotpathUnavailable(RuntimeError):
+    """libalo_hotpath.so cannot be loaded (not built, or built for another ABI)."""
+
+
+def build(force=False):
+    """Compile the HIP kernels for gfx950 with hipcc (``make -C aloception-oss_amd/csrc``). Needs no GPU."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _declare(lib):
+    c = ctypes
+    vp, ip, sz = c.c_void_p, c.c_int, c.c_size_t
+    lib.alo_abi_version.restype = ip
+    lib.alo_abi_version.argtypes = []
+    lib.alo_last_error.restype = c.c_char_p
+    lib.alo_last_error.argtypes = []
+    lib.alo_msda_forward.restype = ip
+    lib.alo_msda_forward.argtypes = [vp] * 6 + [ip] * 9 + [vp]
+    lib.alo_msda_backward.restype = ip
+    lib.alo_msda_backward.argtypes = [vp] * 9 + [ip] * 9 + [vp]
+    lib.alo_corr_level_shape.restype = None
+    lib.alo_corr_level_shape.argtypes = [ip, ip, ip, c.POINTER(ip), c.POINTER(ip)]
+    lib.alo_corr_build_workspace_bytes.restype = sz
+    lib.alo_corr_build_workspace_bytes.argtypes = [ip] * 5
+    lib.alo_corr_build.restype = ip
+    lib.alo_corr_build.argtypes = [vp, vp, c.POINTER(vp), vp, sz] + [ip] * 5 + [vp]
+    lib.alo_corr_lookup.restype = ip
+    lib.alo_corr_lookup.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
+
+
+def lib():
+    """The loaded library; raises :class:`HotpathUnavailable` (never falls back) when it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HotpathUnavailable(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {CSRC_DIR}` (hipcc, --offload-arch=gfx950). There is no CPU fallback for this path."
+            )
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the box
+            raise HotpathUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+        _declare(handle)
+        if handle.alo_abi_version() != 1:
+            raise HotpathUnavailable(f"{LIB_PATH} has ABI version {handle.alo_abi_version()}, expected 1")
+        _lib = handle
+    return _lib
+
+
+def is_available():
+    try:
+        lib()
+        return True
+    except HotpathUnavailable:
+        return False
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().alo_last_error().decode() or f"alo_hotpath error {rc}")
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require_cuda_contiguous(named):
+    # same order and wording as the reference's AT_ASSERTM list (ms_deform_attn_cuda.cu:28-38,91-105)
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+    for name, t in named:
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def _msda_prepare(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, extra=()):
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")  # ms_deform_attn.h:38,60
+    _require_cuda_contiguous(
+        [("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+         ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)] + list(extra)
+    )
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("value must be (N,S,M,D), sampling_loc (N,Lq,M,L,P,2), attn_weight (N,Lq,M,L,P)")
+    if spatial_shapes.dtype != torch.int32 or level_start_index.dtype != torch.int32:
+        # this fork of the op reads int32 metadata (ms_deform_attn_cuda.cu:67-68)
+        raise RuntimeError("spatial_shapes and level_start_index must be int32 tensors")
+    N, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_loc.shape
+    if (M2, two) != (M, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P) or sampling_loc.shape[0] != N:
+        raise RuntimeError("sampling_loc / attn_weight shapes do not match value")
+    if tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,):
+        raise RuntimeError("spatial_shapes must be (L,2) and level_start_index (L,)")
+    step = min(N, int(im2col_step))
+    if step <= 0 or N % step != 0:
+        raise RuntimeError(f"batch({N}) must divide im2col_step({step})")
+    vdt = _DTYPE_CODE.get(value.dtype)
+    if vdt is None:
+        raise RuntimeError(f"ms_deform_attn: unsupported value dtype {value.dtype}")
+    if value.dtype == torch.bfloat16:
+        # bf16 storage: sampling geometry stays fp32 (bf16 locations would cost ~0.3 px at 167-wide maps)
+        sampling_loc, attn_weight = sampling_loc.float(), attn_weight.float()
+    elif sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("sampling_loc and attn_weight must have the dtype of value")
+    ldt = _DTYPE_CODE[sampling_loc.dtype]
+    return (N, S, M, D, L, Lq, P), vdt, ldt, sampling_loc.contiguous(), attn_weight.contiguous()
+
+
+def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """-> (N, Lq, M*D) tensor of ``value``'s dtype.  Replaces ``alonet_custom::ms_deform_attn_forward``."""
+    dims, vdt, ldt, loc, attn = _msda_prepare(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    N, S, M, D, L, Lq, P = dims
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        _check(lib().alo_msda_forward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
+                                      _ptr(out), N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
+    return out
+
+
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight].  Replaces ``alonet_custom::ms_deform_attn_backward``."""
+    dims, vdt, ldt, loc, attn = _msda_prepare(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                              im2col_step, extra=[("grad_output", grad_output)])
+    N, S, M, D, L, Lq, P = dims
+    if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must be (N, Lq, M*D) with the dtype of value")
+    gdt = torch.float64 if value.dtype == torch.float64 else torch.float32
+    grad_value = torch.empty(value.shape, dtype=gdt, device=value.device)
+    grad_loc = torch.empty(loc.shape, dtype=gdt, device=value.device)
+    grad_attn = torch.empty(attn.shape, dtype=gdt, device=value.device)
+    with torch.cuda.device(value.device):
+        _check(lib().alo_msda_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
+                                       _ptr(grad_output), _ptr(grad_value), _ptr(grad_loc), _ptr(grad_attn),
+                                       N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
+    return [grad_value.to(value.dtype), grad_loc.to(sampling_loc.dtype), grad_attn.to(attn_weight.dtype)]
+
+
+def corr_level_shapes(H, W, num_levels):
+    out = []
+    h, w = ctypes.c_int(), ctypes.c_int()
+    for lvl in range(num_levels):
+        lib().alo_corr_level_shape(H, W, lvl, ctypes.byref(h), ctypes.byref(w))
+        out.append((h.value, w.value))
+    return out
+
+
+def _require_f32_cuda(name, t, ndim):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor (the correlation path has no CPU implementation here)")
+    if t.dtype != torch.float32 or t.dim() != ndim:
+        raise RuntimeError(f"{name} must be a {ndim}-d float32 tensor, got {tuple(t.shape)} {t.dtype}")
+
+
+def corr_build(fmap1, fmap2, num_levels=4):
+    """fmaps (B,C,H,W) float32 -> list of ``num_levels`` tensors (B*H*W, 1, h_l, w_l)  (corr.py:13-27)."""
+    _require_f32_cuda("fmap1", fmap1, 4)
+    _require_f32_cuda("fmap2", fmap2, 4)
+    if fmap1.shape != fmap2.shape:
+        raise RuntimeError("fmap1 and fmap2 must have the same shape")
+    fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+    B, C, H, W = fmap1.shape
+    shapes = corr_level_shapes(H, W, num_levels)
+    levels = [torch.empty((B * H * W, 1, h, w), dtype=torch.float32, device=fmap1.device) for h, w in shapes]
+    nbytes = lib().alo_corr_build_workspace_bytes(B, C, H, W, num_levels)
+    ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=fmap1.device)
+    ptrs = (ctypes.c_void_p * num_levels)(*[t.data_ptr() for t in levels])
+    with torch.cuda.device(fmap1.device):
+        _check(lib().alo_corr_build(_ptr(fmap1), _ptr(fmap2), ptrs, _ptr(ws), nbytes, B, C, H, W, num_levels,
+                                    _stream(fmap1.device)))
+    # ws may be released now: the caching allocator keeps the block bound to this stream until the kernels retire
+    return levels
+
+
+def corr_lookup(levels, coords, radius=4):
+    """levels from :func:`corr_build`, coords (B,2,H,W) -> (B, L*(2r+1)^2, H, W) float32  (corr.py:29-50)."""
+    _require_f32_cuda("coords", coords, 4)
+    coords = coords.contiguous()
+    B, two, H, W = coords.shape
+    if two != 2:
+        raise RuntimeError("coords must be (B,2,H,W)")
+    L = len(levels)
+    for lvl, t in enumerate(levels):
+        _require_f32_cuda(f"corr_pyramid[{lvl}]", t, 4)
+        if not t.is_contiguous() or t.shape[0] != B * H * W:
+            raise RuntimeError(f"corr_pyramid[{lvl}] must be a contiguous (B*H*W,1,h,w) tensor")
+    out = torch.empty((B, L * (2 * radius + 1) ** 2, H, W), dtype=torch.float32, device=coords.device)
+    ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in levels])
+    with torch.cuda.device(coords.device):
+        _check(lib().alo_corr_lookup(ptrs, _ptr(coords), _ptr(out), B, H, W, radius, L, _stream(coords.device)))
+    return out

@@ -1,0 +1,8 @@
+from .ms_deform_attn_func import (
+    MSDeformAttnFunction,
+    load_MultiScaleDeformableAttention,
+    load_ops,
+    ms_deform_attn_core_pytorch,
+)
+
+__all__ = ["MSDeformAttnFunction", "ms_deform_attn_core_pytorch", "load_MultiScaleDeformableAttention", "load_ops"]

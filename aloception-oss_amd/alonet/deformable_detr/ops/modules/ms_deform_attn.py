@@ -1,0 +1,120 @@
+"""``MSDeformAttn`` — the multi-scale deformable attention layer of Deformable-DETR on the gfx950 op.
+
+Same constructor, parameter names (state-dict keys ``sampling_offsets / attention_weights / value_proj /
+output_proj``), initialisation and ``forward`` contract as the reference module
+(alonet/deformable_detr/ops/modules/ms_deform_attn.py:34-155).  The four linear layers stay on stock PyTorch-ROCm
+(hipBLASLt); the gather is ``MSDeformAttnFunction`` -> HIP.
+
+Reduced-precision use (``module.bfloat16()``): ``value`` is produced and gathered in bf16, but sampling locations and
+attention weights are evaluated in fp32 — an 8-bit mantissa on a location in [0,1] would move samples by a third of a
+pixel on a 167-wide map.  With fp32/fp64 parameters the arithmetic is the reference's, operation for operation.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, xavier_uniform_
+
+from ..functions import MSDeformAttnFunction, load_MultiScaleDeformableAttention, ms_deform_attn_core_pytorch
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        """
+        :param d_model   hidden dimension
+        :param n_levels  number of feature levels
+        :param n_heads   number of attention heads
+        :param n_points  number of sampling points per attention head per feature level
+        """
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn(
+                "d_model // n_heads is not a power of 2: the gfx950 kernel then leaves lanes idle "
+                "(channels per head are spread over a power-of-two lane group)."
+            )
+        self.im2col_step = 64  # kept for API compatibility; the HIP op has no batch chunking
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+        load_MultiScaleDeformableAttention()
+
+    def _reset_parameters(self):
+        # offsets start as a ring of n_heads directions, point k pushed k+1 pixels out (reference :70-88)
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        angle = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        ring = torch.stack([angle.cos(), angle.sin()], -1)
+        ring = ring / ring.abs().max(-1, keepdim=True)[0]
+        ring = ring.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        ring = ring * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, self.n_points, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(ring.reshape(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None, **kwargs):
+        """
+        :param query                    (N, Lq, C)
+        :param reference_points         (N, Lq, n_levels, 2) in [0,1] (top-left (0,0), bottom-right (1,1), padding included)
+                                        or (N, Lq, n_levels, 4): (cx, cy, w, h) reference boxes
+        :param input_flatten            (N, sum_l H_l*W_l, C)
+        :param input_spatial_shapes     (n_levels, 2) [(H_0, W_0), ...]
+        :param input_level_start_index  (n_levels,)
+        :param input_padding_mask       (N, sum_l H_l*W_l) bool, True on padding
+        :return                         (N, Lq, C)
+        """
+        N, Lq, _ = query.shape
+        _, S, _ = input_flatten.shape
+        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == S
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, S, M, self.d_model // M)
+
+        low_precision = value.dtype in (torch.bfloat16, torch.float16)
+        geo = torch.float32 if low_precision else value.dtype
+        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2).to(geo)
+        weights = self.attention_weights(query).view(N, Lq, M, L * P).to(geo)
+        weights = F.softmax(weights, -1).view(N, Lq, M, L, P)
+        reference_points = reference_points.to(geo)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = (
+                reference_points[:, :, None, :, None, :2]
+                + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+            )
+        else:
+            raise ValueError(
+                "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1])
+            )
+
+        if "is_tracing" in kwargs:  # ONNX / TorchScript export branch of the reference (:138-144)
+            output = ms_deform_attn_core_pytorch(value.to(geo), input_spatial_shapes, locations, weights).to(value.dtype)
+        else:
+            output = MSDeformAttnFunction.apply(
+                value, input_spatial_shapes, input_level_start_index, locations, weights, self.im2col_step
+            )
+        return self.output_proj(output)

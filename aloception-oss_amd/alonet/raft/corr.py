@@ -1,0 +1,28 @@
+"""RAFT correlation block on the gfx950 kernels (fp32 MFMA all-pairs volume + pyramid, gather lookup).
+
+Drop-in for the reference's ``CorrBlock`` (alonet/raft/corr.py:12-60) through RAFT's ``corr_block=`` constructor
+hook (alonet/raft/raft.py:47-60,168,185): ``CorrBlock(fmap1, fmap2, num_levels=4, radius=4)`` builds
+``corr_pyramid`` (list of ``(B*H*W, 1, h_l, w_l)`` float32 tensors) and ``corr_fn(coords)`` returns the
+``(B, num_levels*(2r+1)^2, H, W)`` float32 window features.  ``AlternateCorrBlock`` is not provided: the reference's
+version needs the absent third-party ``alt_cuda_corr`` extension and is unreachable (corr.py:5-9,86).
+"""
+import torch
+
+import alo_hip
+
+
+class CorrBlock:
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.corr_pyramid = alo_hip.corr_build(fmap1.float(), fmap2.float(), num_levels)
+
+    def __call__(self, coords):
+        return alo_hip.corr_lookup(self.corr_pyramid, coords.float(), self.radius)
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """All-pairs correlation only: (B,C,H,W) x2 -> (B,H,W,1,H,W), scaled by 1/sqrt(C)."""
+        B, _, H, W = fmap1.shape
+        (vol,) = alo_hip.corr_build(fmap1.float(), fmap2.float(), 1)
+        return vol.view(B, H, W, 1, H, W)

@@ -1,0 +1,148 @@
+// Shared helpers for the gfx950 kernels: error reporting, buffer-resource loads, element conversion.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/alo_hotpath.h"
+
+namespace alo {
+
+// ---- host side: thread-local error string -------------------------------------------------------------------------
+char* error_buffer();  // api.hip
+inline int fail(alo_status_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return (int)code;
+}
+#define ALO_REQUIRE(cond, code, ...) \
+    do {                             \
+        if (!(cond)) return ::alo::fail(code, __VA_ARGS__); \
+    } while (0)
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return ALO_OK;
+}
+
+constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
+
+// Remap a launch-order block id so that each XCD (private 4 MiB L2) receives one CONTIGUOUS range of logical work
+// items instead of every 8th one.  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned nblocks) {
+    const unsigned q = nblocks / kNumXcd, r = nblocks % kNumXcd;
+    const unsigned xcd = bid % kNumXcd, k = bid / kNumXcd;
+    const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+// ---- device side ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct bf16_t {
+    uint16_t bits;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest even, NaN stays NaN
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// A raw (stride-0) buffer resource over [base, base + bytes).  Loads whose byte offset falls outside return 0 and
+// touch no memory: the hardware's bounds check is how out-of-map bilinear corners get their zero padding.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+constexpr unsigned kOutOfRange = 0xC0000000u;  // byte offset guaranteed past any slab (slabs are < 3 GiB)
+
+// Load VEC elements of storage type T at byte offset `off` and widen them to the compute type CT.
+template <typename T, typename CT, int VEC>
+struct Loader;
+
+template <>
+struct Loader<float, float, 4> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[4]) {
+        u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        v[0] = __uint_as_float(x.x); v[1] = __uint_as_float(x.y); v[2] = __uint_as_float(x.z); v[3] = __uint_as_float(x.w);
+    }
+};
+template <>
+struct Loader<float, float, 1> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[1]) {
+        v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    }
+};
+template <>
+struct Loader<double, double, 2> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, double (&v)[2]) {
+        u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        v[0] = __hiloint2double((int)x.y, (int)x.x);
+        v[1] = __hiloint2double((int)x.w, (int)x.z);
+    }
+};
+template <>
+struct Loader<double, double, 1> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, double (&v)[1]) {
+        u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        v[0] = __hiloint2double((int)x.y, (int)x.x);
+    }
+};
+template <>
+struct Loader<bf16_t, float, 8> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[8]) {
+        u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+};
+template <>
+struct Loader<bf16_t, float, 1> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[1]) {
+        v[0] = bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+    }
+};
+
+// Scalar global load/store with widening / narrowing (sampling locations, attention weights, outputs).
+__device__ __forceinline__ float ld(const float* p) { return *p; }
+__device__ __forceinline__ double ld(const double* p) { return *p; }
+__device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->bits); }
+__device__ __forceinline__ void st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st(double* p, double v) { *p = v; }
+__device__ __forceinline__ void st(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+
+// Store VEC consecutive outputs (16-byte vector store when VEC * sizeof(T) == 16).
+template <typename T, typename CT, int VEC>
+__device__ __forceinline__ void store_vec(T* p, const CT (&v)[VEC]) {
+    if constexpr (sizeof(T) == 4 && VEC == 4) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else if constexpr (sizeof(T) == 8 && VEC == 2) {
+        *reinterpret_cast<double2*>(p) = double2{(double)v[0], (double)v[1]};
+    } else if constexpr (sizeof(T) == 2 && VEC == 8) {
+        u32x4 o;
+        o.x = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        o.y = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        o.z = f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        o.w = f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        *reinterpret_cast<u32x4*>(p) = o;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) st(p + i, v[i]);
+    }
+}
+
+}  // namespace alo

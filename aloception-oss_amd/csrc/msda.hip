@@ -1,0 +1,457 @@
+// Multi-scale deformable attention for gfx950 (MI355X): forward gather and backward scatter.
+//
+// What is computed is fixed by the reference op (alonet/deformable_detr/ops/src/cuda/ms_deform_im2col_cuda.cuh:
+// forward :237-299 + bilinear :33-84; backward rule :87-159, channel reductions :301-403).  How it is computed is not
+// the reference's one-thread-per-output-element scheme:
+//
+//   * a workgroup owns a contiguous run of (query, head) "pairs" of ONE batch item.  For every pair the L*P sampling
+//     points are turned into descriptors ONCE (corner offsets + corner weights already multiplied by the attention
+//     weight) by all 256 threads and parked in LDS; the reference recomputes them in each of the D channel threads.
+//   * the channel dimension is the coalesced one: G lanes x VEC elements = one 16-byte buffer load per lane, so a
+//     corner of one head is a single 128-byte (fp32, D=32) contiguous request.
+//   * corners outside the map are not branched around: their descriptor carries an out-of-range byte offset and the
+//     buffer resource's bounds check returns 0 without touching memory (zero padding for free, NaN-safe).
+//   * launch-order block ids are remapped so that every XCD (private L2) walks one contiguous range of the batch —
+//     with N = 8 each XCD's L2 holds exactly one image's value map.
+//   * backward: lanes reduce d/d(loc), d/d(attn) over channels with wave shuffles (no LDS, no block barriers, no
+//     serial thread-0 sum), grad_value goes out through hardware fp32/fp64 atomics.
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace alo {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxLevels = 32;
+constexpr int kMetaBytes = 512;  // H[32] | W[32] | start[32] as int32, padded
+
+template <typename CT>
+struct alignas(16) FwdDesc {
+    unsigned off[4];  // byte offset of each corner's (pixel, head 0, channel 0) inside the batch item's value slab
+    CT w[4];          // bilinear corner weight * attention weight (0 for skipped samples)
+};
+template <typename CT>
+struct alignas(16) BwdDesc {
+    unsigned off[4];  // ELEMENT offset of each corner row, 0xFFFFFFFF = corner (or whole sample) not touched
+    CT lh, lw, attn;
+    int lvl;
+};
+constexpr unsigned kNoCorner = 0xFFFFFFFFu;
+
+struct Dims {
+    int S, M, D, L, P;
+    int pairs_per_batch;   // Lq * M
+    int blocks_per_batch;  // workgroups per batch item
+    int iters_per_block;   // runs of (256 / G) pairs handled by one workgroup
+    unsigned nblocks;
+};
+
+// Image-space position, validity and the four corners of one sampling point (cuh:285-291, :38-78).
+template <typename CT>
+struct Tap {
+    bool valid, ok[4];
+    int base;  // pixel index (within the batch item's S rows) of the (h_low, w_low) corner
+    int W;
+    CT lh, lw;
+};
+template <typename CT>
+__device__ __forceinline__ Tap<CT> make_tap(CT loc_x, CT loc_y, int H, int W, int start) {
+    Tap<CT> t;
+    const CT h_im = loc_y * (CT)H - (CT)0.5;
+    const CT w_im = loc_x * (CT)W - (CT)0.5;
+    t.valid = (h_im > (CT)-1) && (w_im > (CT)-1) && (h_im < (CT)H) && (w_im < (CT)W);
+    const CT hs = t.valid ? h_im : (CT)0, ws = t.valid ? w_im : (CT)0;  // keep the int conversion defined
+    const CT hf = floor(hs), wf = floor(ws);
+    const int h_low = (int)hf, w_low = (int)wf;
+    t.lh = hs - hf;
+    t.lw = ws - wf;
+    const bool hl = h_low >= 0, hh = h_low + 1 <= H - 1, wl = w_low >= 0, wh = w_low + 1 <= W - 1;
+    t.ok[0] = t.valid && hl && wl;
+    t.ok[1] = t.valid && hl && wh;
+    t.ok[2] = t.valid && hh && wl;
+    t.ok[3] = t.valid && hh && wh;
+    t.base = start + h_low * W + w_low;
+    t.W = W;
+    return t;
+}
+
+__device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, const int32_t* lstart, int L) {
+    const int t = threadIdx.x;
+    if (t < L) {
+        meta[t] = shapes[2 * t];
+        meta[kMaxLevels + t] = shapes[2 * t + 1];
+        meta[2 * kMaxLevels + t] = lstart[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, int WAVES>
+__global__ void __launch_bounds__(kThreads, WAVES)
+msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
+                const LT* __restrict__ loc, const LT* __restrict__ attn, T* __restrict__ out, const Dims dm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* meta = reinterpret_cast<int*>(smem);
+    unsigned char* dbase = smem + kMetaBytes;
+    using Desc = FwdDesc<CT>;
+    constexpr int PAIRS = kThreads / G;
+    const int LP = LP_CT ? LP_CT : dm.L * dm.P;
+    const int pair_stride = LP * (int)sizeof(Desc) + 16;  // +16 B: pairs of one wave land on distinct LDS slots
+
+    const unsigned lb = xcd_contiguous_block(blockIdx.x, dm.nblocks);
+    const int b = lb / dm.blocks_per_batch;
+    const int chunk = lb % dm.blocks_per_batch;
+    const int tid = threadIdx.x;
+
+    load_meta(meta, shapes, lstart, dm.L);
+    __syncthreads();
+
+    const unsigned row_elems = (unsigned)dm.M * dm.D;
+    const unsigned row_bytes = row_elems * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        make_rsrc(value + (size_t)b * dm.S * row_elems, (unsigned)dm.S * row_bytes);
+    const long batch_pair0 = (long)b * dm.pairs_per_batch;
+
+    for (int it = 0; it < dm.iters_per_block; ++it) {
+        const int pair0 = (chunk * dm.iters_per_block + it) * PAIRS;
+        if (pair0 >= dm.pairs_per_batch) break;  // uniform
+
+        // ---- stage 1: one descriptor per (pair, level, point) ------------------------------------------------------
+        const int nsamp = PAIRS * LP;
+        for (int si = tid; si < nsamp; si += kThreads) {
+            const int pl = si / LP, s = si - pl * LP;
+            const int pair = pair0 + pl;
+            Desc d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { d.off[k] = kOutOfRange; d.w[k] = (CT)0; }
+            if (pair < dm.pairs_per_batch) {
+                const int l = s / dm.P;
+                const long g = (batch_pair0 + pair) * LP + s;
+                const CT x = (CT)ld(loc + 2 * g), y = (CT)ld(loc + 2 * g + 1), a = (CT)ld(attn + g);
+                const Tap<CT> t = make_tap<CT>(x, y, meta[l], meta[kMaxLevels + l], meta[2 * kMaxLevels + l]);
+                const CT hh = (CT)1 - t.lh, hw = (CT)1 - t.lw;
+                const CT w[4] = {hh * hw, hh * t.lw, t.lh * hw, t.lh * t.lw};
+                const int px[4] = {t.base, t.base + 1, t.base + t.W, t.base + t.W + 1};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (t.ok[k]) { d.off[k] = (unsigned)px[k] * row_bytes; d.w[k] = w[k] * a; }
+                }
+            }
+            *reinterpret_cast<Desc*>(dbase + pl * pair_stride + s * (int)sizeof(Desc)) = d;
+        }
+        __syncthreads();
+
+        // ---- stage 2: gather.  G lanes cover the channels of one pair ----------------------------------------------
+        {
+            const int pl = tid / G, lane = tid % G;
+            const int pair = pair0 + pl;
+            if (pair < dm.pairs_per_batch) {
+                const int m = pair % dm.M;
+                const unsigned char* dp = dbase + pl * pair_stride;
+                for (int c0 = lane * VEC; c0 < dm.D; c0 += G * VEC) {
+                    const unsigned coff = (unsigned)(m * dm.D + c0) * (unsigned)sizeof(T);
+                    CT acc[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = (CT)0;
+#pragma unroll LP_CT ? LP_CT : 4
+                    for (int s = 0; s < LP; ++s) {
+                        const Desc d = *reinterpret_cast<const Desc*>(dp + s * (int)sizeof(Desc));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            CT v[VEC];
+                            Loader<T, CT, VEC>::load(rsrc, d.off[k] + coff, v);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) acc[i] += d.w[k] * v[i];
+                        }
+                    }
+                    store_vec<T, CT, VEC>(out + (batch_pair0 + pair) * dm.D + c0, acc);
+                }
+            }
+        }
+        __syncthreads();  // descriptors are rewritten by the next run
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT>
+__global__ void __launch_bounds__(kThreads)
+msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
+                const LT* __restrict__ loc, const LT* __restrict__ attn, const T* __restrict__ grad_out,
+                CT* __restrict__ grad_value, CT* __restrict__ grad_loc, CT* __restrict__ grad_attn, const Dims dm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* meta = reinterpret_cast<int*>(smem);
+    unsigned char* dbase = smem + kMetaBytes;
+    using Desc = BwdDesc<CT>;
+    constexpr int PAIRS = kThreads / G;
+    const int LP = LP_CT ? LP_CT : dm.L * dm.P;
+    const int pair_stride = LP * (int)sizeof(Desc) + 16;
+
+    const unsigned lb = xcd_contiguous_block(blockIdx.x, dm.nblocks);
+    const int b = lb / dm.blocks_per_batch;
+    const int chunk = lb % dm.blocks_per_batch;
+    const int tid = threadIdx.x;
+
+    load_meta(meta, shapes, lstart, dm.L);
+    __syncthreads();
+
+    const unsigned row_elems = (unsigned)dm.M * dm.D;
+    const size_t slab = (size_t)b * dm.S * row_elems;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(value + slab, (unsigned)dm.S * row_elems * (unsigned)sizeof(T));
+    CT* gv = grad_value + slab;
+    const long batch_pair0 = (long)b * dm.pairs_per_batch;
+
+    for (int it = 0; it < dm.iters_per_block; ++it) {
+        const int pair0 = (chunk * dm.iters_per_block + it) * PAIRS;
+        if (pair0 >= dm.pairs_per_batch) break;
+
+        const int nsamp = PAIRS * LP;
+        for (int si = tid; si < nsamp; si += kThreads) {
+            const int pl = si / LP, s = si - pl * LP;
+            const int pair = pair0 + pl;
+            Desc d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d.off[k] = kNoCorner;
+            d.lh = d.lw = d.attn = (CT)0;
+            d.lvl = 0;
+            if (pair < dm.pairs_per_batch) {
+                const int l = s / dm.P;
+                const long g = (batch_pair0 + pair) * LP + s;
+                const CT x = (CT)ld(loc + 2 * g), y = (CT)ld(loc + 2 * g + 1);
+                const Tap<CT> t = make_tap<CT>(x, y, meta[l], meta[kMaxLevels + l], meta[2 * kMaxLevels + l]);
+                const int px[4] = {t.base, t.base + 1, t.base + t.W, t.base + t.W + 1};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (t.ok[k]) d.off[k] = (unsigned)px[k] * row_elems;
+                d.lh = t.lh;
+                d.lw = t.lw;
+                d.attn = (CT)ld(attn + g);
+                d.lvl = t.valid ? l : -1;
+            }
+            *reinterpret_cast<Desc*>(dbase + pl * pair_stride + s * (int)sizeof(Desc)) = d;
+        }
+        __syncthreads();
+
+        {
+            const int pl = tid / G, lane = tid % G;
+            const int pair = pair0 + pl;
+            const bool live = pair < dm.pairs_per_batch;
+            const int m = live ? pair % dm.M : 0;
+            const unsigned char* dp = dbase + pl * pair_stride;
+            const T* go = grad_out + (batch_pair0 + (live ? pair : 0)) * dm.D;
+            // Whole waves walk the samples together (the shuffles below need every lane of a group present).
+            for (int s = 0; s < LP; ++s) {
+                const Desc d = *reinterpret_cast<const Desc*>(dp + s * (int)sizeof(Desc));
+                CT s_attn = (CT)0, s_w = (CT)0, s_h = (CT)0;
+                if (live && d.lvl >= 0) {
+                    const CT hh = (CT)1 - d.lh, hw = (CT)1 - d.lw;
+                    const CT w[4] = {hh * hw, hh * d.lw, d.lh * hw, d.lh * d.lw};
+                    for (int c0 = lane * VEC; c0 < dm.D; c0 += G * VEC) {
+                        const unsigned ch = (unsigned)(m * dm.D + c0);
+                        CT v[4][VEC];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned o = d.off[k] == kNoCorner ? kOutOfRange : (d.off[k] + ch) * (unsigned)sizeof(T);
+                            Loader<T, CT, VEC>::load(rsrc, o, v[k]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const CT top = (CT)ld(go + c0 + i);
+                            const CT tgv = top * d.attn;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (d.off[k] != kNoCorner) unsafeAtomicAdd(gv + d.off[k] + ch + i, w[k] * tgv);
+                            const CT val = w[0] * v[0][i] + w[1] * v[1][i] + w[2] * v[2][i] + w[3] * v[3][i];
+                            const CT ghw = -hw * v[0][i] - d.lw * v[1][i] + hw * v[2][i] + d.lw * v[3][i];
+                            const CT gww = -hh * v[0][i] + hh * v[1][i] - d.lh * v[2][i] + d.lh * v[3][i];
+                            s_attn += top * val;
+                            s_w += gww * tgv;
+                            s_h += ghw * tgv;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int off = G / 2; off > 0; off >>= 1) {
+                    s_attn += __shfl_xor(s_attn, off, 64);
+                    s_w += __shfl_xor(s_w, off, 64);
+                    s_h += __shfl_xor(s_h, off, 64);
+                }
+                if (live && lane == 0) {
+                    const long g = (batch_pair0 + pair) * LP + s;
+                    CT W = (CT)0, H = (CT)0;
+                    if (d.lvl >= 0) { H = (CT)meta[d.lvl]; W = (CT)meta[kMaxLevels + d.lvl]; }
+                    grad_attn[g] = s_attn;
+                    grad_loc[2 * g] = W * s_w;
+                    grad_loc[2 * g + 1] = H * s_h;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------------------------
+struct Plan {
+    int vec, g;
+    bool lp16;
+};
+
+// Kernel-tuning knobs, read once from the environment (results never depend on them).
+//   ALO_MSDA_FWD_WAVES  2 | 4 | 8   occupancy target (waves per SIMD) of the unrolled forward kernel
+//   ALO_MSDA_ITERS      1..64       runs of pairs per workgroup (0 = automatic)
+struct Tuning {
+    int fwd_waves = 4;
+    int iters = 0;
+};
+const Tuning& tuning() {
+    static const Tuning t = [] {
+        Tuning x;
+        if (const char* e = getenv("ALO_MSDA_FWD_WAVES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_waves = v; }
+        if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
+        return x;
+    }();
+    return t;
+}
+
+inline int pick_group(int lanes_needed) {
+    static const int kGroups[] = {4, 8, 16, 64};
+    for (int g : kGroups)
+        if (lanes_needed <= g) return g;
+    return 64;
+}
+
+Plan make_plan(int D, int L, int P, size_t elem, bool aligned16) {
+    Plan p;
+    const int vec = (int)(16 / elem);
+    if (aligned16 && D % vec == 0) {
+        p.vec = vec;
+        p.g = pick_group(D / vec);
+    } else {
+        p.vec = 1;
+        p.g = D <= 8 ? 8 : 64;
+    }
+    p.lp16 = (L * P == 16) && p.vec != 1 && p.g != 64;
+    return p;
+}
+
+Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
+    Dims d;
+    d.S = S; d.M = M; d.D = D; d.L = L; d.P = P;
+    d.pairs_per_batch = Lq * M;
+    const int pairs = kThreads / G;
+    const long iters_total = ((long)d.pairs_per_batch + pairs - 1) / pairs;
+    long ipb = iters_total * N / 4096;  // keep >= ~4096 workgroups in flight when the problem allows it
+    if (ipb < 1) ipb = 1;
+    if (ipb > 8) ipb = 8;
+    if (tuning().iters > 0) ipb = tuning().iters;
+    d.iters_per_block = (int)ipb;
+    d.blocks_per_batch = (int)((iters_total + ipb - 1) / ipb);
+    d.nblocks = (unsigned)(d.blocks_per_batch * N);
+    return d;
+}
+
+template <typename K>
+int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char* what, void** args) {
+    if (lds > 160 * 1024) return fail(ALO_ERR_UNSUPPORTED, "%s: L*P too large for LDS (%zu bytes)", what, lds);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    }
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(dm.nblocks), dim3(kThreads), args, lds,
+                                   stream);
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return check_launch(what);
+}
+
+#define ALO_FWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
+    if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
+        const size_t lds = kMetaBytes + (size_t)(kThreads / G) * ((size_t)L * P * sizeof(FwdDesc<CT>) + 16);       \
+        if (LPCT == 16 && waves == 2)                                                                              \
+            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 2 : 1)>, dm, lds, stream, "alo_msda_forward", args); \
+        if (LPCT == 16 && waves == 8)                                                                              \
+            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 8 : 1)>, dm, lds, stream, "alo_msda_forward", args); \
+        return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 1)>, dm, lds, stream, "alo_msda_forward", args);     \
+    }
+#define ALO_BWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
+    if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
+        const size_t lds = kMetaBytes + (size_t)(kThreads / G) * ((size_t)L * P * sizeof(BwdDesc<CT>) + 16);       \
+        return launch(msda_bwd_kernel<T, LT, CT, VEC, G, LPCT>, dm, lds, stream, "alo_msda_backward", args);       \
+    }
+// every (vector width, group) pair a plan can produce for one dtype
+#define ALO_ALL_CASES(CASE, T, LT, CT, VECW)                                                       \
+    CASE(T, LT, CT, VECW, 4, 16) CASE(T, LT, CT, VECW, 8, 16) CASE(T, LT, CT, VECW, 16, 16)         \
+    CASE(T, LT, CT, VECW, 4, 0) CASE(T, LT, CT, VECW, 8, 0) CASE(T, LT, CT, VECW, 16, 0)            \
+    CASE(T, LT, CT, VECW, 64, 0) CASE(T, LT, CT, 1, 8, 0) CASE(T, LT, CT, 1, 64, 0)
+
+int validate(const void* value, const int32_t* shapes, const int32_t* lstart, const void* loc, const void* attn,
+             int N, int S, int M, int D, int L, int Lq, int P, int vdt, int ldt, size_t* elem_out) {
+    ALO_REQUIRE(value && shapes && lstart && loc && attn, ALO_ERR_INVALID_ARGUMENT, "msda: null pointer argument");
+    ALO_REQUIRE(N > 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq > 0 && P > 0, ALO_ERR_INVALID_ARGUMENT,
+                "msda: dimensions must be positive (N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d)", N, S, M, D, L, Lq, P);
+    ALO_REQUIRE(L <= kMaxLevels, ALO_ERR_UNSUPPORTED, "msda: at most %d levels are supported, got %d", kMaxLevels, L);
+    const bool ok = (vdt == ALO_F32 && ldt == ALO_F32) || (vdt == ALO_F64 && ldt == ALO_F64) ||
+                    (vdt == ALO_BF16 && ldt == ALO_F32);
+    ALO_REQUIRE(ok, ALO_ERR_UNSUPPORTED, "msda: unsupported dtype pair (value=%d, loc=%d)", vdt, ldt);
+    const size_t elem = vdt == ALO_F64 ? 8 : (vdt == ALO_F32 ? 4 : 2);
+    ALO_REQUIRE((double)S * M * D * elem < 3.0 * 1024 * 1024 * 1024, ALO_ERR_UNSUPPORTED,
+                "msda: one batch item of value must stay below 3 GiB");
+    ALO_REQUIRE((double)Lq * M < 2.0e9 && (double)Lq * M * L * P < 9.0e18, ALO_ERR_UNSUPPORTED, "msda: Lq*M too large");
+    *elem_out = elem;
+    return ALO_OK;
+}
+
+}  // namespace
+}  // namespace alo
+
+using namespace alo;
+
+extern "C" int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                const void* sampling_loc, const void* attn_weight, void* out, int N, int S, int M,
+                                int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
+    size_t elem = 0;
+    if (int rc = validate(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P,
+                          value_dtype, loc_dtype, &elem))
+        return rc;
+    ALO_REQUIRE(out, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward: out is null");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool aligned = (((uintptr_t)value | (uintptr_t)out) & 15) == 0;
+    const Plan plan = make_plan(D, L, P, elem, aligned);
+    Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
+    const int waves = tuning().fwd_waves;
+    void* args[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &out, &dm};
+    if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
+    if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_FWD_CASE, double, double, double, 2) }
+    if (value_dtype == ALO_BF16) { ALO_ALL_CASES(ALO_FWD_CASE, bf16_t, float, float, 8) }
+    return fail(ALO_ERR_UNSUPPORTED, "alo_msda_forward: no kernel for vec=%d group=%d", plan.vec, plan.g);
+}
+
+extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                 const void* sampling_loc, const void* attn_weight, const void* grad_out,
+                                 void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M,
+                                 int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
+    size_t elem = 0;
+    if (int rc = validate(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P,
+                          value_dtype, loc_dtype, &elem))
+        return rc;
+    ALO_REQUIRE(grad_out && grad_value && grad_sampling_loc && grad_attn_weight, ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_backward: null gradient pointer");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t gelem = value_dtype == ALO_F64 ? 8 : 4;
+    hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * gelem, stream);
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: memset: %s", hipGetErrorString(e));
+    const bool aligned = (((uintptr_t)value | (uintptr_t)grad_out) & 15) == 0;
+    const Plan plan = make_plan(D, L, P, elem, aligned);
+    Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
+    void* args[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &grad_out,
+                    &grad_value, &grad_sampling_loc, &grad_attn_weight, &dm};
+    if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_BWD_CASE, float, float, float, 4) }
+    if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_BWD_CASE, double, double, double, 2) }
+    if (value_dtype == ALO_BF16) { ALO_ALL_CASES(ALO_BWD_CASE, bf16_t, float, float, 8) }
+    return fail(ALO_ERR_UNSUPPORTED, "alo_msda_backward: no kernel for vec=%d group=%d", plan.vec, plan.g);
+}

@@ -1,0 +1,146 @@
+/*
+ * alo_hotpath.h — C ABI of the MI355X (gfx950) dense-vision hot path of aloception.
+ *
+ * One shared library (libalo_hotpath.so, built from aloception-oss_amd/csrc/ with hipcc) exports exactly the entry
+ * points the reference's own binding for this path would bind.  Plain pointers and sizes only: no torch / ATen types.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *   alo_msda_forward   <- alonet_custom::ms_deform_attn_forward   alonet/deformable_detr/ops/src/vision.cpp:21-24,
+ *                          ms_deform_attn.h:20-39, cuda/ms_deform_attn_cuda.cu:20-80, cuda/ms_deform_im2col_cuda.cuh:237-299
+ *   alo_msda_backward  <- alonet_custom::ms_deform_attn_backward  ms_deform_attn.h:41-62, cuda/ms_deform_attn_cuda.cu:83-153,
+ *                          cuda/ms_deform_im2col_cuda.cuh:87-234,301-920
+ *   alo_corr_build     <- CorrBlock.__init__ / CorrBlock.corr     alonet/raft/corr.py:13-27,52-60
+ *   alo_corr_lookup    <- CorrBlock.__call__ + bilinear_sampler   alonet/raft/corr.py:29-50, alonet/raft/utils/utils.py:5-19
+ *
+ * Conventions (all entry points):
+ *   - every data pointer is a DEVICE pointer on the current HIP device, densely packed ("contiguous") in the layout
+ *     documented per function; the library never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and the call returns
+ *     immediately — same contract as the reference op, which enqueues on the current torch stream;
+ *   - outputs are fully overwritten (the caller does not need to zero them);
+ *   - return value: ALO_OK (0) or an alo_status_t error; alo_last_error() gives a thread-local message.  Argument
+ *     errors are detected before anything is enqueued;
+ *   - stateless and re-entrant; safe to call from several host threads on different streams.
+ */
+#ifndef ALO_HOTPATH_H
+#define ALO_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALO_HOTPATH_ABI_VERSION 1
+
+typedef enum alo_status {
+    ALO_OK = 0,
+    ALO_ERR_INVALID_ARGUMENT = 1, /* null pointer, non-positive dimension, misaligned pointer ...           */
+    ALO_ERR_UNSUPPORTED = 2,      /* dtype combination or size outside what the kernels are built for       */
+    ALO_ERR_LAUNCH = 3            /* the HIP runtime refused the launch (message carries hipGetErrorString)  */
+} alo_status_t;
+
+/* Element types.  For MSDA the reference dispatches float and double (AT_DISPATCH_FLOATING_TYPES,
+ * ms_deform_attn_cuda.cu:64,134); bf16 storage with fp32 arithmetic is this library's addition. */
+typedef enum alo_dtype {
+    ALO_F32 = 0,
+    ALO_F64 = 1,
+    ALO_BF16 = 2
+} alo_dtype_t;
+
+/* ABI version of the loaded library (== ALO_HOTPATH_ABI_VERSION it was built with). */
+int alo_abi_version(void);
+
+/* Message of the last error raised on the calling thread ("" if none).  Never NULL. */
+const char* alo_last_error(void);
+
+/*
+ * Multi-scale deformable attention, forward.
+ *
+ *   out[b,q,m,c] = sum_{l<L} sum_{p<P} attn[b,q,m,l,p] * bilinear(value_l[b,:,m,c]; x = loc_x*W_l - 0.5, y = loc_y*H_l - 0.5)
+ *
+ * A sample is skipped unless y > -1 && x > -1 && y < H_l && x < W_l; each of its four corners is bounds-checked on its
+ * own (zero padding, i.e. grid_sample(align_corners=False, padding_mode="zeros") semantics).
+ *
+ *   value               (N, S, M, D)        value_dtype          S = sum_l H_l*W_l
+ *   spatial_shapes      (L, 2) int32        [H_l, W_l]           (device memory, as in the reference)
+ *   level_start_index   (L,)   int32        first row of level l inside S
+ *   sampling_loc        (N, Lq, M, L, P, 2) loc_dtype            last dim = (x, y), normalised to [0,1] of the padded map
+ *   attn_weight         (N, Lq, M, L, P)    loc_dtype
+ *   out                 (N, Lq, M*D)        value_dtype          m-major, c-minor
+ *
+ * dtype pairs (value_dtype, loc_dtype): (F32,F32) (F64,F64) (BF16,F32) (BF16,BF16).  Arithmetic is fp64 for F64 and
+ * fp32 otherwise.  Any D >= 1 is accepted; D % (16 / sizeof(value element)) == 0 with 16-byte aligned `value`/`out`
+ * takes the vectorised path.  L <= 32.  N*S*M*D*sizeof(element) per batch item must stay below 3 GiB.
+ * The reference's `im2col_step` is a scheduling hint with no effect on results and has no counterpart here.
+ */
+int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                     const void* sampling_loc, const void* attn_weight, void* out,
+                     int N, int S, int M, int D, int L, int Lq, int P,
+                     int value_dtype, int loc_dtype, void* stream);
+
+/*
+ * Multi-scale deformable attention, backward (gradients of the forward above w.r.t. value, sampling_loc, attn_weight).
+ *
+ *   grad_out            (N, Lq, M*D)        value_dtype
+ *   grad_value          (N, S, M, D)        grad dtype           zeroed by this call, then accumulated with atomics
+ *   grad_sampling_loc   (N, Lq, M, L, P, 2) grad dtype           fully written (0 for skipped samples)
+ *   grad_attn_weight    (N, Lq, M, L, P)    grad dtype
+ *
+ * grad dtype is F64 when value_dtype is F64 and F32 otherwise (bf16 storage accumulates its gradients in fp32; the
+ * caller narrows afterwards).  Supported (value_dtype, loc_dtype): (F32,F32) (F64,F64) (BF16,F32) (BF16,BF16).
+ * grad_value is accumulated with hardware floating-point atomics, so — exactly like the reference — its low-order
+ * bits depend on scheduling.
+ */
+int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                      const void* sampling_loc, const void* attn_weight, const void* grad_out,
+                      void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
+                      int N, int S, int M, int D, int L, int Lq, int P,
+                      int value_dtype, int loc_dtype, void* stream);
+
+/* Size of level l of the correlation pyramid of an (H, W) feature grid: level 0 = (H, W), level l+1 = floor(level l / 2)
+ * (F.avg_pool2d(2, stride=2), corr.py:25-27). */
+void alo_corr_level_shape(int H, int W, int level, int* h_out, int* w_out);
+
+/* Bytes of scratch alo_corr_build needs (the 2x2-average pyramid of fmap2 below level 0). */
+size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels);
+
+/*
+ * RAFT all-pairs correlation pyramid.
+ *
+ *   level_0[b*HW + i, 0, y, x] = <fmap1[b,:,i], fmap2[b,:,y*W + x]> / sqrt(C)
+ *   level_{l+1}                = avg_pool2d(level_l, 2, stride 2)        over the last two dims
+ *
+ * computed for every level as one fp32 MFMA contraction of fmap1 against the 2x2-average pyramid of fmap2 (average
+ * pooling commutes with the inner product; results agree with pool-after-correlate to fp32 rounding).
+ *
+ *   fmap1, fmap2   (B, C, H, W) float32
+ *   levels         HOST array of num_levels DEVICE pointers; levels[l] is (B*H*W, 1, h_l, w_l) float32, fully written
+ *   workspace      device scratch of alo_corr_build_workspace_bytes(...) bytes (may be NULL when that is 0)
+ *   1 <= num_levels <= 8.  Levels whose h_l or w_l is 0 are rejected (ALO_ERR_INVALID_ARGUMENT).
+ */
+int alo_corr_build(const float* fmap1, const float* fmap2, float* const* levels, void* workspace,
+                   size_t workspace_bytes, int B, int C, int H, int W, int num_levels, void* stream);
+
+/*
+ * RAFT windowed pyramid lookup.
+ *
+ *   out[b, l*(2r+1)^2 + a*(2r+1) + c, y, x] = bilinear_{align_corners=True, zeros}( level_l[b*HW + y*W + x] ;
+ *                                                 px = coords[b,0,y,x] / 2^l + (a - r),  py = coords[b,1,y,x] / 2^l + (c - r) )
+ *
+ * i.e. the first window axis offsets x and the second offsets y (the reference's meshgrid(dy, dx) ordering).
+ * Coordinates take the reference's round trip px -> 2*px/(w_l-1) - 1 -> ((g+1)/2)*(w_l-1) in fp32.
+ *
+ *   levels   HOST array of num_levels DEVICE pointers as produced by alo_corr_build
+ *   coords   (B, 2, H, W) float32, channel 0 = x, 1 = y, in pixels of the (H, W) grid
+ *   out      (B, num_levels*(2r+1)^2, H, W) float32, fully written
+ *   0 <= radius <= 7,  1 <= num_levels <= 8.  Every level must have h_l, w_l >= 2 (the reference returns NaN otherwise).
+ */
+int alo_corr_lookup(const float* const* levels, const float* coords, float* out,
+                    int B, int H, int W, int radius, int num_levels, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALO_HOTPATH_H */

@@ -1,0 +1,76 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/alo_hotpath.h declares.  CPU only."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import alo_hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "alo_hotpath.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(alo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert declared_functions() == sorted(
+        ["alo_abi_version", "alo_last_error", "alo_msda_forward", "alo_msda_backward", "alo_corr_level_shape",
+         "alo_corr_build_workspace_bytes", "alo_corr_build", "alo_corr_lookup"]
+    )
+
+
+def test_library_exports_every_declared_symbol():
+    lib = alo_hip.lib()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} missing from {alo_hip.LIB_PATH}"
+    assert lib.alo_abi_version() == 1
+    assert lib.alo_last_error() is not None
+
+
+def test_no_torch_symbols_in_the_abi():
+    """The boundary is plain C: the shared object must not link libtorch / libc10."""
+    import subprocess
+
+    needed = subprocess.run(["readelf", "-d", alo_hip.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in needed and "c10" not in needed
+    assert "libamdhip64" in needed
+
+
+def test_pyramid_shape_helpers():
+    assert alo_hip.corr_level_shapes(90, 160, 4) == [(90, 160), (45, 80), (22, 40), (11, 20)]
+    assert alo_hip.corr_level_shapes(17, 18, 4) == [(17, 18), (8, 9), (4, 4), (2, 2)]
+    lib = alo_hip.lib()
+    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 4) == 4 * 256 * (3600 + 880 + 220) * 4
+    assert lib.alo_corr_build_workspace_bytes(1, 8, 16, 16, 1) == 0
+
+
+def test_argument_errors_are_reported_before_any_launch():
+    lib = alo_hip.lib()
+    rc = lib.alo_msda_forward(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, 0, None)
+    assert rc == 1 and b"null pointer" in lib.alo_last_error()
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    rc = lib.alo_msda_forward(one, one, one, one, one, one, 1, 1, 1, 0, 1, 1, 1, 0, 0, None)
+    assert rc == 1 and b"positive" in lib.alo_last_error()
+    rc = lib.alo_msda_forward(one, one, one, one, one, one, 1, 1, 1, 1, 1, 1, 1, 2, 2, None)
+    assert rc == 2 and b"dtype" in lib.alo_last_error()
+    rc = lib.alo_msda_forward(one, one, one, one, one, one, 1, 1, 1, 1, 33, 1, 1, 0, 0, None)
+    assert rc == 2 and b"levels" in lib.alo_last_error()
+    ptrs = (ctypes.c_void_p * 4)(16, 16, 16, 16)
+    rc = lib.alo_corr_lookup(ptrs, one, one, 1, 8, 8, 9, 4, None)
+    assert rc == 2 and b"radius" in lib.alo_last_error()
+    rc = lib.alo_corr_lookup(ptrs, one, one, 1, 8, 8, 4, 4, None)  # level 3 of an 8x8 grid is 1x1
+    assert rc == 1 and b"level 3" in lib.alo_last_error()
+    rc = lib.alo_corr_build(one, one, ptrs, None, 0, 1, 8, 16, 16, 4, None)
+    assert rc == 1 and b"workspace" in lib.alo_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(alo_hip, "_lib", None)
+    monkeypatch.setattr(alo_hip, "LIB_PATH", str(tmp_path / "libalo_hotpath.so"))
+    with pytest.raises(alo_hip.HotpathUnavailable, match="no CPU fallback"):
+        alo_hip.lib()

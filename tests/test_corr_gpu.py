@@ -1,0 +1,152 @@
+"""Parity of the HIP correlation pyramid + lookup (through the C ABI) with the golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import alo_hip
+import oracle as O
+from alonet.raft.corr import CorrBlock
+from alonet.raft.utils.utils import coords_grid
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_g6_pyramid_and_lookup_against_reference_outputs(golden):
+    g = golden("g6_corr.npz")
+    blk = CorrBlock(dev(g["f1"]), dev(g["f2"]), radius=4)
+    assert len(blk.corr_pyramid) == 4
+    for lvl in range(4):
+        got = blk.corr_pyramid[lvl].cpu().numpy()
+        assert got.shape == g[f"lvl{lvl}"].shape
+        np.testing.assert_allclose(got, g[f"lvl{lvl}"], rtol=0, atol=2e-5)  # fp32 summation-order noise, values O(1)
+    for k in "abc":
+        out = blk(dev(g["coords_" + k]))
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        np.testing.assert_allclose(out.cpu().numpy(), g["out_" + k], rtol=0, atol=3e-5)
+    vol = CorrBlock.corr(dev(g["f1"]), dev(g["f2"]))
+    assert vol.shape == (1, 16, 20, 1, 16, 20)
+    np.testing.assert_allclose(vol.reshape(320, 1, 16, 20).cpu().numpy(), g["lvl0"], rtol=0, atol=2e-5)
+
+
+def test_g6_odd_sizes_batched_radius3(golden):
+    g = golden("g6_corr.npz")
+    blk = CorrBlock(dev(g["f1o"]), dev(g["f2o"]), radius=3)
+    for lvl in range(4):
+        np.testing.assert_allclose(blk.corr_pyramid[lvl].cpu().numpy(), g[f"lvl{lvl}o"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(blk(dev(g["coords_o"])).cpu().numpy(), g["out_o"], rtol=0, atol=1e-5)
+
+
+def test_lookup_alone_on_the_reference_pyramid(golden):
+    """Feed the reference's own pyramid to the lookup kernel: isolates the gather from the GEMM."""
+    g = golden("g6_corr.npz")
+    levels = [dev(g[f"lvl{lvl}"]) for lvl in range(4)]
+    for k in "abc":
+        out = alo_hip.corr_lookup(levels, dev(g["coords_" + k]), 4).cpu().numpy()
+        np.testing.assert_allclose(out, g["out_" + k], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,C,H,W,r,L", [(2, 256, 24, 32, 4, 4), (1, 64, 19, 23, 4, 3), (3, 37, 16, 18, 2, 4),
+                                         (1, 128, 33, 47, 1, 2), (1, 16, 40, 40, 7, 4), (2, 8, 16, 16, 0, 1)])
+def test_build_and_lookup_vs_oracle(B, C, H, W, r, L):
+    rng = np.random.default_rng(B * 1000 + C + H)
+    f1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    f2 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    ref_pyr = O.corr_pyramid(f1, f2, L)
+    levels = alo_hip.corr_build(dev(f1), dev(f2), L)
+    for lvl in range(L):
+        got = levels[lvl].cpu().numpy()
+        assert got.shape == ref_pyr[lvl].shape
+        np.testing.assert_allclose(got, ref_pyr[lvl], rtol=0, atol=3e-5)
+    grid = coords_grid(B, H, W).numpy()
+    for spread in (0.0, 3.0, 60.0):
+        coords = (grid + rng.standard_normal(grid.shape) * spread).astype(np.float32)
+        out = alo_hip.corr_lookup(levels, dev(coords), r).cpu().numpy()
+        ref = O.corr_lookup([lv.cpu().numpy() for lv in levels], coords, r)  # same pyramid: isolates the gather
+        assert out.shape == (B, L * (2 * r + 1) ** 2, H, W)
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-5)
+
+
+def test_non_finite_and_huge_coordinates_read_as_zero():
+    rng = np.random.default_rng(9)
+    f = rng.standard_normal((1, 32, 16, 16)).astype(np.float32)
+    levels = alo_hip.corr_build(dev(f), dev(f), 4)
+    coords = coords_grid(1, 16, 16).numpy().copy()
+    coords[0, 0, 0, 0] = np.nan
+    coords[0, 1, 0, 1] = np.inf
+    coords[0, 0, 0, 2] = 3e9
+    coords[0, 1, 0, 3] = -3e9
+    out = alo_hip.corr_lookup(levels, dev(coords), 4).cpu().numpy()
+    assert np.all(out[0, :, 0, :4] == 0) and np.isfinite(out).all()
+    ref = O.corr_lookup([lv.cpu().numpy() for lv in levels], coords, 4)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-5)
+
+
+def test_full_size_properties_720p():
+    """BASELINE config 3 grid (90x160, C=256), one pair: properties that need no CPU pass over 830 MB."""
+    B, C, H, W = 1, 256, 90, 160
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    f1 = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    f2 = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    blk = CorrBlock(f1, f2)
+    assert [tuple(p.shape) for p in blk.corr_pyramid] == [(14400, 1, 90, 160), (14400, 1, 45, 80),
+                                                          (14400, 1, 22, 40), (14400, 1, 11, 20)]
+    lvl0 = blk.corr_pyramid[0].view(H * W, H * W)
+    # (1) transpose symmetry: corr(f1, f2)[i, j] == corr(f2, f1)[j, i] (same products, same k order) -> bit equal
+    swapped = CorrBlock.corr(f2, f1).view(H * W, H * W)
+    assert torch.equal(lvl0, swapped.t())
+    # (2) a slab of rows against torch's own fp32 matmul
+    rows = torch.arange(0, H * W, 97, device=DEV)
+    ref = (f1.view(C, -1)[:, rows].t().double() @ f2.view(C, -1).double()) / 16.0
+    assert (lvl0[rows].double() - ref).abs().max().item() <= 2e-5
+    # (3) pyramid consistency: level l+1 equals the 2x2 mean of level l (pool-after-correlate) to fp32 rounding
+    for lvl in range(3):
+        pooled = torch.nn.functional.avg_pool2d(blk.corr_pyramid[lvl][::53], 2, stride=2)
+        assert (blk.corr_pyramid[lvl + 1][::53] - pooled).abs().max().item() <= 2e-5
+    # (4) lookup at integer coordinates: centre tap of level 0 is the volume entry itself, window taps its neighbours
+    coords = coords_grid(B, H, W, device=DEV)
+    out = blk(coords)
+    assert out.shape == (1, 324, 90, 160)
+    centre = out[0, 4 * 9 + 4].reshape(-1)
+    diag = lvl0.diagonal()
+    assert (centre - diag).abs().max().item() <= 1e-4 * diag.abs().max().item()
+    right = out[0, 5 * 9 + 4, :, :-1].reshape(-1)  # a = 5 -> x + 1
+    ii = torch.arange(H * W, device=DEV).view(H, W)[:, :-1].reshape(-1)
+    assert (right - lvl0[ii, ii + 1]).abs().max().item() <= 1e-4 * diag.abs().max().item()
+    down = out[0, 4 * 9 + 5, :-1, :].reshape(-1)  # c = 5 -> y + 1
+    jj = torch.arange(H * W, device=DEV).view(H, W)[:-1, :].reshape(-1)
+    assert (down - lvl0[jj, jj + W]).abs().max().item() <= 1e-4 * diag.abs().max().item()
+    # (5) sub-pixel lookups against the oracle on a strided subset of queries (oracle on 1/64 of the volume)
+    coords2 = coords + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 3.0
+    out2 = blk(coords2).cpu().numpy()
+    sel = np.arange(0, H * W, 64)
+    pyr_sel = [p[sel].cpu().numpy() for p in blk.corr_pyramid]
+    csel = coords2.view(2, -1)[:, sel].cpu().numpy()
+    # oracle expects (B,2,H,W) coords with one volume row per query: present the subset as a 1 x len(sel) grid
+    # whose volumes keep their true (h_l, w_l) shapes
+    import ctypes
+    n = len(sel)
+    o = np.empty((1, 324, 1, n), np.float32)
+    ptrs = (ctypes.c_void_p * 4)(*[p.ctypes.data for p in pyr_sel])
+    hw = np.array([[p.shape[2], p.shape[3]] for p in pyr_sel], np.int32)
+    cc = np.ascontiguousarray(csel.reshape(1, 2, 1, n))
+    O.lib().oracle_corr_lookup(ptrs, hw.ctypes.data_as(ctypes.c_void_p), cc.ctypes.data_as(ctypes.c_void_p),
+                               o.ctypes.data_as(ctypes.c_void_p), 1, 1, n, 4, 4)
+    np.testing.assert_allclose(out2.reshape(324, -1)[:, sel], o.reshape(324, n), rtol=0, atol=2e-5)
+
+
+def test_batch_items_are_independent():
+    rng = np.random.default_rng(21)
+    f1 = dev(rng.standard_normal((3, 64, 16, 24)).astype(np.float32))
+    f2 = dev(rng.standard_normal((3, 64, 16, 24)).astype(np.float32))
+    coords = coords_grid(3, 16, 24, device=DEV) + 1.5
+    full = CorrBlock(f1, f2)
+    solo = CorrBlock(f1[1:2].contiguous(), f2[1:2].contiguous())
+    n = 16 * 24
+    for lvl in range(4):
+        assert torch.equal(full.corr_pyramid[lvl][n:2 * n], solo.corr_pyramid[lvl])
+    assert torch.equal(full(coords)[1], solo(coords[1:2])[0])

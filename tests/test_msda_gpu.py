@@ -1,0 +1,239 @@
+"""Parity of the HIP multi-scale deformable attention (through the C ABI) with the golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import alo_hip
+import oracle as O
+from helpers import DETR_SHAPES, level_start, msda_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    x = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return x.to(dtype) if dtype is not None else x
+
+
+def hip_forward(c, dtype):
+    return alo_hip.msda_forward(dev(c["value"], dtype), dev(c["shapes"]), dev(c["level_start"]),
+                                dev(c["loc"], dtype), dev(c["attn"], dtype), 64)
+
+
+def hip_backward(c, dtype):
+    return alo_hip.msda_backward(dev(c["value"], dtype), dev(c["shapes"]), dev(c["level_start"]),
+                                 dev(c["loc"], dtype), dev(c["attn"], dtype), dev(c["grad_out"], dtype), 64)
+
+
+def test_native_library_is_the_one_running():
+    assert alo_hip.is_available()
+    assert "libalo_hotpath.so" in open("/proc/self/maps").read()
+
+
+# ---- golden vectors (reference outputs) -------------------------------------------------------------------------
+def test_g1_reference_optest_case_fp64_and_fp32(golden):
+    g = golden("g1_msda_optest.npz")
+    c = dict(value=g["value"], shapes=g["shapes"], level_start=g["level_start"], loc=g["loc"], attn=g["attn"])
+    out = hip_forward(c, torch.float64).cpu().numpy()
+    np.testing.assert_allclose(out, g["out_f64"], rtol=1e-5, atol=1e-8)  # torch.allclose defaults (ops/test.py:62)
+    np.testing.assert_allclose(out, g["out_f64"], rtol=1e-12, atol=1e-15)  # and in fact to rounding
+    c = dict(value=g["value_b"], shapes=g["shapes"], level_start=g["level_start"], loc=g["loc_b"], attn=g["attn_b"])
+    out = hip_forward(c, torch.float32).cpu().numpy()
+    np.testing.assert_allclose(out, g["out_f32"], rtol=1e-2, atol=1e-3)  # the reference's fp32 bar (ops/test.py:83)
+    np.testing.assert_allclose(out, g["out_f32"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("D", [30, 32, 64, 71])
+def test_g2_gradcheck_set_fp64(golden, D):
+    g = golden(f"g2_msda_grad_D{D}.npz")
+    c = {k: g[k] for k in ("value", "shapes", "level_start", "loc", "attn", "grad_out")}
+    np.testing.assert_allclose(hip_forward(c, torch.float64).cpu().numpy(), g["out"], rtol=1e-12, atol=1e-15)
+    gv, gl, ga = (x.cpu().numpy() for x in hip_backward(c, torch.float64))
+    np.testing.assert_allclose(gv, g["grad_value"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(gl, g["grad_loc"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(ga, g["grad_attn"], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+def test_g3_borders_fwd_bwd(golden, dtype, atol):
+    g = golden("g3_msda_medium.npz")
+    c = {k: g[k] for k in ("value", "shapes", "level_start", "loc", "attn", "grad_out")}
+    np.testing.assert_allclose(hip_forward(c, dtype).double().cpu().numpy(), g["out"], rtol=0, atol=atol)
+    gv, gl, ga = (x.double().cpu().numpy() for x in hip_backward(c, dtype))
+    np.testing.assert_allclose(gv, g["grad_value"], rtol=1e-5, atol=max(atol, 2e-6))
+    np.testing.assert_allclose(gl, g["grad_loc"], rtol=1e-5, atol=2e-4)  # |grad_loc| reaches 160 here
+    np.testing.assert_allclose(ga, g["grad_attn"], rtol=1e-5, atol=max(atol, 1e-5))
+
+
+def test_g8_known_answers(golden):
+    g = golden("g8_known_answers.npz")
+    c = {k: g[k] for k in ("value", "shapes", "level_start", "loc", "attn")}
+    np.testing.assert_allclose(hip_forward(c, torch.float64).cpu().numpy().ravel(), g["expected"], atol=1e-15)
+    np.testing.assert_allclose(hip_forward(c, torch.float32).cpu().numpy().ravel(), g["expected"], atol=1e-6)
+
+
+# ---- oracle on seeded inputs: every kernel variant ---------------------------------------------------------------
+CASES = [  # (N, M, D, Lq, shapes, P)          which plan it exercises (fp32)
+    (2, 8, 32, 77, [(16, 21), (8, 11), (4, 6), (2, 3)], 4),  # vec4 / group 8 / unrolled LP=16  (the DETR shape)
+    (1, 8, 32, 300, [(20, 27), (10, 14), (5, 7), (3, 4)], 4),  # decoder-like query count
+    (2, 4, 16, 33, [(9, 7), (5, 4)], 8),  # vec4 / group 4 / unrolled LP=16
+    (1, 2, 64, 19, [(6, 5), (3, 3), (2, 2)], 2),  # vec4 / group 16 / runtime LP
+    (1, 1, 256, 9, [(5, 5)], 3),  # vec4 / group 64
+    (1, 2, 512, 5, [(4, 6)], 2),  # vec4 / group 64, two channel chunks
+    (1, 3, 30, 21, [(6, 4), (3, 2)], 2),  # scalar path (D % 4 != 0), group 64
+    (2, 2, 71, 11, [(6, 4), (3, 2)], 2),  # scalar path, two chunks
+    (1, 2, 2, 2, [(6, 4), (3, 2)], 2),  # scalar path, group 8 (the reference test's D)
+    (1, 2, 8, 13, [(7, 3)], 1),  # vec4 / group 4, L*P = 1
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"N{c[0]}M{c[1]}D{c[2]}Lq{c[3]}L{len(c[4])}P{c[5]}")
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_forward_backward_vs_oracle(case, dtype):
+    N, M, D, Lq, shapes, P = case
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    c = msda_case(1234 + D + Lq, N, M, D, Lq, shapes, P, npdt, loc_range=(-0.3, 1.3))
+    ref = O.msda_forward(c["value"].astype(np.float64), c["shapes"], c["level_start"], c["loc"].astype(np.float64),
+                         c["attn"].astype(np.float64))
+    rgv, rgl, rga = O.msda_backward(c["value"].astype(np.float64), c["shapes"], c["level_start"],
+                                    c["loc"].astype(np.float64), c["attn"].astype(np.float64),
+                                    c["grad_out"].astype(np.float64))
+    out = hip_forward(c, dtype).double().cpu().numpy()
+    gv, gl, ga = (x.double().cpu().numpy() for x in hip_backward(c, dtype))
+    if dtype == torch.float64:
+        tol = dict(rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(out, ref, **tol)
+        np.testing.assert_allclose(gv, rgv, **tol)
+        np.testing.assert_allclose(gl, rgl, rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(ga, rga, **tol)
+    else:  # fp32 kernel against the fp64 oracle on fp32-representable inputs: <= 1e-5 abs at O(1) values
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gv, rgv, rtol=1e-4, atol=2e-5)
+        scale = max(1.0, np.abs(rgl).max())
+        np.testing.assert_allclose(gl, rgl, rtol=1e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(ga, rga, rtol=1e-4, atol=1e-4)
+
+
+def test_bf16_storage_matches_oracle_on_bf16_rounded_inputs():
+    """bf16 value/out, fp32 geometry and accumulation: only the final rounding of `out` separates it from the oracle."""
+    c = msda_case(77, 2, 8, 32, 50, [(16, 21), (8, 11), (4, 6), (2, 3)], 4, np.float32)
+    vb = dev(c["value"]).bfloat16()
+    out = alo_hip.msda_forward(vb, dev(c["shapes"]), dev(c["level_start"]), dev(c["loc"]), dev(c["attn"]), 64)
+    assert out.dtype == torch.bfloat16
+    ref = O.msda_forward(vb.float().cpu().numpy().astype(np.float64), c["shapes"], c["level_start"],
+                         c["loc"].astype(np.float64), c["attn"].astype(np.float64))
+    err = np.abs(out.float().cpu().numpy() - ref)
+    assert np.all(err <= np.abs(ref) * 2.0 ** -8 + 1e-6)  # half an ulp of bf16 (8 significant bits) + fp32 noise
+    # gradients of the bf16 path accumulate in fp32
+    go = dev(c["grad_out"]).bfloat16()
+    gv, gl, ga = alo_hip.msda_backward(vb, dev(c["shapes"]), dev(c["level_start"]), dev(c["loc"]), dev(c["attn"]), go, 64)
+    rgv, rgl, rga = O.msda_backward(vb.float().cpu().numpy().astype(np.float64), c["shapes"], c["level_start"],
+                                    c["loc"].astype(np.float64), c["attn"].astype(np.float64),
+                                    go.float().cpu().numpy().astype(np.float64))
+    assert gv.dtype == torch.bfloat16 and gl.dtype == torch.float32
+    np.testing.assert_allclose(gl.cpu().numpy(), rgl, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(ga.cpu().numpy(), rga, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gv.float().cpu().numpy(), rgv, rtol=2.0 ** -7, atol=1e-3)
+
+
+def test_nan_outside_the_sampled_footprint_does_not_leak():
+    """Corners outside the map are never read (buffer bounds check), as in the reference's guarded loads."""
+    c = msda_case(5, 1, 2, 32, 6, [(4, 4)], 2, np.float32, loc_range=(1.2, 1.6))  # every sample is out of range
+    c["value"][:] = np.nan
+    out = hip_forward(c, torch.float32).cpu().numpy()
+    assert np.all(out == 0)
+
+
+# ---- reference-style API on the GPU ------------------------------------------------------------------------------
+def test_autograd_function_and_gradcheck():
+    from alonet.deformable_detr.ops.functions import MSDeformAttnFunction
+
+    for D in (30, 32):  # ops/test.py:130-131 runs gradcheck for D in {30, 32, 64, 71}
+        c = msda_case(3 + D, 1, 2, D, 2, [(6, 4), (3, 2)], 2, np.float64, loc_range=(0.0, 1.0))
+        c["value"] *= 0.01
+        value = dev(c["value"]).requires_grad_(True)
+        loc = dev(c["loc"]).requires_grad_(True)
+        attn = dev(c["attn"]).requires_grad_(True)
+        assert torch.autograd.gradcheck(MSDeformAttnFunction.apply,
+                                        (value, dev(c["shapes"]), dev(c["level_start"]), loc, attn, 2))
+
+
+def test_module_on_gpu_matches_reference_module(golden):
+    from alonet.deformable_detr.ops.modules import MSDeformAttn
+
+    g = golden("g4_msda_module.npz")
+    d_model, n_levels, n_heads, n_points = (int(x) for x in g["cfg"])
+    m = MSDeformAttn(d_model, n_levels, n_heads, n_points).double()
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    m = m.to(DEV)
+    shapes = dev(g["shapes"]).to(torch.int32)
+    with torch.no_grad():
+        out2 = m(dev(g["query"]), dev(g["ref2"]), dev(g["src"]), shapes, dev(g["level_start"]), dev(g["mask"]))
+        out4 = m(dev(g["query"]), dev(g["ref4"]), dev(g["src"]), shapes, dev(g["level_start"]), dev(g["mask"]))
+    np.testing.assert_allclose(out2.cpu().numpy(), g["out2"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(out4.cpu().numpy(), g["out4"], rtol=1e-10, atol=1e-11)
+    m32 = m.float()
+    with torch.no_grad():
+        o32 = m32(dev(g["query"]).float(), dev(g["ref2"]).float(), dev(g["src"]).float(), shapes,
+                  dev(g["level_start"]), dev(g["mask"]))
+    np.testing.assert_allclose(o32.cpu().numpy(), g["out2"], rtol=1e-3, atol=1e-3)  # north-star bar: <= 1e-3 max-abs
+
+
+def test_error_behaviour_matches_the_reference_op():
+    c = msda_case(1, 2, 2, 8, 3, [(4, 4)], 2, np.float32)
+    v, sh, st, loc, attn = dev(c["value"]), dev(c["shapes"]), dev(c["level_start"]), dev(c["loc"]), dev(c["attn"])
+    with pytest.raises(RuntimeError, match="value tensor has to be contiguous"):
+        alo_hip.msda_forward(v.transpose(2, 3), sh, st, loc, attn, 64)
+    with pytest.raises(RuntimeError, match="sampling_loc must be a CUDA tensor"):
+        alo_hip.msda_forward(v, sh, st, loc.cpu(), attn, 64)
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        torch.ops.alonet_custom.ms_deform_attn_forward(torch.cat([v, v[:1]]), sh, st, torch.cat([loc, loc[:1]]),
+                                                       torch.cat([attn, attn[:1]]), 2)
+    out_a = alo_hip.msda_forward(v, sh, st, loc, attn, 1)  # im2col_step is a hint: results do not depend on it
+    out_b = alo_hip.msda_forward(v, sh, st, loc, attn, 64)
+    assert torch.equal(out_a, out_b)
+
+
+# ---- BASELINE.json sizes: size-independent properties + oracle on the full encoder call --------------------------
+def _full_size_case(N, Lq, seed):
+    rng = np.random.default_rng(seed)
+    shapes = np.asarray(DETR_SHAPES, np.int32)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = rng.standard_normal((N, S, 8, 32)).astype(np.float32)
+    loc = rng.uniform(-0.05, 1.05, (N, Lq, 8, 4, 4, 2)).astype(np.float32)
+    attn = rng.random((N, Lq, 8, 4, 4)).astype(np.float32)
+    attn /= attn.reshape(N, Lq, 8, 16).sum(-1)[..., None, None]
+    return dict(value=value, shapes=shapes, level_start=level_start(shapes), loc=loc, attn=attn)
+
+
+def test_full_size_encoder_call_vs_oracle():
+    """One batch item of the config-2 encoder call (S = Lq = 22223, M=8, D=32, L=P=4) against the C oracle."""
+    c = _full_size_case(1, 22223, 11)
+    out = hip_forward(c, torch.float32).cpu().numpy()
+    ref = O.msda_forward(c["value"], c["shapes"], c["level_start"], c["loc"], c["attn"])  # fp32 oracle, same inputs
+    assert np.abs(out - ref).max() <= 1e-5
+
+
+def test_full_size_properties_batch8():
+    """Linearity in `value`, batch independence and constant reproduction at N=8 (the bench workload)."""
+    c = _full_size_case(8, 22223, 12)
+    sh, st = dev(c["shapes"]), dev(c["level_start"])
+    v, loc, attn = dev(c["value"]), dev(c["loc"]), dev(c["attn"])
+    out = alo_hip.msda_forward(v, sh, st, loc, attn, 64)
+    # (1) linear in value
+    out2 = alo_hip.msda_forward(v * 2.0 + 1.0, sh, st, loc, attn, 64)
+    ones = alo_hip.msda_forward(torch.ones_like(v), sh, st, loc, attn, 64)
+    assert (out2 - (2.0 * out + ones)).abs().max().item() <= 2e-5
+    # (2) a constant map is reproduced times the in-range bilinear mass, which never exceeds the attention mass (1)
+    assert ones.max().item() <= 1.0 + 1e-5 and ones.min().item() >= 0.0
+    inner = alo_hip.msda_forward(torch.ones_like(v), sh, st, loc.clamp(0.2, 0.8), attn, 64)
+    assert (inner - 1.0).abs().max().item() <= 1e-5  # all four corners inside: weights sum to exactly one
+    # (3) batch items are independent: item 3 alone gives the same bits
+    solo = alo_hip.msda_forward(v[3:4].contiguous(), sh, st, loc[3:4].contiguous(), attn[3:4].contiguous(), 64)
+    assert torch.equal(solo[0], out[3])
+    # (4) bf16 storage stays within bf16 rounding of the fp32 result on the same (bf16-rounded) values
+    vb = v.bfloat16()
+    ob = alo_hip.msda_forward(vb, sh, st, loc, attn, 64).float()
+    of = alo_hip.msda_forward(vb.float(), sh, st, loc, attn, 64)
+    assert ((ob - of).abs() <= of.abs() * 2.0 ** -8 + 1e-6).all()

@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Kernel-level micro-benchmarks of the hot path at BASELINE.json sizes (HIP events on the launch stream).
+
+    python tools/kbench.py [--which msda_enc,msda_dec,msda_bwd,corr_build,corr_lookup] [--reps 20] [--dtype f32|bf16]
+
+Prints one JSON object per kernel: average launch time, algorithmic bytes / flops (SURVEY.md section 8d formulas),
+achieved GB/s or TFLOP/s.  Tuning knobs are environment variables of the library (ALO_MSDA_FWD_WAVES, ALO_MSDA_ITERS).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "aloception-oss_amd"))
+import alo_hip  # noqa: E402
+
+DETR_SHAPES = [(100, 167), (50, 84), (25, 42), (13, 21)]
+DEV = "cuda:0"
+
+
+def time_launches(fn, reps, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        fn()
+    stop.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(stop) / reps * 1e-3  # seconds per launch
+
+
+def detr_geometry(device=DEV):
+    shapes = torch.tensor(DETR_SHAPES, dtype=torch.int32, device=device)
+    start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]]).to(torch.int32)
+    return shapes, start, int((shapes[:, 0] * shapes[:, 1]).sum())
+
+
+def encoder_like_locations(N, M=8, L=4, P=4, jitter=0.5, seed=0, device=DEV):
+    """Query = every pixel of every level; sampling points = the module's initial ring (head direction x (p+1) pixels)
+    around the query's own position on every level, plus sub-pixel jitter.  (N, S, M, L, P, 2) float32."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    refs = []
+    for (h, w) in DETR_SHAPES:
+        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+        refs.append(torch.stack([(xs.reshape(-1) + 0.5) / w, (ys.reshape(-1) + 0.5) / h], -1))
+    ref = torch.cat(refs, 0)  # (S, 2) normalised (x, y)
+    S = ref.shape[0]
+    ang = torch.arange(M, device=device, dtype=torch.float32) * (2 * torch.pi / M)
+    ring = torch.stack([ang.cos(), ang.sin()], -1)
+    ring = ring / ring.abs().max(-1, keepdim=True)[0]  # (M, 2)
+    steps = torch.arange(1, P + 1, device=device, dtype=torch.float32)  # (P,)
+    off_px = ring[:, None, None, :] * steps[None, None, :, None]  # (M,1,P,2) pixels
+    norm = torch.tensor([[w, h] for h, w in DETR_SHAPES], device=device, dtype=torch.float32)  # (L,2) = (W,H)
+    off = off_px / norm[None, :, None, :]  # (M,L,P,2)
+    loc = ref[None, :, None, None, None, :] + off[None, None]
+    loc = loc.expand(N, S, M, L, P, 2).contiguous()
+    loc += (torch.rand(loc.shape, generator=gen, device=device) - 0.5) * 2 * jitter / norm[None, None, None, :, None, :]
+    return loc
+
+
+def msda_inputs(N, Lq, kind, dtype, seed=0):
+    shapes, start, S = detr_geometry()
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    value = torch.randn(N, S, 8, 32, generator=gen, device=DEV).to(dtype)
+    if kind == "encoder":
+        assert Lq == S
+        loc = encoder_like_locations(N, seed=seed)
+    else:
+        loc = torch.rand(N, Lq, 8, 4, 4, 2, generator=gen, device=DEV)
+    attn = torch.softmax(torch.randn(N, Lq, 8, 16, generator=gen, device=DEV), -1).view(N, Lq, 8, 4, 4)
+    return value, shapes, start, loc, attn
+
+
+def msda_fwd_bytes(N, S, Lq, elem, M=8, D=32, L=4, P=4, loc_elem=4):
+    return elem * (N * S * M * D + N * Lq * M * D) + loc_elem * (N * Lq * M * L * P * 3)
+
+
+def msda_bwd_bytes(N, S, Lq, elem, M=8, D=32, L=4, P=4, loc_elem=4):
+    return elem * (2 * N * S * M * D + N * Lq * M * D) + loc_elem * (N * Lq * M * L * P * 3 * 2)
+
+
+def bench_msda_fwd(N, Lq, kind, dtype, reps):
+    value, shapes, start, loc, attn = msda_inputs(N, Lq, kind, dtype)
+    t = time_launches(lambda: alo_hip.msda_forward(value, shapes, start, loc, attn), reps)
+    nbytes = msda_fwd_bytes(N, value.shape[1], Lq, value.element_size())
+    return dict(kernel=f"msda_fwd[{kind}]", N=N, Lq=Lq, dtype=str(dtype).split(".")[-1], ms=t * 1e3,
+                alg_bytes=nbytes, GBps=nbytes / t / 1e9)
+
+
+def bench_msda_bwd(N, Lq, kind, dtype, reps):
+    value, shapes, start, loc, attn = msda_inputs(N, Lq, kind, dtype)
+    go = torch.randn(N, Lq, 256, device=DEV).to(dtype)
+    t = time_launches(lambda: alo_hip.msda_backward(value, shapes, start, loc, attn, go), reps)
+    nbytes = msda_bwd_bytes(N, value.shape[1], Lq, value.element_size())
+    return dict(kernel=f"msda_bwd[{kind}]", N=N, Lq=Lq, dtype=str(dtype).split(".")[-1], ms=t * 1e3,
+                alg_bytes=nbytes, GBps=nbytes / t / 1e9)
+
+
+def corr_inputs(B, C=256, H=90, W=160, seed=0):
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(B, C, H, W, generator=gen, device=DEV), torch.randn(B, C, H, W, generator=gen, device=DEV))
+
+
+def bench_corr_build(B, reps, H=90, W=160, C=256):
+    f1, f2 = corr_inputs(B, C, H, W)
+    shapes = alo_hip.corr_level_shapes(H, W, 4)
+    HW = H * W
+    levels = [torch.empty((B * HW, 1, h, w), device=DEV) for h, w in shapes]
+    import ctypes
+    nbytes_ws = alo_hip.lib().alo_corr_build_workspace_bytes(B, C, H, W, 4)
+    ws = torch.empty(nbytes_ws // 4, device=DEV)
+    ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in levels])
+
+    def run():
+        rc = alo_hip.lib().alo_corr_build(f1.data_ptr(), f2.data_ptr(), ptrs, ws.data_ptr(), nbytes_ws, B, C, H, W, 4,
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, alo_hip.lib().alo_last_error()
+
+    t = time_launches(run, reps)
+    ncols = sum(h * w for h, w in shapes)
+    flops_l0 = 2.0 * B * HW * HW * C  # 2*HW^2*C per pair (level 0, what the reference's matmul does)
+    flops_all = 2.0 * B * HW * ncols * C  # what the all-levels contraction executes
+    nbytes = 4 * (2 * B * C * HW + B * HW * ncols)
+    return dict(kernel="corr_build", B=B, ms=t * 1e3, alg_flops=flops_l0, exec_flops=flops_all,
+                TFLOPs_alg=flops_l0 / t / 1e12, TFLOPs_exec=flops_all / t / 1e12, alg_bytes=nbytes,
+                GBps=nbytes / t / 1e9)
+
+
+def bench_corr_lookup(B, reps, H=90, W=160, C=256):
+    f1, f2 = corr_inputs(B, C, H, W)
+    levels = alo_hip.corr_build(f1, f2, 4)
+    ys, xs = torch.meshgrid(torch.arange(H, device=DEV), torch.arange(W, device=DEV), indexing="ij")
+    coords = torch.stack([xs, ys]).float()[None].repeat(B, 1, 1, 1) + torch.randn(B, 2, H, W, device=DEV) * 4.0
+    t = time_launches(lambda: alo_hip.corr_lookup(levels, coords, 4), reps)
+    HW = H * W
+    nbytes = 4 * B * (HW * 324 + HW * 4 * 100 + 2 * HW)
+    return dict(kernel="corr_lookup", B=B, ms=t * 1e3, alg_bytes=nbytes, GBps=nbytes / t / 1e9)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="msda_enc,msda_dec,msda_rand,msda_bwd,corr_build,corr_lookup")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="f32,bf16")
+    ap.add_argument("--N", type=int, default=8)
+    ap.add_argument("--B", type=int, default=4)
+    a = ap.parse_args()
+    dts = [dict(f32=torch.float32, bf16=torch.bfloat16, f64=torch.float64)[d] for d in a.dtype.split(",")]
+    S = sum(h * w for h, w in DETR_SHAPES)
+    tags = {k: os.environ[k] for k in os.environ if k.startswith("ALO_")}
+    for w in a.which.split(","):
+        res = []
+        if w == "msda_enc":
+            res = [bench_msda_fwd(a.N, S, "encoder", dt, a.reps) for dt in dts]
+        elif w == "msda_rand":
+            res = [bench_msda_fwd(a.N, S, "uniform", dt, a.reps) for dt in dts]
+        elif w == "msda_dec":
+            res = [bench_msda_fwd(a.N, 300, "uniform", dt, a.reps) for dt in dts]
+        elif w == "msda_bwd":
+            res = [bench_msda_bwd(4, S, "encoder", torch.float32, max(3, a.reps // 4))]
+        elif w == "corr_build":
+            res = [bench_corr_build(a.B, max(3, a.reps // 4))]
+        elif w == "corr_lookup":
+            res = [bench_corr_lookup(a.B, a.reps)]
+        for r in res:
+            r.update(tags)
+            print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
