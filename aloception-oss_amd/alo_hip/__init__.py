@@ -107,6 +107,71 @@ def _require_cuda_contiguous(named):
             raise RuntimeError(f"{name} must be a CUDA tensor")
 
 
+class LaunchTimer:
+    """Times every kernel launch made through this module with HIP events recorded on the launch stream.
+
+    ``with alo_hip.LaunchTimer() as t: ...``; afterwards ``t.summary()`` maps a kernel tag (e.g. ``"msda_fwd/Lq=22223"``)
+    to ``dict(calls, ms_total, ms_avg, alg_bytes_avg, alg_flops_avg)``.  Used by bench.py for the roofline numbers:
+    the algorithmic byte / flop counts are the SURVEY.md section 8(d) formulas evaluated on the actual launch shape.
+    """
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _timer
+        self._prev, _timer = _timer, self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = self._prev
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, start, stop, nbytes, flops in self.records:
+            d = out.setdefault(tag, dict(calls=0, ms_total=0.0, alg_bytes_avg=0.0, alg_flops_avg=0.0))
+            d["calls"] += 1
+            d["ms_total"] += start.elapsed_time(stop)
+            d["alg_bytes_avg"] += nbytes
+            d["alg_flops_avg"] += flops
+        for d in out.values():
+            d["ms_avg"] = d["ms_total"] / d["calls"]
+            d["alg_bytes_avg"] /= d["calls"]
+            d["alg_flops_avg"] /= d["calls"]
+        return out
+
+
+_timer = None
+
+
+class _timed:
+    def __init__(self, tag, nbytes=0.0, flops=0.0):
+        self.tag, self.nbytes, self.flops = tag, nbytes, flops
+
+    def __enter__(self):
+        if _timer is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.stop = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            self.stop.record()
+            _timer.records.append((self.tag, self.start, self.stop, self.nbytes, self.flops))
+
+
+def msda_forward_bytes(N, S, M, D, L, Lq, P, elem, loc_elem=4):
+    """Algorithmic HBM bytes of one forward launch: value once + out once + (loc, attn) once."""
+    return elem * (N * S * M * D + N * Lq * M * D) + loc_elem * (N * Lq * M * L * P * 3)
+
+
+def msda_backward_bytes(N, S, M, D, L, Lq, P, elem, loc_elem=4):
+    return elem * (2 * N * S * M * D + N * Lq * M * D) + loc_elem * (N * Lq * M * L * P * 3 * 2)
+
+
 def _msda_prepare(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, extra=()):
     if not value.is_cuda:
         raise RuntimeError("Not implemented on the CPU")  # ms_deform_attn.h:38,60
@@ -145,7 +210,8 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
     dims, vdt, ldt, loc, attn = _msda_prepare(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     N, S, M, D, L, Lq, P = dims
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device):
+    nbytes = msda_forward_bytes(N, S, M, D, L, Lq, P, value.element_size(), loc.element_size())
+    with torch.cuda.device(value.device), _timed(f"msda_fwd/Lq={Lq}", nbytes):
         _check(lib().alo_msda_forward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
                                       _ptr(out), N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
     return out
@@ -162,7 +228,8 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
     grad_value = torch.empty(value.shape, dtype=gdt, device=value.device)
     grad_loc = torch.empty(loc.shape, dtype=gdt, device=value.device)
     grad_attn = torch.empty(attn.shape, dtype=gdt, device=value.device)
-    with torch.cuda.device(value.device):
+    nbytes = msda_backward_bytes(N, S, M, D, L, Lq, P, value.element_size(), loc.element_size())
+    with torch.cuda.device(value.device), _timed(f"msda_bwd/Lq={Lq}", nbytes):
         _check(lib().alo_msda_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
                                        _ptr(grad_output), _ptr(grad_value), _ptr(grad_loc), _ptr(grad_attn),
                                        N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
@@ -198,7 +265,9 @@ def corr_build(fmap1, fmap2, num_levels=4):
     nbytes = lib().alo_corr_build_workspace_bytes(B, C, H, W, num_levels)
     ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=fmap1.device)
     ptrs = (ctypes.c_void_p * num_levels)(*[t.data_ptr() for t in levels])
-    with torch.cuda.device(fmap1.device):
+    ncols = sum(h * w for h, w in shapes)
+    with torch.cuda.device(fmap1.device), _timed("corr_build", 4.0 * (2 * B * C * H * W + B * H * W * ncols),
+                                                 2.0 * B * (H * W) * (H * W) * C):
         _check(lib().alo_corr_build(_ptr(fmap1), _ptr(fmap2), ptrs, _ptr(ws), nbytes, B, C, H, W, num_levels,
                                     _stream(fmap1.device)))
     # ws may be released now: the caching allocator keeps the block bound to this stream until the kernels retire
@@ -219,6 +288,8 @@ def corr_lookup(levels, coords, radius=4):
             raise RuntimeError(f"corr_pyramid[{lvl}] must be a contiguous (B*H*W,1,h,w) tensor")
     out = torch.empty((B, L * (2 * radius + 1) ** 2, H, W), dtype=torch.float32, device=coords.device)
     ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in levels])
-    with torch.cuda.device(coords.device):
+    taps = (2 * radius + 2) ** 2
+    nbytes = 4.0 * B * H * W * (L * (2 * radius + 1) ** 2 + L * taps + 2)
+    with torch.cuda.device(coords.device), _timed("corr_lookup", nbytes):
         _check(lib().alo_corr_lookup(ptrs, _ptr(coords), _ptr(out), B, H, W, radius, L, _stream(coords.device)))
     return out

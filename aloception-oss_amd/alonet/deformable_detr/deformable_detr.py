@@ -1,0 +1,254 @@
+"""Deformable-DETR object detector (https://arxiv.org/abs/2010.04159) on the gfx950 multi-scale deformable attention.
+
+Same constructor arguments, state-dict layout, ``forward(frames) -> dict`` and ``inference(forward_out) -> [BoundingBoxes2D]``
+as the reference (alonet/deformable_detr/deformable_detr.py:32-760).  Backbone convolutions, linear layers and
+``nn.MultiheadAttention`` run on stock PyTorch-ROCm; the 12 deformable-attention gathers per forward run on the HIP op.
+TensorRT / TorchScript tracing mode is not provided.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+import aloscene
+from alonet.common import load_weights
+from alonet.detr.misc import assert_and_export_onnx
+from alonet.transformers import MLP, PositionEmbeddingSine
+
+from .backbone import Backbone
+from .deformable_transformer import (
+    DeformableTransformer,
+    DeformableTransformerDecoder,
+    DeformableTransformerDecoderLayer,
+)
+from .utils import inverse_sigmoid
+
+INPUT_MEAN_STD = ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class DeformableDETR(nn.Module):
+    """
+    Parameters
+    ----------
+    backbone : nn.Module            ``Joiner(Backbone, PositionEmbeddingSine)``
+    transformer : nn.Module         ``DeformableTransformer``
+    num_classes : int
+    num_queries : int               detection slots (300)
+    num_feature_levels : int        pyramid levels sampled by the attention (4)
+    aux_loss : bool                 also return the predictions of the intermediate decoder layers
+    with_box_refine : bool          iterative bounding-box refinement
+    weights : str                   checkpoint path or registered name
+    device : torch.device           defaults to cuda (the deformable attention op has no CPU implementation)
+    activation_fn : "sigmoid" | "softmax"   (softmax adds a background class)
+    """
+
+    INPUT_MEAN_STD = INPUT_MEAN_STD
+
+    def __init__(self, backbone, transformer, num_classes, num_queries=300, num_feature_levels=4, aux_loss=True,
+                 with_box_refine=False, return_dec_outputs=False, return_enc_outputs=False, return_bb_outputs=False,
+                 weights=None, device=torch.device("cuda"), activation_fn="sigmoid", return_intermediate_dec=True,
+                 strict_load_weights=True, tracing=False, include_preprocessing=False):
+        super().__init__()
+        if tracing:
+            raise NotImplementedError("tracing / ONNX export mode is not part of this build")
+        if activation_fn not in ("sigmoid", "softmax"):
+            raise Exception(f"activation_fn = {activation_fn} must be one of this two values: 'sigmoid' or 'softmax'.")
+        self.num_feature_levels = num_feature_levels
+        self.backbone = backbone
+        self.num_queries = num_queries
+        self.return_intermediate_dec = return_intermediate_dec
+        self.hidden_dim = hidden = transformer.d_model
+        self.return_dec_outputs = return_dec_outputs
+        self.return_enc_outputs = return_enc_outputs
+        self.return_bb_outputs = return_bb_outputs
+        self.activation_fn = activation_fn
+        self.background_class = num_classes if activation_fn == "softmax" else None
+        num_classes += 1 if activation_fn == "softmax" else 0
+
+        def proj(in_ch, **conv):
+            return nn.Sequential(nn.Conv2d(in_ch, hidden, **conv), nn.GroupNorm(32, hidden))
+
+        if num_feature_levels > 1:
+            n_backbone = len(backbone.strides) - 1  # stride-4 stage is not used by the detector
+            projs = [proj(backbone.num_channels[i], kernel_size=1) for i in range(1, n_backbone + 1)]
+            in_ch = backbone.num_channels[n_backbone]
+            for _ in range(num_feature_levels - n_backbone):
+                projs.append(proj(in_ch, kernel_size=3, stride=2, padding=1))
+                in_ch = hidden
+            self.input_proj = nn.ModuleList(projs)
+        else:
+            self.input_proj = nn.ModuleList([proj(backbone.num_channels[0], kernel_size=1)])
+        self.query_embed = nn.Embedding(num_queries, hidden * 2)
+        self.transformer = transformer
+        self.class_embed = nn.Linear(hidden, num_classes)
+        self.bbox_embed = MLP(hidden, hidden, 4, 3)
+        self.aux_loss = aux_loss
+        self.with_box_refine = with_box_refine
+
+        prior_prob = 0.01
+        self.class_embed.bias.data = torch.ones(num_classes) * -math.log((1 - prior_prob) / prior_prob)
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        for p in self.input_proj:
+            nn.init.xavier_uniform_(p[0].weight, gain=1)
+            nn.init.constant_(p[0].bias, 0)
+
+        self.num_decoder_layers = num_pred = transformer.decoder.num_layers
+        if with_box_refine:
+            self.class_embed = _get_clones(self.class_embed, num_pred)
+            self.bbox_embed = _get_clones(self.bbox_embed, num_pred)
+            nn.init.constant_(self.bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            self.transformer.decoder.bbox_embed = self.bbox_embed
+        else:
+            nn.init.constant_(self.bbox_embed.layers[-1].bias.data[2:], -2.0)
+            self.class_embed = nn.ModuleList([self.class_embed for _ in range(num_pred)])  # one shared head
+            self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(num_pred)])
+            self.transformer.decoder.bbox_embed = None
+
+        self.device = device
+        if device is not None:
+            self.to(device)
+        if weights is not None:
+            load_weights(self, weights, device, strict_load_weights=strict_load_weights)
+
+    # ---- forward ----------------------------------------------------------------------------------------------------
+    @assert_and_export_onnx(check_mean_std=True, input_mean_std=INPUT_MEAN_STD)
+    def forward(self, frames, **kwargs):
+        """frames: batched ``aloscene.Frame`` (B,3,H,W), resnet-normalised, with ``frames.mask`` (1 on padding).
+
+        Returns a dict: ``pred_logits`` (B, num_queries, num_classes), ``pred_boxes`` (B, num_queries, 4) as relative
+        (xc, yc, w, h), ``activation_fn``, and optionally ``aux_outputs`` / ``dec_outputs`` / ``enc_outputs`` /
+        ``bb_lvl*_{src,mask,pos}_outputs``.
+        """
+        if "is_tracing" not in kwargs:  # the pure-torch export branch may run anywhere; the HIP op may not
+            assert next(self.parameters()).is_cuda, "DeformableDETR cannot run on CPU (due to MSdeformable op)"
+        frame_masks = frames.mask.as_tensor()
+        features, pos = self.backbone(frames, **kwargs)
+
+        srcs, masks = [], []
+        for lvl, (src, mask) in enumerate(features[1:]):
+            srcs.append(self.input_proj[lvl](src))
+            masks.append(mask[:, 0])
+        for lvl in range(len(srcs), self.num_feature_levels):  # extra, coarser levels
+            src = self.input_proj[lvl](features[-1][0] if lvl == len(features) - 1 else srcs[-1])
+            mask = F.interpolate(frame_masks.float(), size=src.shape[-2:]).to(torch.bool)
+            pos.append(self.backbone[1]((src, mask)).to(src.dtype))
+            srcs.append(src)
+            masks.append(mask[:, 0])
+
+        transformer_out = self.transformer(srcs, masks, pos[1:], self.query_embed.weight, **kwargs)
+        if self.return_bb_outputs:
+            features[-1] = (srcs[-2], masks[-2])
+        return self.forward_heads(transformer_out, bb_outputs=(features, pos[:-1]))
+
+    def forward_position_heads(self, transformer_outputs):
+        hs = transformer_outputs["hs"]
+        init_ref, inter_refs = transformer_outputs["init_reference_out"], transformer_outputs["inter_references_out"]
+        coords = []
+        for lvl in range(hs.shape[0]):
+            reference = inverse_sigmoid(init_ref if lvl == 0 else inter_refs[lvl - 1])
+            tmp = self.bbox_embed[lvl](hs[lvl])
+            if reference.shape[-1] == 4:
+                tmp = tmp + reference
+            else:
+                assert reference.shape[-1] == 2
+                tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], -1)
+            coords.append(tmp.sigmoid())
+        return coords
+
+    def forward_class_heads(self, transformer_outputs):
+        hs = transformer_outputs["hs"]
+        return torch.stack([self.class_embed[lvl](hs[lvl]) for lvl in range(hs.shape[0])])
+
+    def forward_heads(self, transformer_outputs, bb_outputs=None, **kwargs):
+        outputs_class = self.forward_class_heads(transformer_outputs)
+        outputs_coord = self.forward_position_heads(transformer_outputs)
+        last = self.num_decoder_layers - 1 if transformer_outputs["hs"].shape[0] > 1 else 0
+        out = {"pred_logits": outputs_class[last], "pred_boxes": outputs_coord[last],
+               "activation_fn": self.activation_fn}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b, "activation_fn": self.activation_fn}
+                                  for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
+        if self.return_dec_outputs:
+            out["dec_outputs"] = transformer_outputs["hs"]
+        if self.return_enc_outputs:
+            out["enc_outputs"] = transformer_outputs["memory"][-2]
+        if self.return_bb_outputs:
+            features, pos = bb_outputs
+            for lvl, (src, mask) in enumerate(features):
+                out[f"bb_lvl{lvl}_src_outputs"] = src
+                out[f"bb_lvl{lvl}_mask_outputs"] = mask
+                out[f"bb_lvl{lvl}_pos_outputs"] = pos[lvl]
+        return out
+
+    # ---- post-processing ----------------------------------------------------------------------------------------------
+    def get_outs_labels(self, m_outputs=None, activation_fn=None):
+        assert m_outputs is not None
+        activation_fn = m_outputs.get("activation_fn") or activation_fn or self.activation_fn
+        logits = m_outputs["pred_logits"]
+        probs = F.softmax(logits, -1) if activation_fn == "softmax" else logits.sigmoid()
+        scores, labels = probs.max(-1)
+        return labels, scores
+
+    def get_outs_filter(self, outs_scores=None, outs_labels=None, m_outputs=None, threshold=None, activation_fn=None):
+        activation_fn = activation_fn or self.activation_fn
+        if outs_scores is None or outs_labels is None:
+            outs_labels, outs_scores = self.get_outs_labels(m_outputs, activation_fn=activation_fn)
+        filters = []
+        for scores, labels in zip(outs_scores, outs_labels):
+            if activation_fn == "softmax":
+                keep = labels != self.background_class
+                filters.append(keep if threshold is None else keep & (scores > threshold))
+            else:
+                filters.append(scores > (0.2 if threshold is None else threshold))
+        return filters
+
+    @torch.no_grad()
+    def inference(self, forward_out, threshold=0.2, filters=None, **kwargs):
+        """Forward outputs -> one ``aloscene.BoundingBoxes2D`` (relative xcyc, with ``Labels`` + scores) per image."""
+        logits, boxes_all = forward_out["pred_logits"], forward_out["pred_boxes"]
+        activation_fn = forward_out.get("activation_fn") or self.activation_fn
+        probs = F.softmax(logits.float(), -1) if activation_fn == "softmax" else logits.float().sigmoid()
+        scores_all, labels_all = probs.max(-1)
+        if filters is None:
+            filters = self.get_outs_filter(outs_scores=scores_all, outs_labels=labels_all, threshold=threshold,
+                                           activation_fn=activation_fn, **kwargs)
+        preds = []
+        for scores, labels, boxes, keep in zip(scores_all, labels_all, boxes_all, filters):
+            lab = aloscene.Labels(labels[keep].type(torch.float32), encoding="id", scores=scores[keep], names=("N",))
+            preds.append(aloscene.BoundingBoxes2D(boxes[keep].float().cpu(), boxes_format="xcyc", absolute=False,
+                                                  names=("N", None), labels=lab))
+        return preds
+
+    # ---- builders (same names as the reference so subclasses can override them) ----------------------------------------
+    def build_positional_encoding(self, hidden_dim=256):
+        return PositionEmbeddingSine(hidden_dim // 2, normalize=True, center=True)
+
+    def build_backbone(self, backbone_name="resnet50", train_backbone=True, return_interm_layers=True, dilation=False):
+        return Backbone(backbone_name, train_backbone, return_interm_layers, dilation)
+
+    def build_decoder_layer(self, hidden_dim=256, dropout=0.1, nheads=8, dim_feedforward=1024, num_feature_levels=4,
+                            dec_n_points=4):
+        return DeformableTransformerDecoderLayer(d_model=hidden_dim, dim_feedforward=dim_feedforward, dropout=dropout,
+                                                 activation="relu", n_levels=num_feature_levels, n_heads=nheads,
+                                                 n_points=dec_n_points)
+
+    def build_decoder(self, dec_layers=6, return_intermediate_dec=True, hidden_dim=256, num_feature_levels=4):
+        layer = self.build_decoder_layer(hidden_dim=hidden_dim, num_feature_levels=num_feature_levels)
+        return DeformableTransformerDecoder(layer, dec_layers, return_intermediate_dec)
+
+    def build_transformer(self, hidden_dim=256, dropout=0.1, nheads=8, dim_feedforward=1024, enc_layers=6, dec_layers=6,
+                          num_feature_levels=4, dec_n_points=4, enc_n_points=4, return_intermediate_dec=True):
+        decoder = self.build_decoder(dec_layers=dec_layers, return_intermediate_dec=return_intermediate_dec,
+                                     hidden_dim=hidden_dim, num_feature_levels=num_feature_levels)
+        return DeformableTransformer(decoder=decoder, d_model=hidden_dim, dropout=dropout, nhead=nheads,
+                                     dim_feedforward=dim_feedforward, num_encoder_layers=enc_layers,
+                                     num_decoder_layers=dec_layers, num_feature_levels=num_feature_levels,
+                                     dec_n_points=dec_n_points, enc_n_points=enc_n_points,
+                                     return_intermediate_dec=return_intermediate_dec)

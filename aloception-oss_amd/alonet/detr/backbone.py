@@ -1,0 +1,159 @@
+"""ResNet backbone with frozen batch-norm + positional encoding, on stock PyTorch-ROCm (MIOpen convolutions).
+
+Re-states alonet/detr/backbone.py:50-182.  torchvision is not available, so the ResNet-50/101 body is written out here
+with torchvision's module names (``conv1, bn1, layer1..4.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}``): a
+reference checkpoint's ``backbone.0.body.*`` keys load unchanged.  Stride sits on the 3x3 convolution of each
+bottleneck (torchvision's "v1.5" layout).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .misc import assert_and_export_onnx
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Batch-norm with fixed statistics and affine parameters (buffers, so they are never trained); eps = 1e-5."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + 1e-5).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return x * scale.reshape(1, -1, 1, 1).to(x.dtype) + shift.reshape(1, -1, 1, 1).to(x.dtype)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+_DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
+
+
+class ResNetBody(nn.Module):
+    """conv1 .. layer4 of a torchvision ResNet; ``forward`` returns the outputs of the requested stages."""
+
+    def __init__(self, name="resnet50", replace_stride_with_dilation=(False, False, False),
+                 norm_layer=FrozenBatchNorm2d, return_layers=None):
+        super().__init__()
+        if name not in _DEPTHS:
+            raise ValueError(f"backbone {name!r} is not available (have {sorted(_DEPTHS)})")
+        self.inplanes, self.dilation = 64, 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        depths = _DEPTHS[name]
+        self.layer1 = self._stage(64, depths[0], 1, False, norm_layer)
+        self.layer2 = self._stage(128, depths[1], 2, replace_stride_with_dilation[0], norm_layer)
+        self.layer3 = self._stage(256, depths[2], 2, replace_stride_with_dilation[1], norm_layer)
+        self.layer4 = self._stage(512, depths[3], 2, replace_stride_with_dilation[2], norm_layer)
+        self.return_layers = dict(return_layers or {"layer4": "0"})
+        for m in self.modules():  # torchvision's default initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _stage(self, planes, blocks, stride, dilate, norm_layer):
+        prev_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        downsample = None
+        if stride != 1 or self.inplanes != planes * Bottleneck.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * Bottleneck.expansion, 1, stride=stride, bias=False),
+                norm_layer(planes * Bottleneck.expansion))
+        layers = [Bottleneck(self.inplanes, planes, stride, prev_dilation, downsample, norm_layer)]
+        self.inplanes = planes * Bottleneck.expansion
+        layers += [Bottleneck(self.inplanes, planes, 1, self.dilation, None, norm_layer) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        out = {}
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            x = getattr(self, name)(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+def _resize_mask(mask, size):
+    """torchvision ``resize`` of the float padding mask (bilinear, no antialias), as the reference applies before the
+    ``.to(bool)`` cast (detr/backbone.py:127-128): any pixel touched by padding becomes padding."""
+    return F.interpolate(mask, size=size, mode="bilinear", align_corners=False)
+
+
+class BackboneBase(nn.Module):
+    def __init__(self, backbone, train_backbone, num_channels, return_interm_layers, **kwargs):
+        super().__init__()
+        for name, parameter in backbone.named_parameters():
+            if not train_backbone or ("layer2" not in name and "layer3" not in name and "layer4" not in name):
+                parameter.requires_grad_(False)
+        if return_interm_layers:
+            backbone.return_layers = {"layer1": "0", "layer2": "1", "layer3": "2", "layer4": "3"}
+        else:
+            backbone.return_layers = {"layer4": "0"}
+        self.body = backbone
+        self.num_channels = num_channels
+
+    def forward(self, frames, **kwargs):
+        frame_masks = frames.mask.as_tensor()
+        xs = self.body(frames.as_tensor())
+        out = {}
+        for name, x in xs.items():
+            out[name] = (x, _resize_mask(frame_masks.float(), x.shape[-2:]).to(torch.bool))
+        return out
+
+
+class Backbone(BackboneBase):
+    """ResNet backbone with frozen BatchNorm (weights are random unless a checkpoint is loaded: no download here)."""
+
+    def __init__(self, name, train_backbone, return_interm_layers, dilation, **kwargs):
+        body = ResNetBody(name, replace_stride_with_dilation=(False, False, dilation), norm_layer=FrozenBatchNorm2d)
+        super().__init__(body, train_backbone, 2048, return_interm_layers, **kwargs)
+
+
+class Joiner(nn.Sequential):
+    """``[backbone, position_embedding]``; ``forward`` -> (list of (feature, mask), list of positional encodings)."""
+
+    def __init__(self, backbone, position_embedding, tracing=None):
+        super().__init__(backbone, position_embedding)
+
+    @assert_and_export_onnx()
+    def forward(self, frames, **kwargs):
+        out, pos = [], []
+        for _, x in self[0](frames, **kwargs).items():
+            out.append(x)
+            pos.append(self[1](x).to(x[0].dtype))
+        return out, pos

@@ -1,3 +1,4 @@
 from .corr import CorrBlock
+from .raft import RAFT, RAFTBase
 
-__all__ = ["CorrBlock"]
+__all__ = ["CorrBlock", "RAFT", "RAFTBase"]

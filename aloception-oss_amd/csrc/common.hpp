@@ -66,42 +66,57 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 constexpr unsigned kOutOfRange = 0xC0000000u;  // byte offset guaranteed past any slab (slabs are < 3 GiB)
 
-// Load VEC elements of storage type T at byte offset `off` and widen them to the compute type CT.
+// Load VEC elements of storage type T at byte offset `off` (raw registers), widen them to the compute type CT later:
+// keeping the two steps apart lets a kernel put a whole batch of loads in flight before the first conversion.
 template <typename T, typename CT, int VEC>
 struct Loader;
 
 template <>
 struct Loader<float, float, 4> {
-    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[4]) {
-        u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    using raw_t = u32x4;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void widen(const raw_t& x, float (&v)[4]) {
         v[0] = __uint_as_float(x.x); v[1] = __uint_as_float(x.y); v[2] = __uint_as_float(x.z); v[3] = __uint_as_float(x.w);
     }
 };
 template <>
 struct Loader<float, float, 1> {
-    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[1]) {
-        v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    using raw_t = unsigned;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
     }
+    static __device__ __forceinline__ void widen(const raw_t& x, float (&v)[1]) { v[0] = __uint_as_float(x); }
 };
 template <>
 struct Loader<double, double, 2> {
-    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, double (&v)[2]) {
-        u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    using raw_t = u32x4;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void widen(const raw_t& x, double (&v)[2]) {
         v[0] = __hiloint2double((int)x.y, (int)x.x);
         v[1] = __hiloint2double((int)x.w, (int)x.z);
     }
 };
 template <>
 struct Loader<double, double, 1> {
-    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, double (&v)[1]) {
-        u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    using raw_t = u32x2;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void widen(const raw_t& x, double (&v)[1]) {
         v[0] = __hiloint2double((int)x.y, (int)x.x);
     }
 };
 template <>
 struct Loader<bf16_t, float, 8> {
-    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[8]) {
-        u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    using raw_t = u32x4;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void widen(const raw_t& x, float (&v)[8]) {
         const unsigned w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -112,9 +127,11 @@ struct Loader<bf16_t, float, 8> {
 };
 template <>
 struct Loader<bf16_t, float, 1> {
-    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, unsigned off, float (&v)[1]) {
-        v[0] = bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+    using raw_t = unsigned short;
+    static __device__ __forceinline__ raw_t load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0);
     }
+    static __device__ __forceinline__ void widen(const raw_t& x, float (&v)[1]) { v[0] = bf16_to_f32(x); }
 };
 
 // Scalar global load/store with widening / narrowing (sampling locations, attention weights, outputs).

@@ -202,6 +202,7 @@ struct LookupArgs {
 
 // the reference's coordinate round trip (utils.py:8-9, then ATen's unnormalize for align_corners=True)
 __device__ __forceinline__ float round_trip(float p, int size) {
+#pragma clang fp contract(off)  // the reference rounds the product before anything is subtracted from it
     const float s = (float)(size - 1);
     const float gnorm = 2.0f * p / s - 1.0f;
     return ((gnorm + 1.0f) / 2.0f) * s;

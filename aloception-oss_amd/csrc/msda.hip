@@ -88,14 +88,15 @@ __device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, cons
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, int WAVES>
-__global__ void __launch_bounds__(kThreads, WAVES)
+template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, int SB>
+__global__ void __launch_bounds__(kThreads)
 msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
                 const LT* __restrict__ loc, const LT* __restrict__ attn, T* __restrict__ out, const Dims dm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* meta = reinterpret_cast<int*>(smem);
     unsigned char* dbase = smem + kMetaBytes;
     using Desc = FwdDesc<CT>;
+    using Ld = Loader<T, CT, VEC>;
     constexpr int PAIRS = kThreads / G;
     const int LP = LP_CT ? LP_CT : dm.L * dm.P;
     const int pair_stride = LP * (int)sizeof(Desc) + 16;  // +16 B: pairs of one wave land on distinct LDS slots
@@ -155,15 +156,32 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                     CT acc[VEC];
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) acc[i] = (CT)0;
-#pragma unroll LP_CT ? LP_CT : 4
-                    for (int s = 0; s < LP; ++s) {
-                        const Desc d = *reinterpret_cast<const Desc*>(dp + s * (int)sizeof(Desc));
+                    // SB sampling points (4*SB corner rows) are requested before the first one is consumed; the
+                    // outer loop stays rolled so the register allocator sees exactly that much in flight.
+#pragma unroll 1
+                    for (int s0 = 0; s0 < LP; s0 += SB) {
+                        Desc d[SB];
+                        typename Ld::raw_t raw[SB][4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            CT v[VEC];
-                            Loader<T, CT, VEC>::load(rsrc, d.off[k] + coff, v);
+                        for (int j = 0; j < SB; ++j) {
+                            if (LP_CT || s0 + j < LP) {
+                                d[j] = *reinterpret_cast<const Desc*>(dp + (s0 + j) * (int)sizeof(Desc));
+                            } else {
 #pragma unroll
-                            for (int i = 0; i < VEC; ++i) acc[i] += d.w[k] * v[i];
+                                for (int k = 0; k < 4; ++k) { d[j].off[k] = kOutOfRange; d[j].w[k] = (CT)0; }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) raw[j][k] = Ld::load(rsrc, d[j].off[k] + coff);
+                        }
+#pragma unroll
+                        for (int j = 0; j < SB; ++j) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                CT v[VEC];
+                                Ld::widen(raw[j][k], v);
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) acc[i] += d[j].w[k] * v[i];
+                            }
                         }
                     }
                     store_vec<T, CT, VEC>(out + (batch_pair0 + pair) * dm.D + c0, acc);
@@ -186,6 +204,7 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
     int* meta = reinterpret_cast<int*>(smem);
     unsigned char* dbase = smem + kMetaBytes;
     using Desc = BwdDesc<CT>;
+    using Ld = Loader<T, CT, VEC>;
     constexpr int PAIRS = kThreads / G;
     const int LP = LP_CT ? LP_CT : dm.L * dm.P;
     const int pair_stride = LP * (int)sizeof(Desc) + 16;
@@ -251,12 +270,15 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                     const CT w[4] = {hh * hw, hh * d.lw, d.lh * hw, d.lh * d.lw};
                     for (int c0 = lane * VEC; c0 < dm.D; c0 += G * VEC) {
                         const unsigned ch = (unsigned)(m * dm.D + c0);
-                        CT v[4][VEC];
+                        typename Ld::raw_t raw[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const unsigned o = d.off[k] == kNoCorner ? kOutOfRange : (d.off[k] + ch) * (unsigned)sizeof(T);
-                            Loader<T, CT, VEC>::load(rsrc, o, v[k]);
+                            raw[k] = Ld::load(rsrc, o);
                         }
+                        CT v[4][VEC];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) Ld::widen(raw[k], v[k]);
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {
                             const CT top = (CT)ld(go + c0 + i);
@@ -302,16 +324,16 @@ struct Plan {
 };
 
 // Kernel-tuning knobs, read once from the environment (results never depend on them).
-//   ALO_MSDA_FWD_WAVES  2 | 4 | 8   occupancy target (waves per SIMD) of the unrolled forward kernel
+//   ALO_MSDA_FWD_BATCH  2 | 4 | 8   sampling points whose 4 corner loads are put in flight together (forward)
 //   ALO_MSDA_ITERS      1..64       runs of pairs per workgroup (0 = automatic)
 struct Tuning {
-    int fwd_waves = 4;
+    int fwd_batch = 4;
     int iters = 0;
 };
 const Tuning& tuning() {
     static const Tuning t = [] {
         Tuning x;
-        if (const char* e = getenv("ALO_MSDA_FWD_WAVES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_waves = v; }
+        if (const char* e = getenv("ALO_MSDA_FWD_BATCH")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_batch = v; }
         if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
         return x;
     }();
@@ -372,11 +394,11 @@ int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char*
 #define ALO_FWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
     if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
         const size_t lds = kMetaBytes + (size_t)(kThreads / G) * ((size_t)L * P * sizeof(FwdDesc<CT>) + 16);       \
-        if (LPCT == 16 && waves == 2)                                                                              \
-            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 2 : 1)>, dm, lds, stream, "alo_msda_forward", args); \
-        if (LPCT == 16 && waves == 8)                                                                              \
-            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 8 : 1)>, dm, lds, stream, "alo_msda_forward", args); \
-        return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 1)>, dm, lds, stream, "alo_msda_forward", args);     \
+        if (LPCT == 16 && sb == 2)                                                                                 \
+            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, 2>, dm, lds, stream, "alo_msda_forward", args); \
+        if (LPCT == 16 && sb == 8)                                                                                 \
+            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 8 : 2)>, dm, lds, stream, "alo_msda_forward", args); \
+        return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 2)>, dm, lds, stream, "alo_msda_forward", args);     \
     }
 #define ALO_BWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
     if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
@@ -423,7 +445,7 @@ extern "C" int alo_msda_forward(const void* value, const int32_t* spatial_shapes
     const bool aligned = (((uintptr_t)value | (uintptr_t)out) & 15) == 0;
     const Plan plan = make_plan(D, L, P, elem, aligned);
     Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
-    const int waves = tuning().fwd_waves;
+    const int sb = tuning().fwd_batch;
     void* args[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &out, &dm};
     if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_FWD_CASE, double, double, double, 2) }

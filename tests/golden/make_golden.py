@@ -19,7 +19,11 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
                          and 4-d reference points with a padding mask
   g6_corr.npz            CorrBlock: fmaps (1,256,16,20) -> 4 pyramid levels + lookups (in-range, integer and
                          far out-of-frame coords); plus an odd-sized batched case (2,32,17,18), radius 3
+  g5_deformable_transformer.npz   DeformableTransformer (2 enc + 2 dec layers, d_model 64) on padded inputs, fp64:
+                         hs, inter_references_out, memory per level.  Weights come from helpers.formula_state_dict.
+  g7_raft.npz            full RAFT forward on a 64x96 pair, 4 iterations, fp32: per-iteration flow, up_flow
   g8_known_answers.npz   hand-checkable micro cases (pixel-centre sample, corner sample)
+  g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
 """
@@ -256,12 +260,77 @@ def g8(ref):
     )
 
 
+def g5(ref):
+    """DeformableTransformer (small config) through the reference's CPU/tracing branch, fp64."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from helpers import formula_state_dict
+
+    DT = importlib.import_module("alonet.deformable_detr.deformable_transformer")
+    torch.manual_seed(55)
+    d_model, nhead, L = 64, 4, 3
+    tr = DT.DeformableTransformer(d_model=d_model, nhead=nhead, num_encoder_layers=2, num_decoder_layers=2,
+                                  dim_feedforward=96, dropout=0.0, return_intermediate_dec=True,
+                                  num_feature_levels=L, dec_n_points=2, enc_n_points=3).double().eval()
+    tr.load_state_dict(formula_state_dict(tr.state_dict()))
+    B, sizes = 2, [(9, 12), (5, 6), (3, 3)]
+    srcs = [torch.randn(B, d_model, h, w, dtype=torch.float64) for h, w in sizes]
+    poss = [torch.randn(B, d_model, h, w, dtype=torch.float64) * 0.5 for h, w in sizes]
+    masks = []
+    for h, w in sizes:  # image 1 is padded on its right/bottom quarter
+        m = torch.zeros(B, h, w, dtype=torch.bool)
+        m[1, :, w - max(1, w // 4):] = True
+        m[1, h - max(1, h // 4):, :] = True
+        masks.append(m)
+    query_embed = torch.randn(10, 2 * d_model, dtype=torch.float64)
+    with torch.no_grad():
+        out = tr(srcs, masks, poss, query_embed, is_tracing=None)
+    save = dict(cfg=np.array([d_model, nhead, 2, 2, 96, L, 2, 3]), query_embed=_np(query_embed),
+                hs=_np(out["hs"]), inter_references_out=_np(out["inter_references_out"]),
+                init_reference_out=_np(out["init_reference_out"]))
+    for i in range(L):
+        save[f"src{i}"], save[f"pos{i}"], save[f"mask{i}"] = _np(srcs[i]), _np(poss[i]), _np(masks[i])
+        save[f"memory{i}"] = _np(out["memory"][i])
+    np.savez_compressed(os.path.join(OUT, "g5_deformable_transformer.npz"), **save)
+
+
+def g7(ref):
+    """Full RAFT forward (reference model, formula weights), 64x96 pair, 4 iterations, fp32 on CPU."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from helpers import formula_state_dict
+
+    R = importlib.import_module("alonet.raft.raft")
+    torch.manual_seed(77)
+    model = R.RAFT().eval()
+    model.load_state_dict(formula_state_dict(model.state_dict()))
+    img1 = torch.rand(2, 3, 64, 96) * 2 - 1
+    img2 = torch.roll(img1, shifts=(2, -3), dims=(2, 3)) + 0.01 * torch.randn(2, 3, 64, 96)
+    with torch.no_grad():
+        outs = model(ref.Frame(img1, "minmax_sym"), ref.Frame(img2, "minmax_sym"), iters=4, only_last=False)
+    np.savez_compressed(
+        os.path.join(OUT, "g7_raft.npz"), img1=_np(img1), img2=_np(img2),
+        flow=np.stack([_np(o["flow"]) for o in outs]), up_flow_last=_np(outs[-1]["up_flow"]),
+        up_flow_first=_np(outs[0]["up_flow"]), hidden_last=_np(outs[-1]["hidden_state"]),
+    )
+
+
+def g9(ref):
+    """PositionEmbeddingSine (centred + normalised, as Deformable-DETR builds it; and the DETR default)."""
+    PE = importlib.import_module("alonet.transformers.position_encoding")
+    mask = torch.zeros(2, 1, 7, 9)
+    mask[1, :, 5:, :] = 1
+    mask[1, :, :, 6:] = 1
+    ft = torch.zeros(2, 4, 7, 9)
+    out_c = PE.PositionEmbeddingSine(16, normalize=True, center=True)((ft, mask))
+    out_d = PE.PositionEmbeddingSine(16, normalize=True)((ft, mask))
+    np.savez_compressed(os.path.join(OUT, "g9_posenc.npz"), mask=_np(mask), centered=_np(out_c), default=_np(out_d))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
     torch.set_num_threads(4)
     ref = load_reference()
-    for fn in (g1, g2, g3, g4, g6, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         fn(ref)
         print("wrote", fn.__name__)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))

@@ -47,7 +47,7 @@ def test_lookup_alone_on_the_reference_pyramid(golden):
     levels = [dev(g[f"lvl{lvl}"]) for lvl in range(4)]
     for k in "abc":
         out = alo_hip.corr_lookup(levels, dev(g["coords_" + k]), 4).cpu().numpy()
-        np.testing.assert_allclose(out, g["out_" + k], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(out, g["out_" + k], rtol=0, atol=5e-6)  # separable lerp vs 4-tap sum, |v| <= 4
 
 
 @pytest.mark.parametrize("B,C,H,W,r,L", [(2, 256, 24, 32, 4, 4), (1, 64, 19, 23, 4, 3), (3, 37, 16, 18, 2, 4),

@@ -1,0 +1,41 @@
+"""The N > 1 launch path of bench.py (one process per GPU, batch sharding, barrier fences, max-over-ranks timing),
+exercised with world_size 2 on the gloo backend.  CPU only."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_selftest(nproc, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc), "--steps", "5", "--warmup", "1", "--batch", "8", "--selftest"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_two_ranks_weak_scaling_and_max_over_ranks():
+    r2 = run_selftest(2, 29611)
+    assert r2["n_gpus"] == 2 and r2["steps"] == 5 and r2["scaling"] == "weak"
+    # rank 1 sleeps 20 ms per step, rank 0 only 10 ms: the reported time is the slowest rank's
+    assert r2["ms_per_step"] >= 19.0
+    # whole-job throughput counts every rank's frames: 2 ranks x 8 frames x 5 steps / time
+    assert abs(r2["value"] - 2 * 8 * 5 / (r2["ms_per_step"] * 5 / 1e3)) / r2["value"] < 1e-6
+    # ranks hold different shards (seed 1234 + rank): the all-reduced checksum differs from 2 x rank 0's
+    import torch
+    s0 = float(torch.rand(8, 64, generator=torch.Generator().manual_seed(1234)).sum())
+    s1 = float(torch.rand(8, 64, generator=torch.Generator().manual_seed(1235)).sum())
+    assert abs(r2["checksum"] - (s0 + s1)) < 1e-3 and abs(s0 - s1) > 1e-6
+
+
+def test_mismatched_world_size_is_refused():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

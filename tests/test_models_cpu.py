@@ -1,0 +1,116 @@
+"""Model graphs (callers of the hot path) against the reference's outputs, on the CPU.
+
+The gather / correlation ops have no CPU implementation in the product, so here the graphs run through the reference's
+own explicit escape hatches: ``is_tracing`` (pure-torch MSDA branch) and RAFT's ``corr_block=`` hook (fed the oracle's
+torch CorrBlock).  What is pinned is everything AROUND the kernels: module wiring, parameter names, arithmetic.
+"""
+import numpy as np
+import torch
+
+import aloscene
+import torch_ref as T
+from alonet.deformable_detr import DeformableDetrR50, DeformableTransformer
+from alonet.raft import RAFT
+from alonet.transformers import PositionEmbeddingSine
+from helpers import formula_state_dict
+
+t = torch.from_numpy
+
+
+def test_position_encoding_matches_reference(golden):
+    g = golden("g9_posenc.npz")
+    ft = torch.zeros(2, 4, 7, 9)
+    out_c = PositionEmbeddingSine(16, normalize=True, center=True)((ft, t(g["mask"])))
+    out_d = PositionEmbeddingSine(16, normalize=True)((ft, t(g["mask"])))
+    np.testing.assert_allclose(out_c.numpy(), g["centered"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out_d.numpy(), g["default"], rtol=0, atol=1e-6)
+
+
+def build_g5_transformer(g):
+    d_model, nhead, enc, dec, ffn, L, dec_p, enc_p = (int(x) for x in g["cfg"])
+    tr = DeformableTransformer(d_model=d_model, nhead=nhead, num_encoder_layers=enc, num_decoder_layers=dec,
+                               dim_feedforward=ffn, dropout=0.0, return_intermediate_dec=True, num_feature_levels=L,
+                               dec_n_points=dec_p, enc_n_points=enc_p).double().eval()
+    res = tr.load_state_dict(formula_state_dict(tr.state_dict()))
+    assert not res.missing_keys and not res.unexpected_keys
+    return tr, L
+
+
+def test_deformable_transformer_graph_matches_reference(golden):
+    g = golden("g5_deformable_transformer.npz")
+    tr, L = build_g5_transformer(g)
+    srcs = [t(g[f"src{i}"]) for i in range(L)]
+    poss = [t(g[f"pos{i}"]) for i in range(L)]
+    masks = [t(g[f"mask{i}"]) for i in range(L)]
+    with torch.no_grad():
+        out = tr(srcs, masks, poss, t(g["query_embed"]), is_tracing=None)
+    np.testing.assert_allclose(out["hs"].numpy(), g["hs"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out["inter_references_out"].numpy(), g["inter_references_out"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out["init_reference_out"].numpy(), g["init_reference_out"], rtol=1e-9, atol=1e-10)
+    for i in range(L):
+        np.testing.assert_allclose(out["memory"][i].numpy(), g[f"memory{i}"], rtol=1e-9, atol=1e-10)
+
+
+def test_raft_graph_matches_reference(golden):
+    g = golden("g7_raft.npz")
+    model = RAFT(corr_block=T.CorrBlockRef).eval()
+    res = model.load_state_dict(formula_state_dict(model.state_dict()))
+    assert not res.missing_keys and not res.unexpected_keys
+    f1 = aloscene.Frame(t(g["img1"]), normalization="minmax_sym", names=("B", "C", "H", "W"))
+    f2 = aloscene.Frame(t(g["img2"]), normalization="minmax_sym", names=("B", "C", "H", "W"))
+    with torch.no_grad():
+        outs = model(f1, f2, iters=4)
+    flows = np.stack([o["flow"].numpy() for o in outs])
+    np.testing.assert_allclose(flows, g["flow"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(outs[-1]["up_flow"].numpy(), g["up_flow_last"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(outs[0]["up_flow"].numpy(), g["up_flow_first"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(outs[-1]["hidden_state"].numpy(), g["hidden_last"], rtol=0, atol=2e-4)
+    flow_up = model.inference(outs, only_last=True)
+    assert isinstance(flow_up, aloscene.Flow) and flow_up.names == ("B", "C", "H", "W") and flow_up.shape == (2, 2, 64, 96)
+    with torch.no_grad():
+        last = model(f1, f2, iters=4, only_last=True)
+    assert "up_flow" in last[-1] and "up_flow" not in last[0]
+
+
+def test_state_dict_layout_is_the_reference_checkpoint_layout():
+    """Key names a reference checkpoint carries; counts from the reference modules themselves."""
+    det = DeformableDetrR50(device=None, aux_loss=False)
+    keys = set(det.state_dict())
+    for k in ("backbone.0.body.conv1.weight", "backbone.0.body.bn1.running_var",
+              "backbone.0.body.layer1.0.downsample.0.weight", "backbone.0.body.layer4.2.conv3.weight",
+              "input_proj.0.0.weight", "input_proj.3.1.bias", "query_embed.weight", "class_embed.5.bias",
+              "bbox_embed.0.layers.2.weight", "transformer.level_embed", "transformer.reference_points.weight",
+              "transformer.encoder.layers.5.self_attn.sampling_offsets.bias",
+              "transformer.decoder.layers.0.cross_attn.value_proj.weight",
+              "transformer.decoder.layers.3.self_attn.in_proj_weight", "transformer.decoder.layers.5.norm3.bias"):
+        assert k in keys, k
+    assert not any("num_batches_tracked" in k for k in keys)
+    assert det.state_dict()["query_embed.weight"].shape == (300, 512)
+    assert sum(1 for k in keys if k.startswith("transformer.")) == 231
+    assert abs(sum(p.numel() for p in det.parameters() if p.requires_grad) - 39.85e6) < 0.05e6
+    raft = RAFT()
+    rk = set(raft.state_dict())
+    assert len(rk) == 179 and sum(p.numel() for p in raft.parameters()) == 5257536
+    for k in ("fnet.conv1.weight", "fnet.layer2.0.downsample.0.weight", "cnet.norm1.running_mean",
+              "cnet.layer3.0.downsample.1.num_batches_tracked", "update_block.encoder.convc1.weight",
+              "update_block.gru.convq2.bias", "update_block.flow_head.conv2.weight", "update_block.mask.2.weight"):
+        assert k in rk, k
+    assert not any(k.startswith("fnet.") and "norm" in k for k in rk)  # InstanceNorm2d: no affine, no stats
+    assert raft.state_dict()["update_block.encoder.convc1.weight"].shape == (256, 324, 1, 1)
+
+
+def test_frame_io_contract():
+    img = torch.rand(3, 20, 30) * 255
+    f = aloscene.Frame(img, normalization="255")
+    r = f.norm_resnet()
+    assert r.normalization == "resnet" and r.mean_std[0] == (0.485, 0.456, 0.406)
+    np.testing.assert_allclose(r.norm255().as_tensor().numpy(), img.numpy(), atol=1e-4)  # unittest/test_frame.py bar
+    np.testing.assert_allclose(f.norm_minmax_sym().norm01().norm255().as_tensor().numpy(), img.numpy(), atol=1e-4)
+    small = aloscene.Frame(torch.rand(3, 12, 18) * 255).norm_resnet()
+    batch = aloscene.Frame.batch_list([r, small])
+    assert batch.names == ("B", "C", "H", "W") and batch.shape == (2, 3, 20, 30) and batch.normalization == "resnet"
+    assert batch.mask.names == ("B", "C", "H", "W") and batch.mask.shape == (2, 1, 20, 30)
+    m = batch.mask.as_tensor()
+    assert m[0].sum() == 0 and m[1, 0, :12, :18].sum() == 0 and m[1].sum() == 20 * 30 - 12 * 18
+    assert torch.all(batch.as_tensor()[1, :, 12:, :] == 0)
+    assert type(batch.as_tensor()) is torch.Tensor

@@ -1,0 +1,88 @@
+"""The re-stated callers (DeformableTransformer / DeformableDETR-R50 / RAFT) on the GPU, hot path on the HIP kernels."""
+import numpy as np
+import pytest
+import torch
+
+import aloscene
+from alonet.deformable_detr import DeformableDetrR50
+from alonet.raft import RAFT
+from helpers import formula_state_dict
+from test_models_cpu import build_g5_transformer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+t = torch.from_numpy
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-3)])
+def test_deformable_transformer_on_hip_matches_reference(golden, dtype, tol):
+    """North-star bar: <= 1e-3 max-abs deviation from the reference PyTorch path in fp32 (1e-9 in fp64)."""
+    g = golden("g5_deformable_transformer.npz")
+    tr, L = build_g5_transformer(g)
+    tr = tr.to(DEV, dtype)
+    srcs = [t(g[f"src{i}"]).to(DEV, dtype) for i in range(L)]
+    poss = [t(g[f"pos{i}"]).to(DEV, dtype) for i in range(L)]
+    masks = [t(g[f"mask{i}"]).to(DEV) for i in range(L)]
+    with torch.no_grad():
+        out = tr(srcs, masks, poss, t(g["query_embed"]).to(DEV, dtype))
+    assert np.abs(out["hs"].double().cpu().numpy() - g["hs"]).max() <= tol
+    assert np.abs(out["inter_references_out"].double().cpu().numpy() - g["inter_references_out"]).max() <= tol
+    for i in range(L):
+        assert np.abs(out["memory"][i].double().cpu().numpy() - g[f"memory{i}"]).max() <= tol
+
+
+def test_raft_on_hip_matches_reference(golden):
+    g = golden("g7_raft.npz")
+    model = RAFT().eval()  # default corr_block = the HIP CorrBlock
+    model.load_state_dict(formula_state_dict(model.state_dict()))
+    model = model.to(DEV)
+    f1 = aloscene.Frame(t(g["img1"]), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
+    f2 = aloscene.Frame(t(g["img2"]), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
+    with torch.no_grad():
+        outs = model(f1, f2, iters=4)
+    flows = np.stack([o["flow"].cpu().numpy() for o in outs])
+    assert np.abs(flows - g["flow"]).max() <= 1e-3  # 1/8-resolution flow, pixels
+    assert np.abs(outs[-1]["up_flow"].cpu().numpy() - g["up_flow_last"]).max() <= 8e-3  # x8 up-sampled
+    assert np.abs(outs[-1]["hidden_state"].cpu().numpy() - g["hidden_last"]).max() <= 1e-3
+    flow = model.inference(outs, only_last=True)
+    assert isinstance(flow, aloscene.Flow) and flow.shape == (2, 2, 64, 96)
+
+
+def _frames(sizes, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    return [aloscene.Frame(torch.rand(3, h, w, generator=gen) * 255, normalization="255").norm_resnet() for h, w in sizes]
+
+
+def test_deformable_detr_r50_end_to_end_hip_vs_torch_branch():
+    """Full model, ragged batch (padding mask): HIP op vs the pure-torch export branch on the same weights, fp32."""
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=True, device=torch.device(DEV)).eval()
+    frames = aloscene.Frame.batch_list(_frames([(192, 256), (160, 224)])).to(DEV)
+    with torch.no_grad():
+        out = model(frames)
+        ref = model(frames, is_tracing=None)
+    assert out["pred_logits"].shape == (2, 300, 91) and out["pred_boxes"].shape == (2, 300, 4)
+    assert len(out["aux_outputs"]) == 5 and out["activation_fn"] == "sigmoid"
+    assert (out["pred_logits"] - ref["pred_logits"]).abs().max().item() <= 1e-3
+    assert (out["pred_boxes"] - ref["pred_boxes"]).abs().max().item() <= 1e-3
+    boxes = model.inference(out, threshold=0.0)
+    assert len(boxes) == 2 and isinstance(boxes[0], aloscene.BoundingBoxes2D)
+    assert boxes[0].boxes_format == "xcyc" and not boxes[0].absolute and boxes[0].shape == (300, 4)
+    assert boxes[0].labels.scores.shape == (300,) and boxes[0].device.type == "cpu"
+    # a list of Frames is accepted and batched by the forward decorator
+    with torch.no_grad():
+        out_list = model([f.to(DEV) for f in _frames([(192, 256), (160, 224)])])
+    assert torch.allclose(out_list["pred_boxes"], out["pred_boxes"], atol=1e-5)
+
+
+def test_deformable_detr_r50_bf16_runs_and_tracks_fp32():
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=False, device=torch.device(DEV)).eval()
+    frames = aloscene.Frame.batch_list(_frames([(256, 320), (256, 320)], seed=3)).to(DEV)
+    with torch.no_grad():
+        ref = model(frames)
+        model_bf16 = model.bfloat16()
+        out = model_bf16(frames.to(torch.bfloat16))
+    assert out["pred_boxes"].dtype == torch.bfloat16 and torch.isfinite(out["pred_logits"].float()).all()
+    # reduced precision end to end (backbone included): boxes are sigmoids in [0,1]; a loose sanity band only
+    assert (out["pred_boxes"].float() - ref["pred_boxes"]).abs().mean().item() < 0.05
