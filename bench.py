@@ -130,28 +130,33 @@ def cpu_baseline(cpu_frames):
     import torch_ref  # ORACLE: allowed here only as the timed CPU baseline
     import alonet.deformable_detr.ops.modules.ms_deform_attn as mod
 
-    cores = os.cpu_count() or 1
+    # threads actually used: all of a small host, at most 32 of a big one (256 threads on the 256-core GPU host ran
+    # this graph ~15x SLOWER than 8 threads: torch's intra-op pools oversubscribe on these small tensors)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("ALO_CPU_THREADS", min(avail, 32)))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = DeformableDetrR50(num_classes=91, aux_loss=False, device=None).eval()
     gen = torch.Generator().manual_seed(1234)
-    frames = aloscene.Frame.batch_list(
-        [aloscene.Frame(torch.rand(3, 800, 1333, generator=gen) * 255, normalization="255").norm_resnet()
-         for _ in range(cpu_frames)])
+    one = lambda: aloscene.Frame.batch_list(  # noqa: E731
+        [aloscene.Frame(torch.rand(3, 800, 1333, generator=gen) * 255, normalization="255").norm_resnet()])
     saved = mod.ms_deform_attn_core_pytorch
     mod.ms_deform_attn_core_pytorch = torch_ref.msda_core
+    done, spent = 0, 0.0
     try:
         with torch.no_grad():
-            t0 = time.perf_counter()
-            out = model(frames, is_tracing=None)
-            model.inference(out)
-            dt = time.perf_counter() - t0
+            while done < cpu_frames and spent < 20.0:  # bounded: stop adding frames once ~20 s are spent
+                frames = one()
+                t0 = time.perf_counter()
+                model.inference(model(frames, is_tracing=None))
+                spent += time.perf_counter() - t0
+                done += 1
     finally:
         mod.ms_deform_attn_core_pytorch = saved
-    return {"value": cpu_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{cpu_frames} frame(s) of 1333x800 through the same DeformableDETR-R50 graph in fp32 on the host "
-                      f"({dt:.1f} s); multi-scale deformable attention = oracle/torch_ref.py (torch restatement of the "
-                      "reference's ms_deform_attn_core_pytorch CPU path), other layers stock PyTorch CPU ops"}
+    return {"value": done / spent, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{done} frame(s) of 1333x800, one at a time, through the same DeformableDETR-R50 graph in fp32 on "
+                      f"{cores} host threads ({spent:.1f} s); multi-scale deformable attention = oracle/torch_ref.py (torch "
+                      "restatement of the reference's ms_deform_attn_core_pytorch CPU path), other layers stock PyTorch CPU ops"}
 
 
 def kernel_report(summary):

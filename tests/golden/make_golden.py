@@ -21,7 +21,7 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
                          far out-of-frame coords); plus an odd-sized batched case (2,32,17,18), radius 3
   g5_deformable_transformer.npz   DeformableTransformer (2 enc + 2 dec layers, d_model 64) on padded inputs, fp64:
                          hs, inter_references_out, memory per level.  Weights come from helpers.formula_state_dict.
-  g7_raft.npz            full RAFT forward on a 64x96 pair, 4 iterations, fp32: per-iteration flow, up_flow
+  g7_raft.npz            full RAFT forward on a 128x160 pair (images stored as fp16, used as such), 4 iterations, fp32: per-iteration flow, up_flow
   g8_known_answers.npz   hand-checkable micro cases (pixel-centre sample, corner sample)
   g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
 
@@ -294,7 +294,10 @@ def g5(ref):
 
 
 def g7(ref):
-    """Full RAFT forward (reference model, formula weights), 64x96 pair, 4 iterations, fp32 on CPU."""
+    """Full RAFT forward (reference model, formula weights), 128x160 pair, 4 iterations, fp32 on CPU.
+
+    The frame must be at least 128 px on both sides: below that the top pyramid level is 1 pixel wide/high and the
+    reference's own lookup divides by (size - 1) = 0 and returns NaN flow."""
     sys.path.insert(0, os.path.dirname(OUT))
     from helpers import formula_state_dict
 
@@ -302,12 +305,14 @@ def g7(ref):
     torch.manual_seed(77)
     model = R.RAFT().eval()
     model.load_state_dict(formula_state_dict(model.state_dict()))
-    img1 = torch.rand(2, 3, 64, 96) * 2 - 1
-    img2 = torch.roll(img1, shifts=(2, -3), dims=(2, 3)) + 0.01 * torch.randn(2, 3, 64, 96)
+    img1 = torch.rand(2, 3, 128, 160) * 2 - 1
+    img2 = torch.roll(img1, shifts=(2, -3), dims=(2, 3)) + 0.01 * torch.randn(2, 3, 128, 160)
     with torch.no_grad():
+        img1, img2 = img1.half().float(), img2.half().float()  # fp16-representable inputs: half the fixture size
         outs = model(ref.Frame(img1, "minmax_sym"), ref.Frame(img2, "minmax_sym"), iters=4, only_last=False)
+    assert all(torch.isfinite(o["flow"]).all() for o in outs)
     np.savez_compressed(
-        os.path.join(OUT, "g7_raft.npz"), img1=_np(img1), img2=_np(img2),
+        os.path.join(OUT, "g7_raft.npz"), img1=_np(img1.half()), img2=_np(img2.half()),
         flow=np.stack([_np(o["flow"]) for o in outs]), up_flow_last=_np(outs[-1]["up_flow"]),
         up_flow_first=_np(outs[0]["up_flow"]), hidden_last=_np(outs[-1]["hidden_state"]),
     )

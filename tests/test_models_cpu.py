@@ -56,17 +56,18 @@ def test_raft_graph_matches_reference(golden):
     model = RAFT(corr_block=T.CorrBlockRef).eval()
     res = model.load_state_dict(formula_state_dict(model.state_dict()))
     assert not res.missing_keys and not res.unexpected_keys
-    f1 = aloscene.Frame(t(g["img1"]), normalization="minmax_sym", names=("B", "C", "H", "W"))
-    f2 = aloscene.Frame(t(g["img2"]), normalization="minmax_sym", names=("B", "C", "H", "W"))
+    f1 = aloscene.Frame(t(g["img1"]).float(), normalization="minmax_sym", names=("B", "C", "H", "W"))
+    f2 = aloscene.Frame(t(g["img2"]).float(), normalization="minmax_sym", names=("B", "C", "H", "W"))
     with torch.no_grad():
         outs = model(f1, f2, iters=4)
     flows = np.stack([o["flow"].numpy() for o in outs])
+    assert np.isfinite(g["flow"]).all() and np.isfinite(flows).all()
     np.testing.assert_allclose(flows, g["flow"], rtol=0, atol=2e-4)
     np.testing.assert_allclose(outs[-1]["up_flow"].numpy(), g["up_flow_last"], rtol=0, atol=2e-3)
     np.testing.assert_allclose(outs[0]["up_flow"].numpy(), g["up_flow_first"], rtol=0, atol=2e-3)
     np.testing.assert_allclose(outs[-1]["hidden_state"].numpy(), g["hidden_last"], rtol=0, atol=2e-4)
     flow_up = model.inference(outs, only_last=True)
-    assert isinstance(flow_up, aloscene.Flow) and flow_up.names == ("B", "C", "H", "W") and flow_up.shape == (2, 2, 64, 96)
+    assert isinstance(flow_up, aloscene.Flow) and flow_up.names == ("B", "C", "H", "W") and flow_up.shape == (2, 2, 128, 160)
     with torch.no_grad():
         last = model(f1, f2, iters=4, only_last=True)
     assert "up_flow" in last[-1] and "up_flow" not in last[0]

@@ -36,16 +36,17 @@ def test_raft_on_hip_matches_reference(golden):
     model = RAFT().eval()  # default corr_block = the HIP CorrBlock
     model.load_state_dict(formula_state_dict(model.state_dict()))
     model = model.to(DEV)
-    f1 = aloscene.Frame(t(g["img1"]), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
-    f2 = aloscene.Frame(t(g["img2"]), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
+    f1 = aloscene.Frame(t(g["img1"]).float(), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
+    f2 = aloscene.Frame(t(g["img2"]).float(), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
     with torch.no_grad():
         outs = model(f1, f2, iters=4)
     flows = np.stack([o["flow"].cpu().numpy() for o in outs])
+    assert np.isfinite(g["flow"]).all() and np.isfinite(flows).all()
     assert np.abs(flows - g["flow"]).max() <= 1e-3  # 1/8-resolution flow, pixels
     assert np.abs(outs[-1]["up_flow"].cpu().numpy() - g["up_flow_last"]).max() <= 8e-3  # x8 up-sampled
     assert np.abs(outs[-1]["hidden_state"].cpu().numpy() - g["hidden_last"]).max() <= 1e-3
     flow = model.inference(outs, only_last=True)
-    assert isinstance(flow, aloscene.Flow) and flow.shape == (2, 2, 64, 96)
+    assert isinstance(flow, aloscene.Flow) and flow.shape == (2, 2, 128, 160)
 
 
 def _frames(sizes, seed=0):
