@@ -11,7 +11,7 @@
 // re-read to make the coarser levels, and the 1/sqrt(C) scale is folded into the epilogue.
 //
 // Lookup: one workgroup serves 32 consecutive query pixels.  Stage 1 reads each (query, level, window-row) strip of
-// 2r+2 taps once and interpolates it horizontally into LDS; stage 2 interpolates vertically and writes the
+// 2r+3 taps once and interpolates it horizontally into LDS; stage 2 interpolates vertically and writes the
 // (B, L*(2r+1)^2, H, W) output with 128-byte contiguous stores per channel.  The reference issues 4 grid_sample launches
 // plus meshgrid / cat / permute copies per iteration.
 #include "common.hpp"
@@ -211,10 +211,14 @@ __device__ __forceinline__ float round_trip(float p, int size) {
 template <int R>
 __global__ void __launch_bounds__(256)
 corr_lookup_kernel(const LookupArgs a) {
-    constexpr int WIN = 2 * R + 1, ROWS = WIN + 1;
+    // A window of WIN x WIN taps spaced one pixel apart touches a (WIN+1)^2 footprint.  Every tap position goes through
+    // the reference's fp32 round trip on its own, so floor(x_k) may come out as floor(x_0) + k - 1 or + k + 1 when x sits
+    // within an ulp of an integer; one spare row and column (ROWS = COLS = WIN + 2) lets such taps shift by one.
+    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, COLS = WIN + 2;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* hbuf = sm;                                        // [L][ROWS][WIN][TQ]
-    float* tybuf = sm + a.num_levels * ROWS * WIN * TQ;      // [L][WIN][TQ]
+    float* hbuf = sm;                                            // [L][ROWS][WIN][TQ] horizontally interpolated rows
+    float* tybuf = sm + a.num_levels * ROWS * WIN * TQ;          // [L][WIN][TQ]       vertical fraction per tap row
+    int* rowbuf = reinterpret_cast<int*>(tybuf + a.num_levels * WIN * TQ);  // [L][WIN][TQ] upper staged row per tap row
 
     const int b = blockIdx.x / a.tiles_per_batch;
     const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
@@ -230,6 +234,7 @@ corr_lookup_kernel(const LookupArgs a) {
 #pragma unroll
         for (int k = 0; k < WIN; ++k) hv[k] = 0.f;
         float ty = 0.f;
+        int trow = row < WIN ? row : 0;
         if (i < a.HW) {
             const int h = a.h[l], w = a.w[l];
             const float inv = 1.0f / (float)(1 << l);
@@ -237,22 +242,35 @@ corr_lookup_kernel(const LookupArgs a) {
             const float cy = a.coords[((long)b * 2 + 1) * a.HW + i] * inv;
             const float iy0 = round_trip(cy - (float)R, h);
             const float ix0 = round_trip(cx - (float)R, w);
-            if (fabsf(iy0) < 1e8f && fabsf(ix0) < 1e8f) {  // also false for NaN: such queries read as all-zero
+            if (fabsf(iy0) < 1e6f && fabsf(ix0) < 1e6f) {  // false for NaN too: such queries read as all-zero
                 const int yb = (int)floorf(iy0), xb = (int)floorf(ix0);
                 const int ry = yb + row;
-                if (row < WIN) ty = round_trip(cy + (float)(row - R), h) - (float)(yb + row);
-                if (ry >= 0 && ry < h && xb + WIN >= 0 && xb < w) {
+                if (row < WIN) {
+                    const float iy = round_trip(cy + (float)(row - R), h);
+                    const float fy = floorf(iy);
+                    int d = (int)fy - (yb + row);
+                    d = d < -1 ? -1 : (d > 1 ? 1 : d);
+                    if (row == 0) d = 0;
+                    trow = row + d;
+                    ty = iy - (float)(yb + trow);
+                }
+                if (ry >= 0 && ry < h && xb + COLS > 0 && xb < w) {
                     const float* src = a.lvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
-                    float v[ROWS];
+                    float v[COLS];
 #pragma unroll
-                    for (int k = 0; k < ROWS; ++k) {
+                    for (int k = 0; k < COLS; ++k) {
                         const int x = xb + k;
                         v[k] = (x >= 0 && x < w) ? src[x] : 0.f;
                     }
 #pragma unroll
                     for (int k = 0; k < WIN; ++k) {
-                        const float tx = round_trip(cx + (float)(k - R), w) - (float)(xb + k);
-                        hv[k] = (1.0f - tx) * v[k] + tx * v[k + 1];
+                        const float ix = round_trip(cx + (float)(k - R), w);
+                        int d = (int)floorf(ix) - (xb + k);
+                        d = (k == 0) ? 0 : (d < -1 ? -1 : (d > 1 ? 1 : d));
+                        const float lo = d == 0 ? v[k] : (d > 0 ? v[k + 1] : v[k > 0 ? k - 1 : 0]);
+                        const float hi = d == 0 ? v[k + 1] : (d > 0 ? v[k + 2] : v[k]);
+                        const float tx = ix - (float)(xb + k + d);
+                        hv[k] = (1.0f - tx) * lo + tx * hi;
                     }
                 }
             }
@@ -260,7 +278,10 @@ corr_lookup_kernel(const LookupArgs a) {
         float* dst = hbuf + ((l * ROWS + row) * WIN) * TQ + q;
 #pragma unroll
         for (int k = 0; k < WIN; ++k) dst[k * TQ] = hv[k];
-        if (row < WIN) tybuf[(l * WIN + row) * TQ + q] = ty;
+        if (row < WIN) {
+            tybuf[(l * WIN + row) * TQ + q] = ty;
+            rowbuf[(l * WIN + row) * TQ + q] = trow;
+        }
     }
     __syncthreads();
 
@@ -272,8 +293,9 @@ corr_lookup_kernel(const LookupArgs a) {
         const int i = q0 + q;
         if (i < a.HW) {
             const float ty = tybuf[(l * WIN + cy) * TQ + q];
-            const float top = hbuf[((l * ROWS + cy) * WIN + ax) * TQ + q];
-            const float bot = hbuf[((l * ROWS + cy + 1) * WIN + ax) * TQ + q];
+            const int r0 = rowbuf[(l * WIN + cy) * TQ + q];
+            const float top = hbuf[((l * ROWS + r0) * WIN + ax) * TQ + q];
+            const float bot = hbuf[((l * ROWS + r0 + 1) * WIN + ax) * TQ + q];
             a.out[((long)b * CH + ch) * a.HW + i] = (1.0f - ty) * top + ty * bot;
         }
     }
@@ -281,8 +303,8 @@ corr_lookup_kernel(const LookupArgs a) {
 
 template <int R>
 int launch_lookup(const LookupArgs& a, hipStream_t stream) {
-    constexpr int WIN = 2 * R + 1, ROWS = WIN + 1;
-    const size_t lds = (size_t)a.num_levels * (ROWS * WIN + WIN) * TQ * sizeof(float);
+    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2;
+    const size_t lds = (size_t)a.num_levels * (ROWS * WIN + 2 * WIN) * TQ * sizeof(float);
     if (lds > 160 * 1024) return fail(ALO_ERR_UNSUPPORTED, "alo_corr_lookup: window too large for LDS");
     auto kern = corr_lookup_kernel<R>;
     if (lds > 48 * 1024) {
