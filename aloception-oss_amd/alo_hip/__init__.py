@@ -44,6 +44,8 @@ def _declare(lib):
     lib.alo_last_error.argtypes = []
     lib.alo_msda_forward.restype = ip
     lib.alo_msda_forward.argtypes = [vp] * 6 + [ip] * 9 + [vp]
+    lib.alo_msda_forward_fused.restype = ip
+    lib.alo_msda_forward_fused.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_msda_backward.restype = ip
     lib.alo_msda_backward.argtypes = [vp] * 9 + [ip] * 9 + [vp]
     lib.alo_corr_level_shape.restype = None
@@ -214,6 +216,39 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
     with torch.cuda.device(value.device), _timed(f"msda_fwd/Lq={Lq}", nbytes):
         _check(lib().alo_msda_forward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
                                       _ptr(out), N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
+    return out
+
+
+def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points):
+    """MSDeformAttn's prologue + gather in one launch (inference): raw offsets (N,Lq,M,L,P,2) and raw attention logits
+    (N,Lq,M,L*P) in ``value``'s dtype, reference points (N,Lq,L,2|4) in fp32 (fp64 for fp64 values) -> (N,Lq,M*D)."""
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_offsets.shape
+    geo = torch.float64 if value.dtype == torch.float64 else torch.float32
+    reference_points = reference_points.to(geo).contiguous()
+    _require_cuda_contiguous([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                              ("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits),
+                              ("reference_points", reference_points)])
+    if sampling_offsets.dtype != value.dtype or attn_logits.dtype != value.dtype:
+        raise RuntimeError("sampling_offsets and attn_logits must have the dtype of value")
+    if spatial_shapes.dtype != torch.int32 or level_start_index.dtype != torch.int32:
+        raise RuntimeError("spatial_shapes and level_start_index must be int32 tensors")
+    ref_dim = reference_points.shape[-1]
+    if tuple(reference_points.shape) != (N, Lq, L, ref_dim) or attn_logits.numel() != N * Lq * M * L * P:
+        raise RuntimeError("reference_points must be (N,Lq,L,2|4) and attn_logits (N,Lq,M,L*P)")
+    vdt = _DTYPE_CODE.get(value.dtype)
+    if vdt is None:
+        raise RuntimeError(f"ms_deform_attn: unsupported value dtype {value.dtype}")
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    # bytes actually streamed by the fused launch: value + out + raw offsets/logits (value dtype) + reference points
+    e = value.element_size()
+    nbytes = e * (N * S * M * D + N * Lq * M * D + N * Lq * M * L * P * 3) + reference_points.element_size() * reference_points.numel()
+    with torch.cuda.device(value.device), _timed(f"msda_fwd_fused/Lq={Lq}", nbytes):
+        _check(lib().alo_msda_forward_fused(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
+                                            _ptr(sampling_offsets), _ptr(attn_logits), _ptr(reference_points), _ptr(out),
+                                            N, S, M, D, L, Lq, P, ref_dim, vdt, _stream(value.device)))
     return out
 
 

@@ -17,6 +17,8 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
+import alo_hip
+
 from ..functions import MSDeformAttnFunction, load_MultiScaleDeformableAttention, ms_deform_attn_core_pytorch
 
 
@@ -43,6 +45,7 @@ class MSDeformAttn(nn.Module):
                 "(channels per head are spread over a power-of-two lane group)."
             )
         self.im2col_step = 64  # kept for API compatibility; the HIP op has no batch chunking
+        self.fused_prologue = True  # inference: fold softmax + location arithmetic into the kernel (alo_msda_forward_fused)
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
@@ -92,23 +95,33 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, S, M, self.d_model // M)
 
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError(
+                "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1])
+            )
         low_precision = value.dtype in (torch.bfloat16, torch.float16)
         geo = torch.float32 if low_precision else value.dtype
-        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2).to(geo)
-        weights = self.attention_weights(query).view(N, Lq, M, L * P).to(geo)
-        weights = F.softmax(weights, -1).view(N, Lq, M, L, P)
+        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
+        logits = self.attention_weights(query).view(N, Lq, M, L * P)
+
+        needs_grad = torch.is_grad_enabled() and any(
+            t.requires_grad for t in (value, offsets, logits, reference_points))
+        if "is_tracing" not in kwargs and not needs_grad and self.fused_prologue:
+            # inference: softmax + sampling-location arithmetic happen inside the kernel's descriptor stage
+            output = alo_hip.msda_forward_fused(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                                offsets.contiguous(), logits.contiguous(), reference_points)
+            return self.output_proj(output)
+
+        offsets = offsets.to(geo)
+        weights = F.softmax(logits.to(geo), -1).view(N, Lq, M, L, P)
         reference_points = reference_points.to(geo)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
             locations = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
+        else:
             locations = (
                 reference_points[:, :, None, :, None, :2]
                 + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
-            )
-        else:
-            raise ValueError(
-                "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1])
             )
 
         if "is_tracing" in kwargs:  # ONNX / TorchScript export branch of the reference (:138-144)

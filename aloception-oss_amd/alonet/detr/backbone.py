@@ -35,6 +35,34 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.reshape(1, -1, 1, 1).to(x.dtype) + shift.reshape(1, -1, 1, 1).to(x.dtype)
 
 
+def conv_bn(x, conv, bn, relu=False):
+    """``bn(conv(x))`` with the frozen batch-norm folded into the convolution's weight and bias.
+
+    A FrozenBatchNorm2d is a fixed per-channel affine map, so ``bn(conv(x)) == conv'(x)`` with
+    ``w' = w * scale[:, None, None, None]`` and ``b' = shift``: two full passes over the activation (multiply, add)
+    disappear.  In eval mode the folded tensors are cached (keyed on the parameter versions); in training mode they
+    are rebuilt every call so autograd still reaches ``conv.weight``.  The modules and their state-dict keys are
+    untouched.
+    """
+    if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.dtype, bn.weight.data_ptr(), bn.weight._version,
+               bn.running_var._version, bn.running_mean._version, bn.bias._version)
+        cached = conv.__dict__.get("_folded")
+        if conv.training or torch.is_grad_enabled() and conv.weight.requires_grad or cached is None or cached[0] != key:
+            scale, shift = bn.scale_shift()
+            w = (conv.weight.float() * scale.float().reshape(-1, 1, 1, 1)).to(conv.weight.dtype)
+            w = w.contiguous(memory_format=torch.channels_last)
+            b = shift.to(conv.weight.dtype)
+            if not conv.training and not (torch.is_grad_enabled() and conv.weight.requires_grad):
+                conv.__dict__["_folded"] = (key, w.detach(), b.detach())
+        else:
+            _, w, b = cached
+        out = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+    else:
+        out = bn(conv(x))
+    return F.relu_(out) if relu else out
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -50,11 +78,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
+        out = conv_bn(x, self.conv1, self.bn1, relu=True)
+        out = conv_bn(out, self.conv2, self.bn2, relu=True)
+        out = conv_bn(out, self.conv3, self.bn3)
+        return F.relu_(out + identity)
 
 
 _DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
@@ -100,7 +128,10 @@ class ResNetBody(nn.Module):
 
     def forward(self, x):
         out = {}
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        # NHWC activations: MIOpen's bf16/fp32 implicit-GEMM kernels are NHWC-native; fed NCHW they wrap every
+        # convolution in a pair of layout-transpose kernels
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, relu=True))
         for name in ("layer1", "layer2", "layer3", "layer4"):
             x = getattr(self, name)(x)
             if name in self.return_layers:

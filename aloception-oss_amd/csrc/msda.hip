@@ -16,6 +16,7 @@
 //   * backward: lanes reduce d/d(loc), d/d(attn) over channels with wave shuffles (no LDS, no block barriers, no
 //     serial thread-0 sum), grad_value goes out through hardware fp32/fp64 atomics.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -45,6 +46,7 @@ struct Dims {
     int blocks_per_batch;  // workgroups per batch item
     int iters_per_block;   // runs of (256 / G) pairs handled by one workgroup
     unsigned nblocks;
+    int ref_dim;           // fused prologue only: last dim of reference_points (2 or 4)
 };
 
 // Image-space position, validity and the four corners of one sampling point (cuh:285-291, :38-78).
@@ -88,10 +90,19 @@ __device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, cons
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, int SB>
+// FUSED = false: `loc` / `attn` are the reference op's inputs (sampling locations, softmax-ed attention weights), type LT.
+// FUSED = true : `loc` holds the RAW sampling offsets and `attn` the RAW attention logits (both of value's type T) and
+//                `ref` the reference points (N, Lq, L, ref_dim) of type CT; stage 1 evaluates what MSDeformAttn.forward
+//                does between its linear layers and the op (ms_deform_attn.py:119-133): softmax over the L*P logits and
+//                loc = ref + off / (W_l, H_l)   or   ref_xy + off / P * ref_wh * 0.5.
+template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, int SB, bool FUSED>
 __global__ void __launch_bounds__(kThreads)
 msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
-                const LT* __restrict__ loc, const LT* __restrict__ attn, T* __restrict__ out, const Dims dm) {
+                const void* __restrict__ loc_, const void* __restrict__ attn_, const CT* __restrict__ ref,
+                T* __restrict__ out, const Dims dm) {
+    using InT = typename std::conditional<FUSED, T, LT>::type;
+    const InT* loc = static_cast<const InT*>(loc_);
+    const InT* attn = static_cast<const InT*>(attn_);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* meta = reinterpret_cast<int*>(smem);
     unsigned char* dbase = smem + kMetaBytes;
@@ -127,10 +138,44 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
             Desc d;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { d.off[k] = kOutOfRange; d.w[k] = (CT)0; }
-            if (pair < dm.pairs_per_batch) {
-                const int l = s / dm.P;
-                const long g = (batch_pair0 + pair) * LP + s;
-                const CT x = (CT)ld(loc + 2 * g), y = (CT)ld(loc + 2 * g + 1), a = (CT)ld(attn + g);
+            const bool live = pair < dm.pairs_per_batch;
+            const long g = (batch_pair0 + (live ? pair : 0)) * LP + s;
+            CT x = (CT)0, y = (CT)0, a = (CT)0;
+            const int l = s / dm.P;
+            if (live) { x = (CT)ld(loc + 2 * g); y = (CT)ld(loc + 2 * g + 1); a = (CT)ld(attn + g); }
+            if constexpr (FUSED) {
+                // softmax over the pair's L*P logits
+                CT mx, sum;
+                if constexpr (LP_CT == 16) {  // the 16 samples of a pair sit in 16 consecutive, aligned lanes
+                    mx = a;
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+                    a = exp(a - mx);
+                    sum = a;
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                } else {
+                    const long g0 = g - s;
+                    mx = (CT)ld(attn + g0);
+                    for (int j = 1; j < LP; ++j) mx = fmax(mx, (CT)ld(attn + g0 + j));
+                    sum = (CT)0;
+                    for (int j = 0; j < LP; ++j) sum += exp((CT)ld(attn + g0 + j) - mx);
+                    a = exp(a - mx);
+                }
+                a = a / sum;
+                if (live) {
+                    const int q = pair / dm.M;
+                    const CT* r = ref + (((long)b * (dm.pairs_per_batch / dm.M) + q) * dm.L + l) * dm.ref_dim;
+                    if (dm.ref_dim == 2) {
+                        x = r[0] + x / (CT)meta[kMaxLevels + l];
+                        y = r[1] + y / (CT)meta[l];
+                    } else {
+                        x = r[0] + x / (CT)dm.P * r[2] * (CT)0.5;
+                        y = r[1] + y / (CT)dm.P * r[3] * (CT)0.5;
+                    }
+                }
+            }
+            if (live) {
                 const Tap<CT> t = make_tap<CT>(x, y, meta[l], meta[kMaxLevels + l], meta[2 * kMaxLevels + l]);
                 const CT hh = (CT)1 - t.lh, hw = (CT)1 - t.lw;
                 const CT w[4] = {hh * hw, hh * t.lw, t.lh * hw, t.lh * t.lw};
@@ -365,6 +410,7 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
     Dims d;
     d.S = S; d.M = M; d.D = D; d.L = L; d.P = P;
     d.pairs_per_batch = Lq * M;
+    d.ref_dim = 0;
     const int pairs = kThreads / G;
     const long iters_total = ((long)d.pairs_per_batch + pairs - 1) / pairs;
     long ipb = iters_total * N / 4096;  // keep >= ~4096 workgroups in flight when the problem allows it
@@ -394,11 +440,16 @@ int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char*
 #define ALO_FWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
     if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
         const size_t lds = kMetaBytes + (size_t)(kThreads / G) * ((size_t)L * P * sizeof(FwdDesc<CT>) + 16);       \
+        if (fused) {                                                                                               \
+            if (LPCT == 16 && sb == 2)                                                                             \
+                return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, 2, true>, dm, lds, stream, "alo_msda_forward_fused", args); \
+            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 2), true>, dm, lds, stream, "alo_msda_forward_fused", args); \
+        }                                                                                                          \
         if (LPCT == 16 && sb == 2)                                                                                 \
-            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, 2>, dm, lds, stream, "alo_msda_forward", args); \
+            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, 2, false>, dm, lds, stream, "alo_msda_forward", args); \
         if (LPCT == 16 && sb == 8)                                                                                 \
-            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 8 : 2)>, dm, lds, stream, "alo_msda_forward", args); \
-        return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 2)>, dm, lds, stream, "alo_msda_forward", args);     \
+            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 8 : 2), false>, dm, lds, stream, "alo_msda_forward", args); \
+        return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 2), false>, dm, lds, stream, "alo_msda_forward", args);     \
     }
 #define ALO_BWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
     if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
@@ -433,24 +484,48 @@ int validate(const void* value, const int32_t* shapes, const int32_t* lstart, co
 
 using namespace alo;
 
-extern "C" int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                                const void* sampling_loc, const void* attn_weight, void* out, int N, int S, int M,
-                                int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
+namespace {
+int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
+                 const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
+                 int P, int value_dtype, int loc_dtype, void* stream_) {
     size_t elem = 0;
-    if (int rc = validate(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P,
-                          value_dtype, loc_dtype, &elem))
+    if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
+                          loc_dtype, &elem))
         return rc;
     ALO_REQUIRE(out, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward: out is null");
+    const bool fused = ref != nullptr;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const bool aligned = (((uintptr_t)value | (uintptr_t)out) & 15) == 0;
     const Plan plan = make_plan(D, L, P, elem, aligned);
     Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
+    dm.ref_dim = ref_dim;
     const int sb = tuning().fwd_batch;
-    void* args[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &out, &dm};
+    void* args[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm};
     if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_FWD_CASE, double, double, double, 2) }
     if (value_dtype == ALO_BF16) { ALO_ALL_CASES(ALO_FWD_CASE, bf16_t, float, float, 8) }
     return fail(ALO_ERR_UNSUPPORTED, "alo_msda_forward: no kernel for vec=%d group=%d", plan.vec, plan.g);
+}
+}  // namespace
+
+extern "C" int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                const void* sampling_loc, const void* attn_weight, void* out, int N, int S, int M,
+                                int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
+    return forward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, 0, out, N, S, M, D,
+                        L, Lq, P, value_dtype, loc_dtype, stream_);
+}
+
+extern "C" int alo_msda_forward_fused(const void* value, const int32_t* spatial_shapes,
+                                      const int32_t* level_start_index, const void* sampling_offsets,
+                                      const void* attn_logits, const void* reference_points, void* out, int N, int S,
+                                      int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype, void* stream_) {
+    ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused: reference_points is null");
+    ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_forward_fused: last dim of reference_points must be 2 or 4, got %d", ref_dim);
+    // the geometry dtype is implied: fp64 for fp64 values, fp32 otherwise (loc_dtype only steers validation here)
+    const int loc_dtype = value_dtype == ALO_F64 ? ALO_F64 : ALO_F32;
+    return forward_impl(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
+                        ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
 }
 
 extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,

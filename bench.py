@@ -252,7 +252,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    enc = next((v for k, v in kernels.items() if k.startswith("msda_fwd/Lq=22223")), None)
+    enc = next((v for k, v in kernels.items() if k.startswith("msda_fwd") and k.endswith("Lq=22223")), None)
     line = {
         "metric": "frames/sec (whole node) DeformableDETR-R50 inference",
         "value": round(det_fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -262,7 +262,7 @@ def main():
                                "MSDeformAttn on HIP kernels; random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": None if enc is None else {
-            "bound": "hbm", "kernel": "msda_fwd_kernel (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
+            "bound": "hbm", "kernel": "msda_fwd_kernel, fused prologue (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
             "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc["hbm_frac"], "traffic": None,
             "alg_bytes_per_launch": enc["alg_bytes"], "ms_per_launch": enc["ms_avg"]},
         "kernels": kernels,

@@ -7,6 +7,7 @@
  * What each entry point replaces in the reference (/root/reference):
  *   alo_msda_forward   <- alonet_custom::ms_deform_attn_forward   alonet/deformable_detr/ops/src/vision.cpp:21-24,
  *                          ms_deform_attn.h:20-39, cuda/ms_deform_attn_cuda.cu:20-80, cuda/ms_deform_im2col_cuda.cuh:237-299
+ *   alo_msda_forward_fused <- the elementwise prologue of MSDeformAttn.forward + the op   ops/modules/ms_deform_attn.py:119-153
  *   alo_msda_backward  <- alonet_custom::ms_deform_attn_backward  ms_deform_attn.h:41-62, cuda/ms_deform_attn_cuda.cu:83-153,
  *                          cuda/ms_deform_im2col_cuda.cuh:87-234,301-920
  *   alo_corr_build     <- CorrBlock.__init__ / CorrBlock.corr     alonet/raft/corr.py:13-27,52-60
@@ -70,8 +71,8 @@ const char* alo_last_error(void);
  *   attn_weight         (N, Lq, M, L, P)    loc_dtype
  *   out                 (N, Lq, M*D)        value_dtype          m-major, c-minor
  *
- * dtype pairs (value_dtype, loc_dtype): (F32,F32) (F64,F64) (BF16,F32) (BF16,BF16).  Arithmetic is fp64 for F64 and
- * fp32 otherwise.  Any D >= 1 is accepted; D % (16 / sizeof(value element)) == 0 with 16-byte aligned `value`/`out`
+ * dtype pairs (value_dtype, loc_dtype): (F32,F32) (F64,F64) (BF16,F32).  Arithmetic is fp64 for F64 and fp32
+ * otherwise (bf16 locations would cost a third of a pixel on a 167-wide map, so they are not offered).  Any D >= 1 is accepted; D % (16 / sizeof(value element)) == 0 with 16-byte aligned `value`/`out`
  * takes the vectorised path.  L <= 32.  N*S*M*D*sizeof(element) per batch item must stay below 3 GiB.
  * The reference's `im2col_step` is a scheduling hint with no effect on results and has no counterpart here.
  */
@@ -79,6 +80,27 @@ int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int
                      const void* sampling_loc, const void* attn_weight, void* out,
                      int N, int S, int M, int D, int L, int Lq, int P,
                      int value_dtype, int loc_dtype, void* stream);
+
+/*
+ * Multi-scale deformable attention, forward, with MSDeformAttn's prologue fused in (an extension: the reference has no
+ * such entry point — it evaluates these steps as separate PyTorch ops, alonet/deformable_detr/ops/modules/ms_deform_attn.py:119-133):
+ *
+ *   attn[b,q,m,:]  = softmax over the L*P entries of attn_logits[b,q,m,:]
+ *   loc[b,q,m,l,p] = ref[b,q,l,0:2] + sampling_offsets[b,q,m,l,p,:] / (W_l, H_l)                       (ref_dim == 2)
+ *                  = ref[b,q,l,0:2] + sampling_offsets[b,q,m,l,p,:] / P * ref[b,q,l,2:4] * 0.5          (ref_dim == 4)
+ *   out            = alo_msda_forward(value, ..., loc, attn)
+ *
+ *   sampling_offsets    (N, Lq, M, L, P, 2)   value_dtype      raw output of the sampling_offsets linear layer
+ *   attn_logits         (N, Lq, M, L*P)       value_dtype      raw output of the attention_weights linear layer
+ *   reference_points    (N, Lq, L, ref_dim)   F64 when value_dtype is F64, F32 otherwise
+ *
+ * Softmax and location arithmetic run in fp32 (fp64 for F64) inside the kernel's descriptor stage; nothing but `out`
+ * is written.  Inference path only (the gradient path uses alo_msda_forward / alo_msda_backward).
+ */
+int alo_msda_forward_fused(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                           const void* sampling_offsets, const void* attn_logits, const void* reference_points,
+                           void* out, int N, int S, int M, int D, int L, int Lq, int P, int ref_dim,
+                           int value_dtype, void* stream);
 
 /*
  * Multi-scale deformable attention, backward (gradients of the forward above w.r.t. value, sampling_loc, attn_weight).
@@ -89,7 +111,7 @@ int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int
  *   grad_attn_weight    (N, Lq, M, L, P)    grad dtype
  *
  * grad dtype is F64 when value_dtype is F64 and F32 otherwise (bf16 storage accumulates its gradients in fp32; the
- * caller narrows afterwards).  Supported (value_dtype, loc_dtype): (F32,F32) (F64,F64) (BF16,F32) (BF16,BF16).
+ * caller narrows afterwards).  Supported (value_dtype, loc_dtype): (F32,F32) (F64,F64) (BF16,F32).
  * grad_value is accumulated with hardware floating-point atomics, so — exactly like the reference — its low-order
  * bits depend on scheduling.
  */

@@ -237,3 +237,69 @@ def test_full_size_properties_batch8():
     ob = alo_hip.msda_forward(vb, sh, st, loc, attn, 64).float()
     of = alo_hip.msda_forward(vb.float(), sh, st, loc, attn, 64)
     assert ((ob - of).abs() <= of.abs() * 2.0 ** -8 + 1e-6).all()
+
+
+# ---- fused prologue (softmax + sampling-location arithmetic inside the kernel) ------------------------------------
+def _prologue_in_torch(offsets, logits, ref, shapes, P):
+    """What MSDeformAttn.forward does between its linear layers and the op (reference ms_deform_attn.py:119-133)."""
+    N, Lq, M, L = offsets.shape[:4]
+    attn = torch.softmax(logits, -1).view(N, Lq, M, L, P)
+    if ref.shape[-1] == 2:
+        normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + offsets / P * ref[:, :, None, :, None, 2:] * 0.5
+    return loc.contiguous(), attn.contiguous()
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("shape", [(2, 8, 32, 77, [(16, 21), (8, 11), (4, 6), (2, 3)], 4),  # L*P = 16: shuffle softmax
+                                   (1, 4, 16, 300, [(9, 7), (5, 4), (3, 3)], 2),  # L*P = 6: generic softmax
+                                   (1, 2, 30, 21, [(6, 4), (3, 2)], 2)])  # scalar channel path
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+def test_fused_prologue_matches_unfused(shape, ref_dim, dtype):
+    N, M, D, Lq, shapes_l, P = shape
+    L = len(shapes_l)
+    gen = torch.Generator(device=DEV).manual_seed(99 + D + ref_dim)
+    shapes = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
+    start = dev(level_start(shapes_l))
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    geo = torch.float64 if dtype == torch.float64 else torch.float32
+    value = torch.randn(N, S, M, D, generator=gen, device=DEV, dtype=geo).to(dtype)
+    offsets = (torch.randn(N, Lq, M, L, P, 2, generator=gen, device=DEV, dtype=geo) * 2.5).to(dtype)
+    logits = (torch.randn(N, Lq, M, L * P, generator=gen, device=DEV, dtype=geo) * 2.0).to(dtype)
+    ref = torch.rand(N, Lq, L, ref_dim, generator=gen, device=DEV, dtype=geo)
+    if ref_dim == 4:
+        ref[..., 2:] *= 0.4
+    fused = alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref)
+    loc, attn = _prologue_in_torch(offsets.to(geo), logits.to(geo), ref, shapes, P)
+    plain = alo_hip.msda_forward(value, shapes, start, loc, attn, 64)
+    assert fused.dtype == dtype and fused.shape == plain.shape
+    if dtype == torch.float64:
+        assert (fused - plain).abs().max().item() <= 1e-12
+    elif dtype == torch.float32:
+        assert (fused - plain).abs().max().item() <= 5e-6  # softmax summation order, exp
+    else:  # both round the same fp32 sum to bf16: at most one bf16 ulp apart
+        assert ((fused.float() - plain.float()).abs() <= plain.float().abs() * 2.0 ** -7 + 1e-6).all()
+
+
+def test_module_uses_fused_prologue_in_inference_and_unfused_under_grad(golden):
+    from alonet.deformable_detr.ops.modules import MSDeformAttn
+
+    g = golden("g4_msda_module.npz")
+    d_model, n_levels, n_heads, n_points = (int(x) for x in g["cfg"])
+    m = MSDeformAttn(d_model, n_levels, n_heads, n_points).double()
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    m = m.to(DEV)
+    args = (dev(g["query"]), dev(g["ref4"]), dev(g["src"]), dev(g["shapes"]).to(torch.int32), dev(g["level_start"]),
+            dev(g["mask"]))
+    with alo_hip.LaunchTimer() as t1, torch.no_grad():
+        fused = m(*args)
+    with alo_hip.LaunchTimer() as t2:
+        plain = m(*args)  # parameters require grad -> the reference-shaped op (differentiable) is used
+    assert any(k.startswith("msda_fwd_fused") for k in t1.summary())
+    assert any(k.startswith("msda_fwd/") for k in t2.summary())
+    np.testing.assert_allclose(fused.cpu().numpy(), g["out4"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(plain.detach().cpu().numpy(), g["out4"], rtol=1e-10, atol=1e-11)
+    plain.sum().backward()
+    assert m.sampling_offsets.weight.grad is not None and torch.isfinite(m.value_proj.weight.grad).all()
