@@ -92,6 +92,37 @@ def bench_msda_fwd(N, Lq, kind, dtype, reps):
                 alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
+def fused_inputs(N, dtype, seed=0):
+    """Raw module tensors for the fused-prologue entry point, encoder-like: offsets = the init ring (+ jitter) in
+    pixels, reference points = every pixel's own centre on every level."""
+    shapes, start, S = detr_geometry()
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    value = torch.randn(N, S, 8, 32, generator=gen, device=DEV).to(dtype)
+    refs = []
+    for (h, w) in DETR_SHAPES:
+        ys, xs = torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w, device=DEV), indexing="ij")
+        refs.append(torch.stack([(xs.reshape(-1) + 0.5) / w, (ys.reshape(-1) + 0.5) / h], -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(N, S, 4, 2).contiguous()
+    ang = torch.arange(8, device=DEV, dtype=torch.float32) * (2 * torch.pi / 8)
+    ring = torch.stack([ang.cos(), ang.sin()], -1)
+    ring = ring / ring.abs().max(-1, keepdim=True)[0]
+    steps = torch.arange(1, 5, device=DEV, dtype=torch.float32)
+    off = (ring[:, None, None, :] * steps[None, None, :, None]).expand(8, 4, 4, 2)
+    offsets = off[None, None].expand(N, S, 8, 4, 4, 2) + (torch.rand(N, S, 8, 4, 4, 2, generator=gen, device=DEV) - 0.5)
+    logits = torch.randn(N, S, 8, 16, generator=gen, device=DEV)
+    return value, shapes, start, offsets.to(dtype).contiguous(), logits.to(dtype), ref
+
+
+def bench_msda_fused(N, dtype, reps):
+    value, shapes, start, offsets, logits, ref = fused_inputs(N, dtype)
+    S = value.shape[1]
+    t = time_launches(lambda: alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref), reps)
+    e = value.element_size()
+    nbytes = e * (N * S * 256 * 2 + N * S * 8 * 16 * 3) + ref.numel() * 4
+    return dict(kernel="msda_fwd_fused[encoder]", N=N, Lq=S, dtype=str(dtype).split(".")[-1], ms=t * 1e3,
+                alg_bytes=nbytes, GBps=nbytes / t / 1e9)
+
+
 def bench_msda_bwd(N, Lq, kind, dtype, reps):
     value, shapes, start, loc, attn = msda_inputs(N, Lq, kind, dtype)
     go = torch.randn(N, Lq, 256, device=DEV).to(dtype)
@@ -157,6 +188,8 @@ def main():
         res = []
         if w == "msda_enc":
             res = [bench_msda_fwd(a.N, S, "encoder", dt, a.reps) for dt in dts]
+        elif w == "msda_fused":
+            res = [bench_msda_fused(a.N, dt, a.reps) for dt in dts]
         elif w == "msda_rand":
             res = [bench_msda_fwd(a.N, S, "uniform", dt, a.reps) for dt in dts]
         elif w == "msda_dec":
