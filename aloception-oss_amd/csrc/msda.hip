@@ -15,6 +15,7 @@
 //     with N = 8 each XCD's L2 holds exactly one image's value map.
 //   * backward: lanes reduce d/d(loc), d/d(attn) over channels with wave shuffles (no LDS, no block barriers, no
 //     serial thread-0 sum), grad_value goes out through hardware fp32/fp64 atomics.
+#include <climits>
 #include <cstdlib>
 #include <type_traits>
 
@@ -47,6 +48,7 @@ struct Dims {
     int iters_per_block;   // runs of (256 / G) pairs handled by one workgroup
     unsigned nblocks;
     int ref_dim;           // fused prologue only: last dim of reference_points (2 or 4)
+    int ablate;            // tuning experiments only (ALO_MSDA_ABLATE): 1 = no gathers, 2 = descriptors built once
 };
 
 // Image-space position, validity and the four corners of one sampling point (cuh:285-291, :38-78).
@@ -55,6 +57,7 @@ struct Tap {
     bool valid, ok[4];
     int base;  // pixel index (within the batch item's S rows) of the (h_low, w_low) corner
     int W;
+    int h_low, w_low;
     CT lh, lw;
 };
 template <typename CT>
@@ -75,6 +78,8 @@ __device__ __forceinline__ Tap<CT> make_tap(CT loc_x, CT loc_y, int H, int W, in
     t.ok[3] = t.valid && hh && wh;
     t.base = start + h_low * W + w_low;
     t.W = W;
+    t.h_low = h_low;
+    t.w_low = w_low;
     return t;
 }
 
@@ -131,7 +136,7 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
         if (pair0 >= dm.pairs_per_batch) break;  // uniform
 
         // ---- stage 1: one descriptor per (pair, level, point) ------------------------------------------------------
-        const int nsamp = PAIRS * LP;
+        const int nsamp = (dm.ablate == 2 && it > 0) ? 0 : PAIRS * LP;
         for (int si = tid; si < nsamp; si += kThreads) {
             const int pl = si / LP, s = si - pl * LP;
             const int pair = pair0 + pl;
@@ -216,7 +221,8 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                                 for (int k = 0; k < 4; ++k) { d[j].off[k] = kOutOfRange; d[j].w[k] = (CT)0; }
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) raw[j][k] = Ld::load(rsrc, d[j].off[k] + coff);
+                            for (int k = 0; k < 4; ++k)
+                                raw[j][k] = Ld::load(rsrc, dm.ablate == 1 ? kOutOfRange : d[j].off[k] + coff);
                         }
 #pragma unroll
                         for (int j = 0; j < SB; ++j) {
@@ -235,6 +241,277 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
         }
         __syncthreads();  // descriptors are rewritten by the next run
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward, tiled encoder variant: sample footprint staged in LDS
+// ------------------------------------------------------------------------------------------------------------------
+// The generic kernel above is bound by the rate at which a CU's texture path accepts gather lanes (64 B/clk): every
+// (query, head, point) costs four 64/128-byte requests whether or not they hit in L1 (measured: with the gathers pointed
+// out of range the kernel still takes 80 % of its time).  In the encoder the queries ARE the pixels of the pyramid, and
+// neighbouring queries sample overlapping neighbourhoods.  Here one workgroup owns (image, head, TY x 8 tile of query
+// pixels of one level): stage 1 builds the tile's sampling taps and, per value level, the bounding box of every corner
+// they touch; the boxes (one head's D channels per pixel) are copied into LDS once; the gather then runs out of LDS at
+// ds_read_b128 rate.  A level whose box does not fit the LDS budget is gathered from global memory exactly as in the
+// generic kernel, so nothing is assumed about the sampling locations — a wider spread only costs speed.
+constexpr int kTileLevels = 4;
+struct TileArgs {
+    const void* value; const void* loc; const void* attn; const void* ref; void* out;
+    int N, S, M, D, Lq, ref_dim;
+    int H[kTileLevels], W[kTileLevels], start[kTileLevels];
+    int tiles_x[kTileLevels], tile_prefix[kTileLevels + 1];
+    int tiles_total;
+    unsigned nblocks;
+    int window_budget;  // bytes of LDS available for staged windows
+};
+
+template <typename T, typename LT, typename CT, int VEC, int G, bool FUSED>
+__global__ void __launch_bounds__(kThreads)
+msda_fwd_tile_kernel(const TileArgs a) {
+    constexpr int TQ = kThreads / G;  // queries per tile
+    constexpr int TX = 8, TY = TQ / TX;
+    constexpr int L = kTileLevels, P = 4, LP = L * P;
+    constexpr int ROWB = G * 16;      // bytes of one (pixel, head) row: D * sizeof(T)
+    constexpr int NK = TQ * LP / kThreads;  // taps built per thread
+    using Desc = FwdDesc<CT>;
+    using Ld = Loader<T, CT, VEC>;
+    using InT = typename std::conditional<FUSED, T, LT>::type;
+    constexpr int PAIR_STRIDE = LP * (int)sizeof(Desc) + 16;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* bbox = reinterpret_cast<int*>(smem);  // [L][ymin, ymax, xmin, xmax]
+    unsigned char* dbase = smem + 64;
+    unsigned char* win = dbase + TQ * PAIR_STRIDE;
+
+    const InT* loc = static_cast<const InT*>(a.loc);
+    const InT* attn = static_cast<const InT*>(a.attn);
+    const CT* ref = static_cast<const CT*>(a.ref);
+    const T* value = static_cast<const T*>(a.value);
+    T* out = static_cast<T*>(a.out);
+
+    const unsigned lb = xcd_contiguous_block(blockIdx.x, a.nblocks);
+    const int m = lb % a.M;
+    const int t = (lb / a.M) % a.tiles_total;
+    const int b = lb / (a.M * a.tiles_total);
+    int lq = 0;
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+        if (t >= a.tile_prefix[l]) lq = l;
+    const int tt = t - a.tile_prefix[lq];
+    const int ty = tt / a.tiles_x[lq], tx = tt - ty * a.tiles_x[lq];
+    const int tid = threadIdx.x;
+
+    if (tid < 4 * L) bbox[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+    __syncthreads();
+
+    const unsigned row_elems = (unsigned)a.M * a.D;
+    const unsigned row_bytes = row_elems * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(value + (size_t)b * a.S * row_elems, (unsigned)a.S * row_bytes);
+
+    // ---- stage 1: taps (registers) + per-level bounding box ------------------------------------------------------------
+    // si = tid + k*256 -> query slot si / 16, sample s = si % 16 = tid % 16: all taps of a thread belong to ONE level
+    const int s = tid & (LP - 1);
+    const int lv = s / P;
+    const int Hl = a.H[lv], Wl = a.W[lv];
+    int tyl[NK], txl[NK];
+    unsigned okm[NK];
+    CT tw[NK][4];
+    int ylo = INT_MAX, yhi = INT_MIN, xlo = INT_MAX, xhi = INT_MIN;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int ql = (tid + k * kThreads) / LP;
+        const int qy = ty * TY + ql / TX, qx = tx * TX + ql % TX;
+        const bool live = qy < a.H[lq] && qx < a.W[lq];
+        const int q = a.start[lq] + qy * a.W[lq] + qx;
+        const long g = (((long)b * a.Lq + (live ? q : 0)) * a.M + m) * LP + s;
+        CT x = (CT)0, y = (CT)0, w = (CT)0;
+        if (live) { x = (CT)ld(loc + 2 * g); y = (CT)ld(loc + 2 * g + 1); w = (CT)ld(attn + g); }
+        if constexpr (FUSED) {
+            CT mx = w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+            w = exp(w - mx);
+            CT sum = w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            w = w / sum;
+            if (live) {
+                const CT* r = ref + (((long)b * a.Lq + q) * L + lv) * a.ref_dim;
+                if (a.ref_dim == 2) {
+                    x = r[0] + x / (CT)Wl;
+                    y = r[1] + y / (CT)Hl;
+                } else {
+                    x = r[0] + x / (CT)P * r[2] * (CT)0.5;
+                    y = r[1] + y / (CT)P * r[3] * (CT)0.5;
+                }
+            }
+        }
+        const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
+        const CT hh = (CT)1 - tp.lh, hw = (CT)1 - tp.lw;
+        const CT wk[4] = {hh * hw, hh * tp.lw, tp.lh * hw, tp.lh * tp.lw};
+        unsigned mask = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = live && tp.ok[c];
+            tw[k][c] = ok ? wk[c] * w : (CT)0;
+            mask |= ok ? (1u << c) : 0u;
+        }
+        okm[k] = mask;
+        tyl[k] = tp.h_low;
+        txl[k] = tp.w_low;
+        if (mask) {  // rows / columns of the map this tap really touches
+            ylo = min(ylo, max(tp.h_low, 0));
+            yhi = max(yhi, min(tp.h_low + 1, Hl - 1));
+            xlo = min(xlo, max(tp.w_low, 0));
+            xhi = max(xhi, min(tp.w_low + 1, Wl - 1));
+        }
+    }
+    // lanes of one level inside a wave differ in bits {0,1} (point) and {4,5} (query): reduce over those
+#pragma unroll
+    for (int o : {1, 2, 16, 32}) {
+        ylo = min(ylo, __shfl_xor(ylo, o, 64));
+        yhi = max(yhi, __shfl_xor(yhi, o, 64));
+        xlo = min(xlo, __shfl_xor(xlo, o, 64));
+        xhi = max(xhi, __shfl_xor(xhi, o, 64));
+    }
+    if ((tid & 0x33) == 0) {
+        atomicMin(&bbox[lv * 4 + 0], ylo);
+        atomicMax(&bbox[lv * 4 + 1], yhi);
+        atomicMin(&bbox[lv * 4 + 2], xlo);
+        atomicMax(&bbox[lv * 4 + 3], xhi);
+    }
+    __syncthreads();
+
+    // ---- window plan (every thread computes the same thing) ---------------------------------------------------------------
+    int wy0[L], wx0[L], wh[L], ww[L], wbase[L];
+    bool staged[L];
+    int used = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int y0 = bbox[l * 4 + 0], y1 = bbox[l * 4 + 1], x0 = bbox[l * 4 + 2], x1 = bbox[l * 4 + 3];
+        const bool any = y0 <= y1 && x0 <= x1;
+        wy0[l] = any ? y0 : 0;
+        wx0[l] = any ? x0 : 0;
+        wh[l] = any ? y1 - y0 + 1 : 0;
+        ww[l] = any ? x1 - x0 + 1 : 0;
+        const long bytes = (long)wh[l] * ww[l] * ROWB;
+        staged[l] = used + bytes <= (long)a.window_budget;
+        wbase[l] = used;
+        if (staged[l]) used += (int)bytes;
+    }
+
+    // ---- descriptors: LDS offsets for staged levels, global byte offsets otherwise -------------------------------------------
+    {
+        const bool st = staged[lv];
+        const int y0 = wy0[lv], x0 = wx0[lv], wd = ww[lv], base = wbase[lv], start = a.start[lv];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int ql = (tid + k * kThreads) / LP;
+            Desc d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int y = tyl[k] + (c >> 1), x = txl[k] + (c & 1);
+                const bool ok = (okm[k] >> c) & 1u;
+                unsigned off;
+                if (st) off = ok ? (unsigned)(base + ((y - y0) * wd + (x - x0)) * ROWB) : (unsigned)base;
+                else off = ok ? (unsigned)(start + y * Wl + x) * row_bytes : kOutOfRange;
+                d.off[c] = off;
+                d.w[c] = tw[k][c];
+            }
+            *reinterpret_cast<Desc*>(dbase + ql * PAIR_STRIDE + s * (int)sizeof(Desc)) = d;
+        }
+    }
+
+    // ---- copy the staged windows: one head's D channels of every pixel in the box ---------------------------------------------
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        if (!staged[l]) continue;
+        const int chunks = wh[l] * ww[l] * G;
+        const float inv_w = 1.0f / (float)(ww[l] > 0 ? ww[l] : 1);
+        for (int i = tid; i < chunks; i += kThreads) {
+            const int px = i / G, part = i - px * G;
+            int py = (int)(((float)px + 0.5f) * inv_w);
+            int pxx = px - py * ww[l];
+            if (pxx < 0) { --py; pxx += ww[l]; }
+            if (pxx >= ww[l]) { ++py; pxx -= ww[l]; }
+            const unsigned goff = (unsigned)(a.start[l] + (wy0[l] + py) * a.W[l] + wx0[l] + pxx) * row_bytes +
+                                  (unsigned)(m * a.D) * (unsigned)sizeof(T) + (unsigned)part * 16u;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0);
+            *reinterpret_cast<u32x4*>(win + wbase[l] + i * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- gather: G lanes per query, samples of a staged level come from LDS ---------------------------------------------------
+    const int ql = tid / G, part = tid % G;
+    const int qy = ty * TY + ql / TX, qx = tx * TX + ql % TX;
+    if (qy < a.H[lq] && qx < a.W[lq]) {
+        const int q = a.start[lq] + qy * a.W[lq] + qx;
+        const unsigned char* dp = dbase + ql * PAIR_STRIDE;
+        const unsigned coff = (unsigned)(m * a.D + part * VEC) * (unsigned)sizeof(T);
+        CT acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = (CT)0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            Desc d[P];
+            typename Ld::raw_t raw[P][4];
+#pragma unroll
+            for (int p = 0; p < P; ++p) d[p] = *reinterpret_cast<const Desc*>(dp + (l * P + p) * (int)sizeof(Desc));
+            if (staged[l]) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        raw[p][c] = *reinterpret_cast<const typename Ld::raw_t*>(win + d[p].off[c] + part * 16);
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) raw[p][c] = Ld::load(rsrc, d[p].off[c] + coff);
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    CT v[VEC];
+                    Ld::widen(raw[p][c], v);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] += d[p].w[c] * v[i];
+                }
+        }
+        store_vec<T, CT, VEC>(out + (((long)b * a.Lq + q) * a.M + m) * a.D + part * VEC, acc);
+    }
+}
+
+// Can the tiled kernel take this call?  (host copy of the shapes known, the model's L = P = 4, queries = pixels,
+// channels of a head = one 16-byte load per lane for 4 or 8 lanes)
+bool tile_plan(TileArgs& ta, const int32_t* shapes_host, int N, int S, int M, int D, int L, int Lq, int P, size_t elem,
+               bool aligned) {
+    if (!shapes_host || L != kTileLevels || P != 4 || Lq != S || !aligned) return false;
+    const int vec = (int)(16 / elem);
+    if (D % vec != 0) return false;
+    const int g = D / vec;
+    if (!((elem == 2 && g == 4) || (elem == 4 && g == 8))) return false;
+    const int tq = kThreads / g, tyq = tq / 8;
+    long total = 0, start = 0;
+    for (int l = 0; l < L; ++l) {
+        const int h = shapes_host[2 * l], w = shapes_host[2 * l + 1];
+        if (h <= 0 || w <= 0) return false;
+        ta.H[l] = h; ta.W[l] = w; ta.start[l] = (int)start;
+        ta.tiles_x[l] = (w + 7) / 8;
+        ta.tile_prefix[l] = (int)total;
+        total += (long)ta.tiles_x[l] * ((h + tyq - 1) / tyq);
+        start += (long)h * w;
+    }
+    if (start != S) return false;
+    ta.tile_prefix[L] = (int)total;
+    ta.tiles_total = (int)total;
+    const long nblocks = total * M * N;
+    if (nblocks <= 0 || nblocks >= 0x7fffffffL) return false;
+    ta.nblocks = (unsigned)nblocks;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -371,14 +648,21 @@ struct Plan {
 // Kernel-tuning knobs, read once from the environment (results never depend on them).
 //   ALO_MSDA_FWD_BATCH  2 | 4 | 8   sampling points whose 4 corner loads are put in flight together (forward)
 //   ALO_MSDA_ITERS      1..64       runs of pairs per workgroup (0 = automatic)
+//   ALO_MSDA_TILE       0 | 1       tiled (LDS-staged) encoder kernel off / on;  ALO_MSDA_TILE_LDS = its window budget
 struct Tuning {
     int fwd_batch = 4;
     int iters = 0;
+    int ablate = 0;
+    int tile = 1;          // ALO_MSDA_TILE=0 disables the tiled encoder kernel
+    int tile_lds = 44 * 1024;  // ALO_MSDA_TILE_LDS: bytes of LDS for staged windows (2 workgroups / CU at 44 KB)
 };
 const Tuning& tuning() {
     static const Tuning t = [] {
         Tuning x;
         if (const char* e = getenv("ALO_MSDA_FWD_BATCH")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_batch = v; }
+        if (const char* e = getenv("ALO_MSDA_ABLATE")) x.ablate = atoi(e);
+        if (const char* e = getenv("ALO_MSDA_TILE")) x.tile = atoi(e);
+        if (const char* e = getenv("ALO_MSDA_TILE_LDS")) { const int v = atoi(e); if (v >= 0 && v <= 120 * 1024) x.tile_lds = v; }
         if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
         return x;
     }();
@@ -411,6 +695,7 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
     d.S = S; d.M = M; d.D = D; d.L = L; d.P = P;
     d.pairs_per_batch = Lq * M;
     d.ref_dim = 0;
+    d.ablate = tuning().ablate;
     const int pairs = kThreads / G;
     const long iters_total = ((long)d.pairs_per_batch + pairs - 1) / pairs;
     long ipb = iters_total * N / 4096;  // keep >= ~4096 workgroups in flight when the problem allows it
@@ -485,9 +770,20 @@ int validate(const void* value, const int32_t* shapes, const int32_t* lstart, co
 using namespace alo;
 
 namespace {
+template <typename K>
+int launch_tile(K kernel, const TileArgs& ta, size_t lds, hipStream_t stream) {
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward(tile): %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kernel, dim3(ta.nblocks), dim3(kThreads), lds, stream, ta);
+    return check_launch("alo_msda_forward(tile)");
+}
+
 int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
-                 const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
-                 int P, int value_dtype, int loc_dtype, void* stream_) {
+                 const void* attn, const void* ref, int ref_dim, const int32_t* shapes_host, void* out, int N, int S,
+                 int M, int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
                           loc_dtype, &elem))
@@ -500,6 +796,21 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
     Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
     dm.ref_dim = ref_dim;
     const int sb = tuning().fwd_batch;
+    if (tuning().tile && value_dtype != ALO_F64) {
+        TileArgs ta;
+        if (tile_plan(ta, shapes_host, N, S, M, D, L, Lq, P, elem, aligned)) {
+            ta.value = value; ta.loc = loc; ta.attn = attn; ta.ref = ref; ta.out = out;
+            ta.N = N; ta.S = S; ta.M = M; ta.D = D; ta.Lq = Lq; ta.ref_dim = ref_dim;
+            ta.window_budget = tuning().tile_lds;
+            const int g = D / (int)(16 / elem);
+            const size_t lds = 64 + (size_t)(kThreads / g) * (16 * sizeof(FwdDesc<float>) + 16) + (size_t)ta.window_budget;
+            if (value_dtype == ALO_BF16)
+                return fused ? launch_tile(msda_fwd_tile_kernel<bf16_t, float, float, 8, 4, true>, ta, lds, stream)
+                             : launch_tile(msda_fwd_tile_kernel<bf16_t, float, float, 8, 4, false>, ta, lds, stream);
+            return fused ? launch_tile(msda_fwd_tile_kernel<float, float, float, 4, 8, true>, ta, lds, stream)
+                         : launch_tile(msda_fwd_tile_kernel<float, float, float, 4, 8, false>, ta, lds, stream);
+        }
+    }
     void* args[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm};
     if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_FWD_CASE, double, double, double, 2) }
@@ -511,21 +822,22 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
 extern "C" int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
                                 const void* sampling_loc, const void* attn_weight, void* out, int N, int S, int M,
                                 int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
-    return forward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, 0, out, N, S, M, D,
-                        L, Lq, P, value_dtype, loc_dtype, stream_);
+    return forward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, 0, nullptr, out, N,
+                        S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
 }
 
 extern "C" int alo_msda_forward_fused(const void* value, const int32_t* spatial_shapes,
                                       const int32_t* level_start_index, const void* sampling_offsets,
-                                      const void* attn_logits, const void* reference_points, void* out, int N, int S,
-                                      int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype, void* stream_) {
+                                      const void* attn_logits, const void* reference_points,
+                                      const int32_t* spatial_shapes_host, void* out, int N, int S, int M, int D, int L,
+                                      int Lq, int P, int ref_dim, int value_dtype, void* stream_) {
     ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused: reference_points is null");
     ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
                 "alo_msda_forward_fused: last dim of reference_points must be 2 or 4, got %d", ref_dim);
     // the geometry dtype is implied: fp64 for fp64 values, fp32 otherwise (loc_dtype only steers validation here)
     const int loc_dtype = value_dtype == ALO_F64 ? ALO_F64 : ALO_F32;
     return forward_impl(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
-                        ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
+                        ref_dim, spatial_shapes_host, out, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
 }
 
 extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
