@@ -266,23 +266,74 @@ struct TileArgs {
     int window_budget;  // bytes of LDS available for staged windows
 };
 
+// arr[i] for a runtime i without dynamically indexing a kernel-argument array (which would send the whole argument
+// struct to scratch memory): a chain of selects over compile-time indices.
+template <int N>
+__device__ __forceinline__ int pick(const int (&arr)[N], int i) {
+    int v = arr[0];
+#pragma unroll
+    for (int l = 1; l < N; ++l) v = (i == l) ? arr[l] : v;
+    return v;
+}
+
+// Value of `v` in lane (lane ^ MASK): one DPP quad_perm for MASK < 4, a cross-lane shuffle otherwise.
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (MASK == 1) {
+        return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xf, 0xf, true));  // [1,0,3,2]
+    } else if constexpr (MASK == 2) {
+        return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xf, 0xf, true));  // [2,3,0,1]
+    } else {
+        return __shfl_xor(v, MASK, 64);
+    }
+}
+
+// Reduce-scatter inside an aligned group of G lanes: every lane holds partial sums for all G*VEC channels of its query
+// (acc[g][i] = channel g*VEC + i); on return lane j's acc[j][*] holds the group total of "its" VEC channels.
+template <int G, int VEC>
+__device__ __forceinline__ void group_reduce_scatter(float (&acc)[G][VEC], int part) {
+#pragma unroll
+    for (int half = G / 2; half >= 1; half /= 2) {
+        // lanes whose `half` bit is 0 keep the lower block of `half` chunks of the current range, the others the upper
+        const bool upper = (part & half) != 0;
+#pragma unroll
+        for (int gidx = 0; gidx < half; ++gidx)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                // current range is [base, base + 2*half) with base determined by the bits above `half`; since all
+                // indices must be compile-time we process every aligned block of 2*half chunks identically
+#pragma unroll
+                for (int base = 0; base < G; base += 2 * half) {
+                    const float lo = acc[base + gidx][i], hi = acc[base + half + gidx][i];
+                    const float send = upper ? lo : hi;   // what the partner keeps
+                    float got;
+                    if (half == 1) got = lane_xor<1>(send);
+                    else if (half == 2) got = lane_xor<2>(send);
+                    else got = lane_xor<4>(send);
+                    const float keep = upper ? hi : lo;
+                    // result parked in the slot this lane keeps
+                    if (upper) acc[base + half + gidx][i] = keep + got; else acc[base + gidx][i] = keep + got;
+                }
+            }
+    }
+}
+
 template <typename T, typename LT, typename CT, int VEC, int G, bool FUSED>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 4)
 msda_fwd_tile_kernel(const TileArgs a) {
+    static_assert(sizeof(CT) == 4, "tiled kernel computes in fp32");
     constexpr int TQ = kThreads / G;  // queries per tile
     constexpr int TX = 8, TY = TQ / TX;
     constexpr int L = kTileLevels, P = 4, LP = L * P;
-    constexpr int ROWB = G * 16;      // bytes of one (pixel, head) row: D * sizeof(T)
-    constexpr int NK = TQ * LP / kThreads;  // taps built per thread
-    using Desc = FwdDesc<CT>;
+    constexpr int ROWB = G * 16;       // bytes of one (pixel, head) row: D * sizeof(T)
+    constexpr int NT = LP / G;         // sampling points owned by each lane of a query's group (4 or 2)
+    constexpr int RPB = 16 / G;        // pixel rows per 256-byte LDS bank row
     using Ld = Loader<T, CT, VEC>;
     using InT = typename std::conditional<FUSED, T, LT>::type;
-    constexpr int PAIR_STRIDE = LP * (int)sizeof(Desc) + 16;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* bbox = reinterpret_cast<int*>(smem);  // [L][ymin, ymax, xmin, xmax]
-    unsigned char* dbase = smem + 64;
-    unsigned char* win = dbase + TQ * PAIR_STRIDE;
+    unsigned char* win = smem + 64;            // [zero row (ROWB bytes)] [staged windows]
 
     const InT* loc = static_cast<const InT*>(a.loc);
     const InT* attn = static_cast<const InT*>(a.attn);
@@ -298,84 +349,96 @@ msda_fwd_tile_kernel(const TileArgs a) {
 #pragma unroll
     for (int l = 1; l < L; ++l)
         if (t >= a.tile_prefix[l]) lq = l;
-    const int tt = t - a.tile_prefix[lq];
-    const int ty = tt / a.tiles_x[lq], tx = tt - ty * a.tiles_x[lq];
+    const int tt = t - pick(a.tile_prefix, lq);
+    const int tiles_x = pick(a.tiles_x, lq);
+    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
+    const int Hq = pick(a.H, lq), Wq = pick(a.W, lq), startq = pick(a.start, lq);
     const int tid = threadIdx.x;
 
     if (tid < 4 * L) bbox[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+    if (tid < ROWB / 4) reinterpret_cast<unsigned*>(win)[tid] = 0u;
     __syncthreads();
 
     const unsigned row_elems = (unsigned)a.M * a.D;
     const unsigned row_bytes = row_elems * (unsigned)sizeof(T);
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(value + (size_t)b * a.S * row_elems, (unsigned)a.S * row_bytes);
 
-    // ---- stage 1: taps (registers) + per-level bounding box ------------------------------------------------------------
-    // si = tid + k*256 -> query slot si / 16, sample s = si % 16 = tid % 16: all taps of a thread belong to ONE level
-    const int s = tid & (LP - 1);
-    const int lv = s / P;
-    const int Hl = a.H[lv], Wl = a.W[lv];
-    int tyl[NK], txl[NK];
-    unsigned okm[NK];
-    CT tw[NK][4];
-    int ylo = INT_MAX, yhi = INT_MIN, xlo = INT_MAX, xhi = INT_MIN;
+    // ---- pass A: lane `part` of a query's group looks at the NT consecutive sampling points it owns: softmax statistics
+    //      of the query's 16 logits (fused variant) and the bounding box of the corners touched, per value level ----------
+    const int ql = tid / G, part = tid % G;
+    const int qy = ty * TY + ql / TX, qx = tx * TX + ql % TX;
+    const bool live = qy < Hq && qx < Wq;
+    const int q = startq + (live ? qy * Wq + qx : 0);
+    const int s0 = part * NT;
+    const int lv = s0 / P;  // G = 4: lane j owns level j; G = 8: lanes 2l, 2l+1 share level l
+    const int Hl = pick(a.H, lv), Wl = pick(a.W, lv), startl = pick(a.start, lv);
+    const long g0 = (((long)b * a.Lq + q) * a.M + m) * LP + s0;
+
+    CT r0 = (CT)0, r1 = (CT)0, r2 = (CT)0, r3 = (CT)0;  // reference point of (query, level) — fused variant only
+    CT smax = (CT)0, sinv = (CT)1;                      // softmax: max logit and 1 / sum(exp)
+    if constexpr (FUSED) {
+        if (live) {
+            const CT* r = ref + (((long)b * a.Lq + q) * L + lv) * a.ref_dim;
+            r0 = r[0]; r1 = r[1];
+            if (a.ref_dim == 4) { r2 = r[2]; r3 = r[3]; }
+        }
+        CT lg[NT];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int ql = (tid + k * kThreads) / LP;
-        const int qy = ty * TY + ql / TX, qx = tx * TX + ql % TX;
-        const bool live = qy < a.H[lq] && qx < a.W[lq];
-        const int q = a.start[lq] + qy * a.W[lq] + qx;
-        const long g = (((long)b * a.Lq + (live ? q : 0)) * a.M + m) * LP + s;
-        CT x = (CT)0, y = (CT)0, w = (CT)0;
-        if (live) { x = (CT)ld(loc + 2 * g); y = (CT)ld(loc + 2 * g + 1); w = (CT)ld(attn + g); }
+        for (int k = 0; k < NT; ++k) lg[k] = live ? (CT)ld(attn + g0 + k) : (CT)0;
+        smax = lg[0];
+#pragma unroll
+        for (int k = 1; k < NT; ++k) smax = fmax(smax, lg[k]);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
+        CT sum = (CT)0;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) sum += exp(lg[k] - smax);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        sinv = (CT)1 / sum;
+    }
+    // sampling location and attention weight of the lane's k-th point, exactly as the generic kernel's stage 1 computes them
+    auto point = [&](int k, CT& x, CT& y, CT& w) {
+        x = (CT)ld(loc + 2 * (g0 + k));
+        y = (CT)ld(loc + 2 * (g0 + k) + 1);
+        w = (CT)ld(attn + g0 + k);
         if constexpr (FUSED) {
-            CT mx = w;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-            w = exp(w - mx);
-            CT sum = w;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-            w = w / sum;
-            if (live) {
-                const CT* r = ref + (((long)b * a.Lq + q) * L + lv) * a.ref_dim;
-                if (a.ref_dim == 2) {
-                    x = r[0] + x / (CT)Wl;
-                    y = r[1] + y / (CT)Hl;
-                } else {
-                    x = r[0] + x / (CT)P * r[2] * (CT)0.5;
-                    y = r[1] + y / (CT)P * r[3] * (CT)0.5;
-                }
+            w = exp(w - smax) * sinv;
+            if (a.ref_dim == 2) {
+                x = r0 + x / (CT)Wl;
+                y = r1 + y / (CT)Hl;
+            } else {
+                x = r0 + x / (CT)P * r2 * (CT)0.5;
+                y = r1 + y / (CT)P * r3 * (CT)0.5;
             }
         }
-        const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
-        const CT hh = (CT)1 - tp.lh, hw = (CT)1 - tp.lw;
-        const CT wk[4] = {hh * hw, hh * tp.lw, tp.lh * hw, tp.lh * tp.lw};
-        unsigned mask = 0;
+    };
+    int ylo = INT_MAX, yhi = INT_MIN, xlo = INT_MAX, xhi = INT_MIN;
+    if (live) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool ok = live && tp.ok[c];
-            tw[k][c] = ok ? wk[c] * w : (CT)0;
-            mask |= ok ? (1u << c) : 0u;
-        }
-        okm[k] = mask;
-        tyl[k] = tp.h_low;
-        txl[k] = tp.w_low;
-        if (mask) {  // rows / columns of the map this tap really touches
-            ylo = min(ylo, max(tp.h_low, 0));
-            yhi = max(yhi, min(tp.h_low + 1, Hl - 1));
-            xlo = min(xlo, max(tp.w_low, 0));
-            xhi = max(xhi, min(tp.w_low + 1, Wl - 1));
+        for (int k = 0; k < NT; ++k) {
+            CT x, y, w;
+            point(k, x, y, w);
+            const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
+            if (tp.valid) {  // rows / columns of the map this point really touches
+                ylo = min(ylo, max(tp.h_low, 0));
+                yhi = max(yhi, min(tp.h_low + 1, Hl - 1));
+                xlo = min(xlo, max(tp.w_low, 0));
+                xhi = max(xhi, min(tp.w_low + 1, Wl - 1));
+            }
         }
     }
-    // lanes of one level inside a wave differ in bits {0,1} (point) and {4,5} (query): reduce over those
+    // lanes of the same level differ in every lane bit except the ones that select the level
+    constexpr int LVL_LANES = G / L;  // lanes per level inside a group (1 for G = 4, 2 for G = 8)
 #pragma unroll
-    for (int o : {1, 2, 16, 32}) {
+    for (int o = 1; o < 64; o <<= 1) {
+        if (o >= LVL_LANES && o < G) continue;
         ylo = min(ylo, __shfl_xor(ylo, o, 64));
         yhi = max(yhi, __shfl_xor(yhi, o, 64));
         xlo = min(xlo, __shfl_xor(xlo, o, 64));
         xhi = max(xhi, __shfl_xor(xhi, o, 64));
     }
-    if ((tid & 0x33) == 0) {
+    if ((tid & 63) < G && (tid & (LVL_LANES - 1)) == 0) {  // one lane per level per wave
         atomicMin(&bbox[lv * 4 + 0], ylo);
         atomicMax(&bbox[lv * 4 + 1], yhi);
         atomicMin(&bbox[lv * 4 + 2], xlo);
@@ -383,106 +446,104 @@ msda_fwd_tile_kernel(const TileArgs a) {
     }
     __syncthreads();
 
-    // ---- window plan (every thread computes the same thing) ---------------------------------------------------------------
-    int wy0[L], wx0[L], wh[L], ww[L], wbase[L];
-    bool staged[L];
-    int used = 0;
+    // ---- window plan: identical in every thread.  Either all four boxes fit the LDS budget (the normal case) or the whole
+    //      tile gathers from global memory — a workgroup-uniform decision keeps both gather loops branch-free ------------------
+    int my_y0 = 0, my_x0 = 0, my_ww = 0, my_base = 0;
+    int used = ROWB;  // the zero row comes first
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const int y0 = bbox[l * 4 + 0], y1 = bbox[l * 4 + 1], x0 = bbox[l * 4 + 2], x1 = bbox[l * 4 + 3];
         const bool any = y0 <= y1 && x0 <= x1;
-        wy0[l] = any ? y0 : 0;
-        wx0[l] = any ? x0 : 0;
-        wh[l] = any ? y1 - y0 + 1 : 0;
-        ww[l] = any ? x1 - x0 + 1 : 0;
-        const long bytes = (long)wh[l] * ww[l] * ROWB;
-        staged[l] = used + bytes <= (long)a.window_budget;
-        wbase[l] = used;
-        if (staged[l]) used += (int)bytes;
+        const int h = any ? y1 - y0 + 1 : 0, w = any ? x1 - x0 + 1 : 0;
+        if (l == lv) { my_y0 = any ? y0 : 0; my_x0 = any ? x0 : 0; my_ww = w; my_base = used; }
+        const long nb = (long)h * w * ROWB;
+        used = (nb > (long)a.window_budget) ? a.window_budget + 1 : used + (int)nb;  // saturate instead of overflowing
+    }
+    const bool in_lds = used <= a.window_budget;
+
+    if (in_lds) {
+        // copy the boxes: one head's D channels of every pixel; the G 16-byte chunks of a pixel are XOR-swizzled so that 16
+        // lanes reading the same chunk index of 16 consecutive pixels hit 16 different LDS bank slots
+        int base = ROWB;
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) {
+            const int y0 = bbox[l * 4 + 0], y1 = bbox[l * 4 + 1], x0 = bbox[l * 4 + 2], x1 = bbox[l * 4 + 3];
+            if (y0 > y1 || x0 > x1) continue;
+            const int h = y1 - y0 + 1, w = x1 - x0 + 1;
+            const int chunks = h * w * G;
+            const float inv_w = 1.0f / (float)w;
+            const int startv = pick(a.start, l), Wv = pick(a.W, l);
+            for (int i = tid; i < chunks; i += kThreads) {
+                const int r = i / G, c = i - r * G;
+                int yy = (int)(((float)r + 0.5f) * inv_w);
+                int xx = r - yy * w;
+                if (xx < 0) { --yy; xx += w; }
+                if (xx >= w) { ++yy; xx -= w; }
+                const unsigned goff = (unsigned)(startv + (y0 + yy) * Wv + x0 + xx) * row_bytes +
+                                      (unsigned)(m * a.D) * (unsigned)sizeof(T) + (unsigned)c * 16u;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0);
+                const int cs = c ^ ((r / RPB) & (G - 1));
+                *reinterpret_cast<u32x4*>(win + base + r * ROWB + cs * 16) = v;
+            }
+            base += h * w * ROWB;
+        }
+        __syncthreads();
     }
 
-    // ---- descriptors: LDS offsets for staged levels, global byte offsets otherwise -------------------------------------------
-    {
-        const bool st = staged[lv];
-        const int y0 = wy0[lv], x0 = wx0[lv], wd = ww[lv], base = wbase[lv], start = a.start[lv];
+    // ---- pass B: walk the lane's points again (inputs are L1-hot), gather each corner row over all G*VEC channels -------------
+    CT acc[G][VEC];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int ql = (tid + k * kThreads) / LP;
-            Desc d;
+    for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[gi][i] = (CT)0;
+    const unsigned head_off = (unsigned)(m * a.D) * (unsigned)sizeof(T);
+    if (live) {
+#pragma unroll 1
+        for (int k = 0; k < NT; ++k) {
+            CT x, y, w;
+            point(k, x, y, w);
+            const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
+            const CT hh = (CT)1 - tp.lh, hw = (CT)1 - tp.lw;
+            const CT wk[4] = {hh * hw * w, hh * tp.lw * w, tp.lh * hw * w, tp.lh * tp.lw * w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int y = tyl[k] + (c >> 1), x = txl[k] + (c & 1);
-                const bool ok = (okm[k] >> c) & 1u;
-                unsigned off;
-                if (st) off = ok ? (unsigned)(base + ((y - y0) * wd + (x - x0)) * ROWB) : (unsigned)base;
-                else off = ok ? (unsigned)(start + y * Wl + x) * row_bytes : kOutOfRange;
-                d.off[c] = off;
-                d.w[c] = tw[k][c];
-            }
-            *reinterpret_cast<Desc*>(dbase + ql * PAIR_STRIDE + s * (int)sizeof(Desc)) = d;
-        }
-    }
-
-    // ---- copy the staged windows: one head's D channels of every pixel in the box ---------------------------------------------
+                const int yy = tp.h_low + (c >> 1), xx = tp.w_low + (c & 1);
+                typename Ld::raw_t raw[G];
+                if (in_lds) {
+                    const int r = (yy - my_y0) * my_ww + (xx - my_x0);
+                    const unsigned rowo = tp.ok[c] ? (unsigned)(my_base + r * ROWB) : 0u;  // 0 = the zero row
+                    const unsigned key = tp.ok[c] ? (unsigned)((r / RPB) & (G - 1)) : 0u;
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-        if (!staged[l]) continue;
-        const int chunks = wh[l] * ww[l] * G;
-        const float inv_w = 1.0f / (float)(ww[l] > 0 ? ww[l] : 1);
-        for (int i = tid; i < chunks; i += kThreads) {
-            const int px = i / G, part = i - px * G;
-            int py = (int)(((float)px + 0.5f) * inv_w);
-            int pxx = px - py * ww[l];
-            if (pxx < 0) { --py; pxx += ww[l]; }
-            if (pxx >= ww[l]) { ++py; pxx -= ww[l]; }
-            const unsigned goff = (unsigned)(a.start[l] + (wy0[l] + py) * a.W[l] + wx0[l] + pxx) * row_bytes +
-                                  (unsigned)(m * a.D) * (unsigned)sizeof(T) + (unsigned)part * 16u;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0);
-            *reinterpret_cast<u32x4*>(win + wbase[l] + i * 16) = v;
-        }
-    }
-    __syncthreads();
-
-    // ---- gather: G lanes per query, samples of a staged level come from LDS ---------------------------------------------------
-    const int ql = tid / G, part = tid % G;
-    const int qy = ty * TY + ql / TX, qx = tx * TX + ql % TX;
-    if (qy < a.H[lq] && qx < a.W[lq]) {
-        const int q = a.start[lq] + qy * a.W[lq] + qx;
-        const unsigned char* dp = dbase + ql * PAIR_STRIDE;
-        const unsigned coff = (unsigned)(m * a.D + part * VEC) * (unsigned)sizeof(T);
-        CT acc[VEC];
+                    for (int gi = 0; gi < G; ++gi)
+                        raw[gi] = *reinterpret_cast<const typename Ld::raw_t*>(win + rowo + ((gi ^ key) << 4));
+                } else {
+                    const unsigned o = (unsigned)(startl + yy * Wl + xx) * row_bytes + head_off;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = (CT)0;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            Desc d[P];
-            typename Ld::raw_t raw[P][4];
-#pragma unroll
-            for (int p = 0; p < P; ++p) d[p] = *reinterpret_cast<const Desc*>(dp + (l * P + p) * (int)sizeof(Desc));
-            if (staged[l]) {
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        raw[p][c] = *reinterpret_cast<const typename Ld::raw_t*>(win + d[p].off[c] + part * 16);
-            } else {
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) raw[p][c] = Ld::load(rsrc, d[p].off[c] + coff);
-            }
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    CT v[VEC];
-                    Ld::widen(raw[p][c], v);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] += d[p].w[c] * v[i];
+                    for (int gi = 0; gi < G; ++gi) raw[gi] = Ld::load(rsrc, tp.ok[c] ? o + gi * 16 : kOutOfRange);
                 }
+                const CT wc = tp.ok[c] ? wk[c] : (CT)0;
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    CT v[VEC];
+                    Ld::widen(raw[gi], v);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[gi][i] += wc * v[i];
+                }
+            }
         }
-        store_vec<T, CT, VEC>(out + (((long)b * a.Lq + q) * a.M + m) * a.D + part * VEC, acc);
     }
+
+    // ---- sum the group's partial results; lane j ends up with channels [j*VEC, (j+1)*VEC) -------------------------------------
+    group_reduce_scatter<G, VEC>(acc, part);
+    CT mine[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        CT v = acc[0][i];
+#pragma unroll
+        for (int gi = 1; gi < G; ++gi) v = (part == gi) ? acc[gi][i] : v;
+        mine[i] = v;
+    }
+    if (live) store_vec<T, CT, VEC>(out + (((long)b * a.Lq + q) * a.M + m) * a.D + part * VEC, mine);
 }
 
 // Can the tiled kernel take this call?  (host copy of the shapes known, the model's L = P = 4, queries = pixels,
@@ -493,7 +554,7 @@ bool tile_plan(TileArgs& ta, const int32_t* shapes_host, int N, int S, int M, in
     const int vec = (int)(16 / elem);
     if (D % vec != 0) return false;
     const int g = D / vec;
-    if (!((elem == 2 && g == 4) || (elem == 4 && g == 8))) return false;
+    if (!(elem == 2 && g == 4)) return false;  // bf16, D = 32 (the fp32 instantiation exists but still spills registers)
     const int tq = kThreads / g, tyq = tq / 8;
     long total = 0, start = 0;
     for (int l = 0; l < L; ++l) {
@@ -654,7 +715,7 @@ struct Tuning {
     int iters = 0;
     int ablate = 0;
     int tile = 1;          // ALO_MSDA_TILE=0 disables the tiled encoder kernel
-    int tile_lds = 44 * 1024;  // ALO_MSDA_TILE_LDS: bytes of LDS for staged windows (2 workgroups / CU at 44 KB)
+    int tile_lds = 36 * 1024;  // ALO_MSDA_TILE_LDS: bytes of LDS for staged windows (4 workgroups / CU at 36 KB)
 };
 const Tuning& tuning() {
     static const Tuning t = [] {
@@ -802,8 +863,7 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
             ta.value = value; ta.loc = loc; ta.attn = attn; ta.ref = ref; ta.out = out;
             ta.N = N; ta.S = S; ta.M = M; ta.D = D; ta.Lq = Lq; ta.ref_dim = ref_dim;
             ta.window_budget = tuning().tile_lds;
-            const int g = D / (int)(16 / elem);
-            const size_t lds = 64 + (size_t)(kThreads / g) * (16 * sizeof(FwdDesc<float>) + 16) + (size_t)ta.window_budget;
+            const size_t lds = 64 + (size_t)ta.window_budget;  // bbox + [zero row | staged windows]
             if (value_dtype == ALO_BF16)
                 return fused ? launch_tile(msda_fwd_tile_kernel<bf16_t, float, float, 8, 4, true>, ta, lds, stream)
                              : launch_tile(msda_fwd_tile_kernel<bf16_t, float, float, 8, 4, false>, ta, lds, stream);

@@ -325,8 +325,8 @@ def test_tiled_encoder_kernel_equals_generic(shapes_l, dtype, spread):
     logits = torch.randn(N, S, M, L * P, generator=gen, device=DEV).to(dtype)
     generic = alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref)
     tiled = alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref, shapes_host=shapes_l)
-    if dtype == torch.float32:
-        assert (tiled - generic).abs().max().item() <= 2e-6  # same taps, same weights; only the summation grouping differs
+    if dtype == torch.float32:  # (fp32 currently takes the generic kernel on both sides)
+        assert (tiled - generic).abs().max().item() <= 2e-6
     else:
         assert ((tiled.float() - generic.float()).abs() <= generic.float().abs() * 2.0 ** -7 + 1e-6).all()
     # reference-box form (ref_dim = 4) through the same kernel
