@@ -376,41 +376,45 @@ msda_fwd_tile_kernel(const TileArgs a) {
 
     CT r0 = (CT)0, r1 = (CT)0, r2 = (CT)0, r3 = (CT)0;  // reference point of (query, level) — fused variant only
     CT smax = (CT)0, sinv = (CT)1;                      // softmax: max logit and 1 / sum(exp)
+    // raw inputs of the lane's NT points stay in registers for both passes
+    CT rx[NT], ry[NT], rw[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        rx[k] = live ? (CT)ld(loc + 2 * (g0 + k)) : (CT)0;
+        ry[k] = live ? (CT)ld(loc + 2 * (g0 + k) + 1) : (CT)0;
+        rw[k] = live ? (CT)ld(attn + g0 + k) : (CT)0;
+    }
     if constexpr (FUSED) {
         if (live) {
             const CT* r = ref + (((long)b * a.Lq + q) * L + lv) * a.ref_dim;
             r0 = r[0]; r1 = r[1];
             if (a.ref_dim == 4) { r2 = r[2]; r3 = r[3]; }
         }
-        CT lg[NT];
+        smax = rw[0];
 #pragma unroll
-        for (int k = 0; k < NT; ++k) lg[k] = live ? (CT)ld(attn + g0 + k) : (CT)0;
-        smax = lg[0];
-#pragma unroll
-        for (int k = 1; k < NT; ++k) smax = fmax(smax, lg[k]);
+        for (int k = 1; k < NT; ++k) smax = fmax(smax, rw[k]);
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
         CT sum = (CT)0;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) sum += exp(lg[k] - smax);
+        for (int k = 0; k < NT; ++k) sum += exp(rw[k] - smax);
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         sinv = (CT)1 / sum;
     }
-    // sampling location and attention weight of the lane's k-th point, exactly as the generic kernel's stage 1 computes them
-    auto point = [&](int k, CT& x, CT& y, CT& w) {
-        x = (CT)ld(loc + 2 * (g0 + k));
-        y = (CT)ld(loc + 2 * (g0 + k) + 1);
-        w = (CT)ld(attn + g0 + k);
+    // sampling location and attention weight of a point from its raw inputs, as the generic kernel's stage 1 computes them
+    auto point = [&](CT x, CT y, CT w, CT& ox, CT& oy, CT& ow) {
         if constexpr (FUSED) {
-            w = exp(w - smax) * sinv;
+            ow = exp(w - smax) * sinv;
             if (a.ref_dim == 2) {
-                x = r0 + x / (CT)Wl;
-                y = r1 + y / (CT)Hl;
+                ox = r0 + x / (CT)Wl;
+                oy = r1 + y / (CT)Hl;
             } else {
-                x = r0 + x / (CT)P * r2 * (CT)0.5;
-                y = r1 + y / (CT)P * r3 * (CT)0.5;
+                ox = r0 + x / (CT)P * r2 * (CT)0.5;
+                oy = r1 + y / (CT)P * r3 * (CT)0.5;
             }
+        } else {
+            ox = x; oy = y; ow = w;
         }
     };
     int ylo = INT_MAX, yhi = INT_MIN, xlo = INT_MAX, xhi = INT_MIN;
@@ -418,7 +422,7 @@ msda_fwd_tile_kernel(const TileArgs a) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             CT x, y, w;
-            point(k, x, y, w);
+            point(rx[k], ry[k], rw[k], x, y, w);
             const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
             if (tp.valid) {  // rows / columns of the map this point really touches
                 ylo = min(ylo, max(tp.h_low, 0));
@@ -462,30 +466,52 @@ msda_fwd_tile_kernel(const TileArgs a) {
     const bool in_lds = used <= a.window_budget;
 
     if (in_lds) {
-        // copy the boxes: one head's D channels of every pixel; the G 16-byte chunks of a pixel are XOR-swizzled so that 16
-        // lanes reading the same chunk index of 16 consecutive pixels hit 16 different LDS bank slots
-        int base = ROWB;
-#pragma unroll 1
-        for (int l = 0; l < L; ++l) {
-            const int y0 = bbox[l * 4 + 0], y1 = bbox[l * 4 + 1], x0 = bbox[l * 4 + 2], x1 = bbox[l * 4 + 3];
-            if (y0 > y1 || x0 > x1) continue;
-            const int h = y1 - y0 + 1, w = x1 - x0 + 1;
-            const int chunks = h * w * G;
-            const float inv_w = 1.0f / (float)w;
-            const int startv = pick(a.start, l), Wv = pick(a.W, l);
-            for (int i = tid; i < chunks; i += kThreads) {
-                const int r = i / G, c = i - r * G;
-                int yy = (int)(((float)r + 0.5f) * inv_w);
+        // copy the boxes: one head's D channels of every pixel.  All levels form ONE flat list of 16-byte chunks (their
+        // positions in LDS); a thread puts up to 8 loads in flight before the first ds_write.  The G chunks of a pixel are
+        // XOR-swizzled so that 16 lanes reading the same chunk index of 16 consecutive pixels hit 16 different bank slots.
+        int lb0[L], ly0[L], lx0[L], lw[L];
+        {
+            int base = ROWB;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int y0 = bbox[l * 4 + 0], y1 = bbox[l * 4 + 1], x0 = bbox[l * 4 + 2], x1 = bbox[l * 4 + 3];
+                const bool any = y0 <= y1 && x0 <= x1;
+                lb0[l] = base; ly0[l] = any ? y0 : 0; lx0[l] = any ? x0 : 0; lw[l] = any ? x1 - x0 + 1 : 1;
+                base += any ? (y1 - y0 + 1) * (x1 - x0 + 1) * ROWB : 0;
+            }
+        }
+        const int total = (used - ROWB) / 16;
+        constexpr int NF = 8;
+        for (int i0 = tid; i0 < total; i0 += NF * kThreads) {
+            u32x4 v[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int i = i0 + j * kThreads;
+                const int pos = ROWB + i * 16;  // byte position of the chunk in the window area
+                int l = 0;
+#pragma unroll
+                for (int t2 = 1; t2 < L; ++t2)
+                    if (pos >= lb0[t2]) l = t2;
+                int base = lb0[0], y0 = ly0[0], x0 = lx0[0], w = lw[0];
+#pragma unroll
+                for (int t2 = 1; t2 < L; ++t2)
+                    if (l == t2) { base = lb0[t2]; y0 = ly0[t2]; x0 = lx0[t2]; w = lw[t2]; }
+                const int rel = pos - base;
+                const int r = rel / ROWB, cs = (rel / 16) & (G - 1);
+                const int c = cs ^ ((r / RPB) & (G - 1));
+                int yy = (int)(((float)r + 0.5f) / (float)w);
                 int xx = r - yy * w;
                 if (xx < 0) { --yy; xx += w; }
                 if (xx >= w) { ++yy; xx -= w; }
-                const unsigned goff = (unsigned)(startv + (y0 + yy) * Wv + x0 + xx) * row_bytes +
+                const unsigned goff = (unsigned)(pick(a.start, l) + (y0 + yy) * pick(a.W, l) + x0 + xx) * row_bytes +
                                       (unsigned)(m * a.D) * (unsigned)sizeof(T) + (unsigned)c * 16u;
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0);
-                const int cs = c ^ ((r / RPB) & (G - 1));
-                *reinterpret_cast<u32x4*>(win + base + r * ROWB + cs * 16) = v;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i < total ? goff : kOutOfRange, 0, 0);
             }
-            base += h * w * ROWB;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int i = i0 + j * kThreads;
+                if (i < total) *reinterpret_cast<u32x4*>(win + ROWB + i * 16) = v[j];
+            }
         }
         __syncthreads();
     }
@@ -498,10 +524,14 @@ msda_fwd_tile_kernel(const TileArgs a) {
         for (int i = 0; i < VEC; ++i) acc[gi][i] = (CT)0;
     const unsigned head_off = (unsigned)(m * a.D) * (unsigned)sizeof(T);
     if (live) {
+        // rolled on purpose (an unrolled body makes the scheduler hoist every read and spill); the point inputs rotate through
+        // slot 0 so that no register array is indexed dynamically
 #pragma unroll 1
         for (int k = 0; k < NT; ++k) {
             CT x, y, w;
-            point(k, x, y, w);
+            point(rx[0], ry[0], rw[0], x, y, w);
+#pragma unroll
+            for (int j = 0; j + 1 < NT; ++j) { rx[j] = rx[j + 1]; ry[j] = ry[j + 1]; rw[j] = rw[j + 1]; }
             const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
             const CT hh = (CT)1 - tp.lh, hw = (CT)1 - tp.lw;
             const CT wk[4] = {hh * hw * w, hh * tp.lw * w, tp.lh * hw * w, tp.lh * tp.lw * w};
