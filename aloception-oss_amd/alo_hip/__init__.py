@@ -45,7 +45,7 @@ def _declare(lib):
     lib.alo_msda_forward.restype = ip
     lib.alo_msda_forward.argtypes = [vp] * 6 + [ip] * 9 + [vp]
     lib.alo_msda_forward_fused.restype = ip
-    lib.alo_msda_forward_fused.argtypes = [vp] * 8 + [ip] * 9 + [vp]
+    lib.alo_msda_forward_fused.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_msda_backward.restype = ip
     lib.alo_msda_backward.argtypes = [vp] * 9 + [ip] * 9 + [vp]
     lib.alo_corr_level_shape.restype = None
@@ -219,13 +219,9 @@ def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_we
     return out
 
 
-def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
-                       shapes_host=None):
+def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points):
     """MSDeformAttn's prologue + gather in one launch (inference): raw offsets (N,Lq,M,L,P,2) and raw attention logits
-    (N,Lq,M,L*P) in ``value``'s dtype, reference points (N,Lq,L,2|4) in fp32 (fp64 for fp64 values) -> (N,Lq,M*D).
-
-    ``shapes_host``: optional sequence of (H_l, W_l) equal to ``spatial_shapes`` (known on the host without a sync);
-    it enables the tiled encoder kernel when the call is a self-attention over the pyramid (Lq == S)."""
+    (N,Lq,M,L*P) in ``value``'s dtype, reference points (N,Lq,L,2|4) in fp32 (fp64 for fp64 values) -> (N,Lq,M*D)."""
     if not value.is_cuda:
         raise RuntimeError("Not implemented on the CPU")
     N, S, M, D = value.shape
@@ -249,16 +245,10 @@ def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offset
     # bytes actually streamed by the fused launch: value + out + raw offsets/logits (value dtype) + reference points
     e = value.element_size()
     nbytes = e * (N * S * M * D + N * Lq * M * D + N * Lq * M * L * P * 3) + reference_points.element_size() * reference_points.numel()
-    host = None
-    if shapes_host is not None:
-        flat = [int(v) for hw in shapes_host for v in hw]
-        if len(flat) != 2 * L:
-            raise RuntimeError("shapes_host must hold one (H, W) pair per level")
-        host = (ctypes.c_int32 * len(flat))(*flat)
     with torch.cuda.device(value.device), _timed(f"msda_fwd_fused/Lq={Lq}", nbytes):
         _check(lib().alo_msda_forward_fused(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
-                                            _ptr(sampling_offsets), _ptr(attn_logits), _ptr(reference_points), host,
-                                            _ptr(out), N, S, M, D, L, Lq, P, ref_dim, vdt, _stream(value.device)))
+                                            _ptr(sampling_offsets), _ptr(attn_logits), _ptr(reference_points), _ptr(out),
+                                            N, S, M, D, L, Lq, P, ref_dim, vdt, _stream(value.device)))
     return out
 
 

@@ -248,9 +248,6 @@ class DeformableTransformer(nn.Module):
         sizes = [h * w for h, w in shapes]
         level_start_index = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int32, device=device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
-        # the level shapes are Python ints here: hand them down so the attention op can lay out query tiles on the
-        # host without reading `spatial_shapes` back from the device
-        kwargs = dict(kwargs, spatial_shapes_host=tuple(shapes))
 
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, pos_flatten, mask_flatten,
                               **kwargs)

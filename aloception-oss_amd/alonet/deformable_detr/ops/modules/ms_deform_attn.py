@@ -109,8 +109,7 @@ class MSDeformAttn(nn.Module):
         if "is_tracing" not in kwargs and not needs_grad and self.fused_prologue:
             # inference: softmax + sampling-location arithmetic happen inside the kernel's descriptor stage
             output = alo_hip.msda_forward_fused(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                                                offsets.contiguous(), logits.contiguous(), reference_points,
-                                                shapes_host=kwargs.get("spatial_shapes_host"))
+                                                offsets.contiguous(), logits.contiguous(), reference_points)
             return self.output_proj(output)
 
         offsets = offsets.to(geo)

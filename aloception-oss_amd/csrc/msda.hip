@@ -15,7 +15,6 @@
 //     with N = 8 each XCD's L2 holds exactly one image's value map.
 //   * backward: lanes reduce d/d(loc), d/d(attn) over channels with wave shuffles (no LDS, no block barriers, no
 //     serial thread-0 sum), grad_value goes out through hardware fp32/fp64 atomics.
-#include <climits>
 #include <cstdlib>
 #include <type_traits>
 
@@ -48,7 +47,6 @@ struct Dims {
     int iters_per_block;   // runs of (256 / G) pairs handled by one workgroup
     unsigned nblocks;
     int ref_dim;           // fused prologue only: last dim of reference_points (2 or 4)
-    int ablate;            // tuning experiments only (ALO_MSDA_ABLATE): 1 = no gathers, 2 = descriptors built once
 };
 
 // Image-space position, validity and the four corners of one sampling point (cuh:285-291, :38-78).
@@ -57,7 +55,6 @@ struct Tap {
     bool valid, ok[4];
     int base;  // pixel index (within the batch item's S rows) of the (h_low, w_low) corner
     int W;
-    int h_low, w_low;
     CT lh, lw;
 };
 template <typename CT>
@@ -78,8 +75,6 @@ __device__ __forceinline__ Tap<CT> make_tap(CT loc_x, CT loc_y, int H, int W, in
     t.ok[3] = t.valid && hh && wh;
     t.base = start + h_low * W + w_low;
     t.W = W;
-    t.h_low = h_low;
-    t.w_low = w_low;
     return t;
 }
 
@@ -136,7 +131,7 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
         if (pair0 >= dm.pairs_per_batch) break;  // uniform
 
         // ---- stage 1: one descriptor per (pair, level, point) ------------------------------------------------------
-        const int nsamp = (dm.ablate == 2 && it > 0) ? 0 : PAIRS * LP;
+        const int nsamp = PAIRS * LP;
         for (int si = tid; si < nsamp; si += kThreads) {
             const int pl = si / LP, s = si - pl * LP;
             const int pair = pair0 + pl;
@@ -221,8 +216,7 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                                 for (int k = 0; k < 4; ++k) { d[j].off[k] = kOutOfRange; d[j].w[k] = (CT)0; }
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                raw[j][k] = Ld::load(rsrc, dm.ablate == 1 ? kOutOfRange : d[j].off[k] + coff);
+                            for (int k = 0; k < 4; ++k) raw[j][k] = Ld::load(rsrc, d[j].off[k] + coff);
                         }
 #pragma unroll
                         for (int j = 0; j < SB; ++j) {
@@ -241,368 +235,6 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
         }
         __syncthreads();  // descriptors are rewritten by the next run
     }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------
-// forward, tiled encoder variant: sample footprint staged in LDS
-// ------------------------------------------------------------------------------------------------------------------
-// The generic kernel above is bound by the rate at which a CU's texture path accepts gather lanes (64 B/clk): every
-// (query, head, point) costs four 64/128-byte requests whether or not they hit in L1 (measured: with the gathers pointed
-// out of range the kernel still takes 80 % of its time).  In the encoder the queries ARE the pixels of the pyramid, and
-// neighbouring queries sample overlapping neighbourhoods.  Here one workgroup owns (image, head, TY x 8 tile of query
-// pixels of one level): stage 1 builds the tile's sampling taps and, per value level, the bounding box of every corner
-// they touch; the boxes (one head's D channels per pixel) are copied into LDS once; the gather then runs out of LDS at
-// ds_read_b128 rate.  A level whose box does not fit the LDS budget is gathered from global memory exactly as in the
-// generic kernel, so nothing is assumed about the sampling locations — a wider spread only costs speed.
-constexpr int kTileLevels = 4;
-struct TileArgs {
-    const void* value; const void* loc; const void* attn; const void* ref; void* out;
-    int N, S, M, D, Lq, ref_dim;
-    int H[kTileLevels], W[kTileLevels], start[kTileLevels];
-    int tiles_x[kTileLevels], tile_prefix[kTileLevels + 1];
-    int tiles_total;
-    unsigned nblocks;
-    int window_budget;  // bytes of LDS available for staged windows
-};
-
-// arr[i] for a runtime i without dynamically indexing a kernel-argument array (which would send the whole argument
-// struct to scratch memory): a chain of selects over compile-time indices.
-template <int N>
-__device__ __forceinline__ int pick(const int (&arr)[N], int i) {
-    int v = arr[0];
-#pragma unroll
-    for (int l = 1; l < N; ++l) v = (i == l) ? arr[l] : v;
-    return v;
-}
-
-// Value of `v` in lane (lane ^ MASK): one DPP quad_perm for MASK < 4, a cross-lane shuffle otherwise.
-template <int MASK>
-__device__ __forceinline__ float lane_xor(float v) {
-    if constexpr (MASK == 1) {
-        return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xf, 0xf, true));  // [1,0,3,2]
-    } else if constexpr (MASK == 2) {
-        return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xf, 0xf, true));  // [2,3,0,1]
-    } else {
-        return __shfl_xor(v, MASK, 64);
-    }
-}
-
-// Reduce-scatter inside an aligned group of G lanes: every lane holds partial sums for all G*VEC channels of its query
-// (acc[g][i] = channel g*VEC + i); on return lane j's acc[j][*] holds the group total of "its" VEC channels.
-template <int G, int VEC>
-__device__ __forceinline__ void group_reduce_scatter(float (&acc)[G][VEC], int part) {
-#pragma unroll
-    for (int half = G / 2; half >= 1; half /= 2) {
-        // lanes whose `half` bit is 0 keep the lower block of `half` chunks of the current range, the others the upper
-        const bool upper = (part & half) != 0;
-#pragma unroll
-        for (int gidx = 0; gidx < half; ++gidx)
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                // current range is [base, base + 2*half) with base determined by the bits above `half`; since all
-                // indices must be compile-time we process every aligned block of 2*half chunks identically
-#pragma unroll
-                for (int base = 0; base < G; base += 2 * half) {
-                    const float lo = acc[base + gidx][i], hi = acc[base + half + gidx][i];
-                    const float send = upper ? lo : hi;   // what the partner keeps
-                    float got;
-                    if (half == 1) got = lane_xor<1>(send);
-                    else if (half == 2) got = lane_xor<2>(send);
-                    else got = lane_xor<4>(send);
-                    const float keep = upper ? hi : lo;
-                    // result parked in the slot this lane keeps
-                    if (upper) acc[base + half + gidx][i] = keep + got; else acc[base + gidx][i] = keep + got;
-                }
-            }
-    }
-}
-
-template <typename T, typename LT, typename CT, int VEC, int G, bool FUSED>
-__global__ void __launch_bounds__(kThreads, 4)
-msda_fwd_tile_kernel(const TileArgs a) {
-    static_assert(sizeof(CT) == 4, "tiled kernel computes in fp32");
-    constexpr int TQ = kThreads / G;  // queries per tile
-    constexpr int TX = 8, TY = TQ / TX;
-    constexpr int L = kTileLevels, P = 4, LP = L * P;
-    constexpr int ROWB = G * 16;       // bytes of one (pixel, head) row: D * sizeof(T)
-    constexpr int NT = LP / G;         // sampling points owned by each lane of a query's group (4 or 2)
-    constexpr int RPB = 16 / G;        // pixel rows per 256-byte LDS bank row
-    using Ld = Loader<T, CT, VEC>;
-    using InT = typename std::conditional<FUSED, T, LT>::type;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* bbox = reinterpret_cast<int*>(smem);  // [L][ymin, ymax, xmin, xmax]
-    unsigned char* win = smem + 64;            // [zero row (ROWB bytes)] [staged windows]
-
-    const InT* loc = static_cast<const InT*>(a.loc);
-    const InT* attn = static_cast<const InT*>(a.attn);
-    const CT* ref = static_cast<const CT*>(a.ref);
-    const T* value = static_cast<const T*>(a.value);
-    T* out = static_cast<T*>(a.out);
-
-    const unsigned lb = xcd_contiguous_block(blockIdx.x, a.nblocks);
-    const int m = lb % a.M;
-    const int t = (lb / a.M) % a.tiles_total;
-    const int b = lb / (a.M * a.tiles_total);
-    int lq = 0;
-#pragma unroll
-    for (int l = 1; l < L; ++l)
-        if (t >= a.tile_prefix[l]) lq = l;
-    const int tt = t - pick(a.tile_prefix, lq);
-    const int tiles_x = pick(a.tiles_x, lq);
-    const int ty = tt / tiles_x, tx = tt - ty * tiles_x;
-    const int Hq = pick(a.H, lq), Wq = pick(a.W, lq), startq = pick(a.start, lq);
-    const int tid = threadIdx.x;
-
-    if (tid < 4 * L) bbox[tid] = (tid & 1) ? INT_MIN : INT_MAX;
-    if (tid < ROWB / 4) reinterpret_cast<unsigned*>(win)[tid] = 0u;
-    __syncthreads();
-
-    const unsigned row_elems = (unsigned)a.M * a.D;
-    const unsigned row_bytes = row_elems * (unsigned)sizeof(T);
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(value + (size_t)b * a.S * row_elems, (unsigned)a.S * row_bytes);
-
-    // ---- pass A: lane `part` of a query's group looks at the NT consecutive sampling points it owns: softmax statistics
-    //      of the query's 16 logits (fused variant) and the bounding box of the corners touched, per value level ----------
-    const int ql = tid / G, part = tid % G;
-    const int qy = ty * TY + ql / TX, qx = tx * TX + ql % TX;
-    const bool live = qy < Hq && qx < Wq;
-    const int q = startq + (live ? qy * Wq + qx : 0);
-    const int s0 = part * NT;
-    const int lv = s0 / P;  // G = 4: lane j owns level j; G = 8: lanes 2l, 2l+1 share level l
-    const int Hl = pick(a.H, lv), Wl = pick(a.W, lv), startl = pick(a.start, lv);
-    const long g0 = (((long)b * a.Lq + q) * a.M + m) * LP + s0;
-
-    CT r0 = (CT)0, r1 = (CT)0, r2 = (CT)0, r3 = (CT)0;  // reference point of (query, level) — fused variant only
-    CT smax = (CT)0, sinv = (CT)1;                      // softmax: max logit and 1 / sum(exp)
-    // raw inputs of the lane's NT points stay in registers for both passes
-    CT rx[NT], ry[NT], rw[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        rx[k] = live ? (CT)ld(loc + 2 * (g0 + k)) : (CT)0;
-        ry[k] = live ? (CT)ld(loc + 2 * (g0 + k) + 1) : (CT)0;
-        rw[k] = live ? (CT)ld(attn + g0 + k) : (CT)0;
-    }
-    if constexpr (FUSED) {
-        if (live) {
-            const CT* r = ref + (((long)b * a.Lq + q) * L + lv) * a.ref_dim;
-            r0 = r[0]; r1 = r[1];
-            if (a.ref_dim == 4) { r2 = r[2]; r3 = r[3]; }
-        }
-        smax = rw[0];
-#pragma unroll
-        for (int k = 1; k < NT; ++k) smax = fmax(smax, rw[k]);
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) smax = fmax(smax, __shfl_xor(smax, o, 64));
-        CT sum = (CT)0;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) sum += exp(rw[k] - smax);
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        sinv = (CT)1 / sum;
-    }
-    // sampling location and attention weight of a point from its raw inputs, as the generic kernel's stage 1 computes them
-    auto point = [&](CT x, CT y, CT w, CT& ox, CT& oy, CT& ow) {
-        if constexpr (FUSED) {
-            ow = exp(w - smax) * sinv;
-            if (a.ref_dim == 2) {
-                ox = r0 + x / (CT)Wl;
-                oy = r1 + y / (CT)Hl;
-            } else {
-                ox = r0 + x / (CT)P * r2 * (CT)0.5;
-                oy = r1 + y / (CT)P * r3 * (CT)0.5;
-            }
-        } else {
-            ox = x; oy = y; ow = w;
-        }
-    };
-    int ylo = INT_MAX, yhi = INT_MIN, xlo = INT_MAX, xhi = INT_MIN;
-    if (live) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            CT x, y, w;
-            point(rx[k], ry[k], rw[k], x, y, w);
-            const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
-            if (tp.valid) {  // rows / columns of the map this point really touches
-                ylo = min(ylo, max(tp.h_low, 0));
-                yhi = max(yhi, min(tp.h_low + 1, Hl - 1));
-                xlo = min(xlo, max(tp.w_low, 0));
-                xhi = max(xhi, min(tp.w_low + 1, Wl - 1));
-            }
-        }
-    }
-    // lanes of the same level differ in every lane bit except the ones that select the level
-    constexpr int LVL_LANES = G / L;  // lanes per level inside a group (1 for G = 4, 2 for G = 8)
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        if (o >= LVL_LANES && o < G) continue;
-        ylo = min(ylo, __shfl_xor(ylo, o, 64));
-        yhi = max(yhi, __shfl_xor(yhi, o, 64));
-        xlo = min(xlo, __shfl_xor(xlo, o, 64));
-        xhi = max(xhi, __shfl_xor(xhi, o, 64));
-    }
-    if ((tid & 63) < G && (tid & (LVL_LANES - 1)) == 0) {  // one lane per level per wave
-        atomicMin(&bbox[lv * 4 + 0], ylo);
-        atomicMax(&bbox[lv * 4 + 1], yhi);
-        atomicMin(&bbox[lv * 4 + 2], xlo);
-        atomicMax(&bbox[lv * 4 + 3], xhi);
-    }
-    __syncthreads();
-
-    // ---- window plan: identical in every thread.  Either all four boxes fit the LDS budget (the normal case) or the whole
-    //      tile gathers from global memory — a workgroup-uniform decision keeps both gather loops branch-free ------------------
-    int my_y0 = 0, my_x0 = 0, my_ww = 0, my_base = 0;
-    int used = ROWB;  // the zero row comes first
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int y0 = bbox[l * 4 + 0], y1 = bbox[l * 4 + 1], x0 = bbox[l * 4 + 2], x1 = bbox[l * 4 + 3];
-        const bool any = y0 <= y1 && x0 <= x1;
-        const int h = any ? y1 - y0 + 1 : 0, w = any ? x1 - x0 + 1 : 0;
-        if (l == lv) { my_y0 = any ? y0 : 0; my_x0 = any ? x0 : 0; my_ww = w; my_base = used; }
-        const long nb = (long)h * w * ROWB;
-        used = (nb > (long)a.window_budget) ? a.window_budget + 1 : used + (int)nb;  // saturate instead of overflowing
-    }
-    const bool in_lds = used <= a.window_budget;
-
-    if (in_lds) {
-        // copy the boxes: one head's D channels of every pixel.  All levels form ONE flat list of 16-byte chunks (their
-        // positions in LDS); a thread puts up to 8 loads in flight before the first ds_write.  The G chunks of a pixel are
-        // XOR-swizzled so that 16 lanes reading the same chunk index of 16 consecutive pixels hit 16 different bank slots.
-        int lb0[L], ly0[L], lx0[L], lw[L];
-        {
-            int base = ROWB;
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int y0 = bbox[l * 4 + 0], y1 = bbox[l * 4 + 1], x0 = bbox[l * 4 + 2], x1 = bbox[l * 4 + 3];
-                const bool any = y0 <= y1 && x0 <= x1;
-                lb0[l] = base; ly0[l] = any ? y0 : 0; lx0[l] = any ? x0 : 0; lw[l] = any ? x1 - x0 + 1 : 1;
-                base += any ? (y1 - y0 + 1) * (x1 - x0 + 1) * ROWB : 0;
-            }
-        }
-        const int total = (used - ROWB) / 16;
-        constexpr int NF = 8;
-        for (int i0 = tid; i0 < total; i0 += NF * kThreads) {
-            u32x4 v[NF];
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int i = i0 + j * kThreads;
-                const int pos = ROWB + i * 16;  // byte position of the chunk in the window area
-                int l = 0;
-#pragma unroll
-                for (int t2 = 1; t2 < L; ++t2)
-                    if (pos >= lb0[t2]) l = t2;
-                int base = lb0[0], y0 = ly0[0], x0 = lx0[0], w = lw[0];
-#pragma unroll
-                for (int t2 = 1; t2 < L; ++t2)
-                    if (l == t2) { base = lb0[t2]; y0 = ly0[t2]; x0 = lx0[t2]; w = lw[t2]; }
-                const int rel = pos - base;
-                const int r = rel / ROWB, cs = (rel / 16) & (G - 1);
-                const int c = cs ^ ((r / RPB) & (G - 1));
-                int yy = (int)(((float)r + 0.5f) / (float)w);
-                int xx = r - yy * w;
-                if (xx < 0) { --yy; xx += w; }
-                if (xx >= w) { ++yy; xx -= w; }
-                const unsigned goff = (unsigned)(pick(a.start, l) + (y0 + yy) * pick(a.W, l) + x0 + xx) * row_bytes +
-                                      (unsigned)(m * a.D) * (unsigned)sizeof(T) + (unsigned)c * 16u;
-                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i < total ? goff : kOutOfRange, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int i = i0 + j * kThreads;
-                if (i < total) *reinterpret_cast<u32x4*>(win + ROWB + i * 16) = v[j];
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- pass B: walk the lane's points again (inputs are L1-hot), gather each corner row over all G*VEC channels -------------
-    CT acc[G][VEC];
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi)
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[gi][i] = (CT)0;
-    const unsigned head_off = (unsigned)(m * a.D) * (unsigned)sizeof(T);
-    if (live) {
-        // rolled on purpose (an unrolled body makes the scheduler hoist every read and spill); the point inputs rotate through
-        // slot 0 so that no register array is indexed dynamically
-#pragma unroll 1
-        for (int k = 0; k < NT; ++k) {
-            CT x, y, w;
-            point(rx[0], ry[0], rw[0], x, y, w);
-#pragma unroll
-            for (int j = 0; j + 1 < NT; ++j) { rx[j] = rx[j + 1]; ry[j] = ry[j + 1]; rw[j] = rw[j + 1]; }
-            const Tap<CT> tp = make_tap<CT>(x, y, Hl, Wl, 0);
-            const CT hh = (CT)1 - tp.lh, hw = (CT)1 - tp.lw;
-            const CT wk[4] = {hh * hw * w, hh * tp.lw * w, tp.lh * hw * w, tp.lh * tp.lw * w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int yy = tp.h_low + (c >> 1), xx = tp.w_low + (c & 1);
-                typename Ld::raw_t raw[G];
-                if (in_lds) {
-                    const int r = (yy - my_y0) * my_ww + (xx - my_x0);
-                    const unsigned rowo = tp.ok[c] ? (unsigned)(my_base + r * ROWB) : 0u;  // 0 = the zero row
-                    const unsigned key = tp.ok[c] ? (unsigned)((r / RPB) & (G - 1)) : 0u;
-#pragma unroll
-                    for (int gi = 0; gi < G; ++gi)
-                        raw[gi] = *reinterpret_cast<const typename Ld::raw_t*>(win + rowo + ((gi ^ key) << 4));
-                } else {
-                    const unsigned o = (unsigned)(startl + yy * Wl + xx) * row_bytes + head_off;
-#pragma unroll
-                    for (int gi = 0; gi < G; ++gi) raw[gi] = Ld::load(rsrc, tp.ok[c] ? o + gi * 16 : kOutOfRange);
-                }
-                const CT wc = tp.ok[c] ? wk[c] : (CT)0;
-#pragma unroll
-                for (int gi = 0; gi < G; ++gi) {
-                    CT v[VEC];
-                    Ld::widen(raw[gi], v);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[gi][i] += wc * v[i];
-                }
-            }
-        }
-    }
-
-    // ---- sum the group's partial results; lane j ends up with channels [j*VEC, (j+1)*VEC) -------------------------------------
-    group_reduce_scatter<G, VEC>(acc, part);
-    CT mine[VEC];
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        CT v = acc[0][i];
-#pragma unroll
-        for (int gi = 1; gi < G; ++gi) v = (part == gi) ? acc[gi][i] : v;
-        mine[i] = v;
-    }
-    if (live) store_vec<T, CT, VEC>(out + (((long)b * a.Lq + q) * a.M + m) * a.D + part * VEC, mine);
-}
-
-// Can the tiled kernel take this call?  (host copy of the shapes known, the model's L = P = 4, queries = pixels,
-// channels of a head = one 16-byte load per lane for 4 or 8 lanes)
-bool tile_plan(TileArgs& ta, const int32_t* shapes_host, int N, int S, int M, int D, int L, int Lq, int P, size_t elem,
-               bool aligned) {
-    if (!shapes_host || L != kTileLevels || P != 4 || Lq != S || !aligned) return false;
-    const int vec = (int)(16 / elem);
-    if (D % vec != 0) return false;
-    const int g = D / vec;
-    if (!(elem == 2 && g == 4)) return false;  // bf16, D = 32 (the fp32 instantiation exists but still spills registers)
-    const int tq = kThreads / g, tyq = tq / 8;
-    long total = 0, start = 0;
-    for (int l = 0; l < L; ++l) {
-        const int h = shapes_host[2 * l], w = shapes_host[2 * l + 1];
-        if (h <= 0 || w <= 0) return false;
-        ta.H[l] = h; ta.W[l] = w; ta.start[l] = (int)start;
-        ta.tiles_x[l] = (w + 7) / 8;
-        ta.tile_prefix[l] = (int)total;
-        total += (long)ta.tiles_x[l] * ((h + tyq - 1) / tyq);
-        start += (long)h * w;
-    }
-    if (start != S) return false;
-    ta.tile_prefix[L] = (int)total;
-    ta.tiles_total = (int)total;
-    const long nblocks = total * M * N;
-    if (nblocks <= 0 || nblocks >= 0x7fffffffL) return false;
-    ta.nblocks = (unsigned)nblocks;
-    return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -739,21 +371,14 @@ struct Plan {
 // Kernel-tuning knobs, read once from the environment (results never depend on them).
 //   ALO_MSDA_FWD_BATCH  2 | 4 | 8   sampling points whose 4 corner loads are put in flight together (forward)
 //   ALO_MSDA_ITERS      1..64       runs of pairs per workgroup (0 = automatic)
-//   ALO_MSDA_TILE       0 | 1       tiled (LDS-staged) encoder kernel off / on;  ALO_MSDA_TILE_LDS = its window budget
 struct Tuning {
     int fwd_batch = 4;
     int iters = 0;
-    int ablate = 0;
-    int tile = 1;          // ALO_MSDA_TILE=0 disables the tiled encoder kernel
-    int tile_lds = 36 * 1024;  // ALO_MSDA_TILE_LDS: bytes of LDS for staged windows (4 workgroups / CU at 36 KB)
 };
 const Tuning& tuning() {
     static const Tuning t = [] {
         Tuning x;
         if (const char* e = getenv("ALO_MSDA_FWD_BATCH")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_batch = v; }
-        if (const char* e = getenv("ALO_MSDA_ABLATE")) x.ablate = atoi(e);
-        if (const char* e = getenv("ALO_MSDA_TILE")) x.tile = atoi(e);
-        if (const char* e = getenv("ALO_MSDA_TILE_LDS")) { const int v = atoi(e); if (v >= 0 && v <= 120 * 1024) x.tile_lds = v; }
         if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
         return x;
     }();
@@ -786,7 +411,6 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
     d.S = S; d.M = M; d.D = D; d.L = L; d.P = P;
     d.pairs_per_batch = Lq * M;
     d.ref_dim = 0;
-    d.ablate = tuning().ablate;
     const int pairs = kThreads / G;
     const long iters_total = ((long)d.pairs_per_batch + pairs - 1) / pairs;
     long ipb = iters_total * N / 4096;  // keep >= ~4096 workgroups in flight when the problem allows it
@@ -861,20 +485,9 @@ int validate(const void* value, const int32_t* shapes, const int32_t* lstart, co
 using namespace alo;
 
 namespace {
-template <typename K>
-int launch_tile(K kernel, const TileArgs& ta, size_t lds, hipStream_t stream) {
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward(tile): %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(kernel, dim3(ta.nblocks), dim3(kThreads), lds, stream, ta);
-    return check_launch("alo_msda_forward(tile)");
-}
-
 int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
-                 const void* attn, const void* ref, int ref_dim, const int32_t* shapes_host, void* out, int N, int S,
-                 int M, int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
+                 const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
+                 int P, int value_dtype, int loc_dtype, void* stream_) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
                           loc_dtype, &elem))
@@ -887,20 +500,6 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
     Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
     dm.ref_dim = ref_dim;
     const int sb = tuning().fwd_batch;
-    if (tuning().tile && value_dtype != ALO_F64) {
-        TileArgs ta;
-        if (tile_plan(ta, shapes_host, N, S, M, D, L, Lq, P, elem, aligned)) {
-            ta.value = value; ta.loc = loc; ta.attn = attn; ta.ref = ref; ta.out = out;
-            ta.N = N; ta.S = S; ta.M = M; ta.D = D; ta.Lq = Lq; ta.ref_dim = ref_dim;
-            ta.window_budget = tuning().tile_lds;
-            const size_t lds = 64 + (size_t)ta.window_budget;  // bbox + [zero row | staged windows]
-            if (value_dtype == ALO_BF16)
-                return fused ? launch_tile(msda_fwd_tile_kernel<bf16_t, float, float, 8, 4, true>, ta, lds, stream)
-                             : launch_tile(msda_fwd_tile_kernel<bf16_t, float, float, 8, 4, false>, ta, lds, stream);
-            return fused ? launch_tile(msda_fwd_tile_kernel<float, float, float, 4, 8, true>, ta, lds, stream)
-                         : launch_tile(msda_fwd_tile_kernel<float, float, float, 4, 8, false>, ta, lds, stream);
-        }
-    }
     void* args[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm};
     if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_FWD_CASE, double, double, double, 2) }
@@ -912,22 +511,21 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
 extern "C" int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
                                 const void* sampling_loc, const void* attn_weight, void* out, int N, int S, int M,
                                 int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
-    return forward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, 0, nullptr, out, N,
-                        S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
+    return forward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, nullptr, 0, out, N, S, M, D,
+                        L, Lq, P, value_dtype, loc_dtype, stream_);
 }
 
 extern "C" int alo_msda_forward_fused(const void* value, const int32_t* spatial_shapes,
                                       const int32_t* level_start_index, const void* sampling_offsets,
-                                      const void* attn_logits, const void* reference_points,
-                                      const int32_t* spatial_shapes_host, void* out, int N, int S, int M, int D, int L,
-                                      int Lq, int P, int ref_dim, int value_dtype, void* stream_) {
+                                      const void* attn_logits, const void* reference_points, void* out, int N, int S,
+                                      int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype, void* stream_) {
     ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused: reference_points is null");
     ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
                 "alo_msda_forward_fused: last dim of reference_points must be 2 or 4, got %d", ref_dim);
     // the geometry dtype is implied: fp64 for fp64 values, fp32 otherwise (loc_dtype only steers validation here)
     const int loc_dtype = value_dtype == ALO_F64 ? ALO_F64 : ALO_F32;
     return forward_impl(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
-                        ref_dim, spatial_shapes_host, out, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
+                        ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
 }
 
 extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,

@@ -94,19 +94,13 @@ int alo_msda_forward(const void* value, const int32_t* spatial_shapes, const int
  *   attn_logits         (N, Lq, M, L*P)       value_dtype      raw output of the attention_weights linear layer
  *   reference_points    (N, Lq, L, ref_dim)   F64 when value_dtype is F64, F32 otherwise
  *
- *   spatial_shapes_host (L, 2) int32, HOST memory, optional (NULL = not available): a host copy of spatial_shapes.
- *                       With it, and Lq == S, L == P == 4 and D*sizeof(element) in {64 B x 4 lanes, 128 B x 8 lanes}, the
- *                       call runs the tiled encoder kernel (query tiles laid out over the pyramid, sample footprint
- *                       staged in LDS).  It steers scheduling only: results do not depend on it, provided it equals the
- *                       device copy.
- *
  * Softmax and location arithmetic run in fp32 (fp64 for F64) inside the kernel's descriptor stage; nothing but `out`
  * is written.  Inference path only (the gradient path uses alo_msda_forward / alo_msda_backward).
  */
 int alo_msda_forward_fused(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
                            const void* sampling_offsets, const void* attn_logits, const void* reference_points,
-                           const int32_t* spatial_shapes_host, void* out, int N, int S, int M, int D, int L, int Lq,
-                           int P, int ref_dim, int value_dtype, void* stream);
+                           void* out, int N, int S, int M, int D, int L, int Lq, int P, int ref_dim,
+                           int value_dtype, void* stream);
 
 /*
  * Multi-scale deformable attention, backward (gradients of the forward above w.r.t. value, sampling_loc, attn_weight).

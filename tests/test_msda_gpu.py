@@ -303,34 +303,3 @@ def test_module_uses_fused_prologue_in_inference_and_unfused_under_grad(golden):
     np.testing.assert_allclose(plain.detach().cpu().numpy(), g["out4"], rtol=1e-10, atol=1e-11)
     plain.sum().backward()
     assert m.sampling_offsets.weight.grad is not None and torch.isfinite(m.value_proj.weight.grad).all()
-
-
-# ---- tiled (LDS-staged) encoder kernel: must give what the generic kernel gives --------------------------------------
-@pytest.mark.parametrize("shapes_l", [DETR_SHAPES, [(16, 21), (8, 11), (4, 6), (2, 3)], [(9, 8), (5, 4), (3, 2), (1, 1)]])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("spread", [1.5, 12.0, 400.0])  # px: footprint fits LDS / partly falls back / mostly out of the map
-def test_tiled_encoder_kernel_equals_generic(shapes_l, dtype, spread):
-    N, M, D, L, P = 2, 8, 32, 4, 4
-    gen = torch.Generator(device=DEV).manual_seed(int(spread * 10) + len(shapes_l[0]))
-    shapes = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
-    start = dev(level_start(shapes_l))
-    S = int((shapes[:, 0] * shapes[:, 1]).sum())
-    value = torch.randn(N, S, M, D, generator=gen, device=DEV).to(dtype)
-    refs = []
-    for (h, w) in shapes_l:
-        ys, xs = torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w, device=DEV), indexing="ij")
-        refs.append(torch.stack([(xs.reshape(-1) + 0.5) / w, (ys.reshape(-1) + 0.5) / h], -1))
-    ref = torch.cat(refs, 0)[None, :, None, :].expand(N, S, L, 2).contiguous()
-    offsets = (torch.randn(N, S, M, L, P, 2, generator=gen, device=DEV) * spread).to(dtype)
-    logits = torch.randn(N, S, M, L * P, generator=gen, device=DEV).to(dtype)
-    generic = alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref)
-    tiled = alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref, shapes_host=shapes_l)
-    if dtype == torch.float32:  # (fp32 currently takes the generic kernel on both sides)
-        assert (tiled - generic).abs().max().item() <= 2e-6
-    else:
-        assert ((tiled.float() - generic.float()).abs() <= generic.float().abs() * 2.0 ** -7 + 1e-6).all()
-    # reference-box form (ref_dim = 4) through the same kernel
-    ref4 = torch.cat([ref, torch.rand(N, S, L, 2, generator=gen, device=DEV) * 0.2], -1)
-    g4 = alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref4)
-    t4 = alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref4, shapes_host=shapes_l)
-    assert ((t4.float() - g4.float()).abs() <= g4.float().abs() * 2.0 ** -7 + 2e-6).all()

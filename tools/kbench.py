@@ -116,8 +116,7 @@ def fused_inputs(N, dtype, seed=0):
 def bench_msda_fused(N, dtype, reps):
     value, shapes, start, offsets, logits, ref = fused_inputs(N, dtype)
     S = value.shape[1]
-    host = DETR_SHAPES if os.environ.get("KBENCH_TILE", "1") != "0" else None
-    t = time_launches(lambda: alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref, shapes_host=host), reps)
+    t = time_launches(lambda: alo_hip.msda_forward_fused(value, shapes, start, offsets, logits, ref), reps)
     e = value.element_size()
     nbytes = e * (N * S * 256 * 2 + N * S * 8 * 16 * 3) + ref.numel() * 4
     return dict(kernel="msda_fwd_fused[encoder]", N=N, Lq=S, dtype=str(dtype).split(".")[-1], ms=t * 1e3,
