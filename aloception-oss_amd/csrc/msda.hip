@@ -25,7 +25,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxLevels = 32;
-constexpr int kMetaBytes = 512;  // H[32] | W[32] | start[32] as int32, padded
+constexpr int kMetaBytes = 640;  // H[32] | W[32] | start[32] as int32 | 1/W[32] 1/H[32] as float bits... see load_meta
 
 template <typename CT>
 struct alignas(16) FwdDesc {
@@ -47,6 +47,7 @@ struct Dims {
     int iters_per_block;   // runs of (256 / G) pairs handled by one workgroup
     unsigned nblocks;
     int ref_dim;           // fused prologue only: last dim of reference_points (2 or 4)
+    int p_shift, m_shift;  // log2(P), log2(M) when they are powers of two, else -1 (integer division fallback)
 };
 
 // Image-space position, validity and the four corners of one sampling point (cuh:285-291, :38-78).
@@ -84,6 +85,8 @@ __device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, cons
         meta[t] = shapes[2 * t];
         meta[kMaxLevels + t] = shapes[2 * t + 1];
         meta[2 * kMaxLevels + t] = lstart[t];
+        meta[3 * kMaxLevels + t] = (int)__float_as_uint(1.0f / (float)shapes[2 * t + 1]);  // 1 / W_l
+        meta[4 * kMaxLevels + t] = (int)__float_as_uint(1.0f / (float)shapes[2 * t]);      // 1 / H_l
     }
 }
 
@@ -141,16 +144,19 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
             const bool live = pair < dm.pairs_per_batch;
             const long g = (batch_pair0 + (live ? pair : 0)) * LP + s;
             CT x = (CT)0, y = (CT)0, a = (CT)0;
-            const int l = s / dm.P;
+            const int l = dm.p_shift >= 0 ? (s >> dm.p_shift) : s / dm.P;  // wave-uniform choice, shift in the common case
             if (live) { x = (CT)ld(loc + 2 * g); y = (CT)ld(loc + 2 * g + 1); a = (CT)ld(attn + g); }
             if constexpr (FUSED) {
-                // softmax over the pair's L*P logits
+                // softmax over the pair's L*P logits.  Storage narrower than fp32 (bf16) carries 2^-9 relative error in the
+                // logits and offsets themselves, so the hardware exp and reciprocal multiplies (<= 2 ulp) are used there;
+                // fp32 / fp64 keep the exact library exp and true divisions of the unfused path.
+                constexpr bool kFast = sizeof(T) < 4;
                 CT mx, sum;
                 if constexpr (LP_CT == 16) {  // the 16 samples of a pair sit in 16 consecutive, aligned lanes
                     mx = a;
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-                    a = exp(a - mx);
+                    if constexpr (kFast) a = __expf(a - mx); else a = exp(a - mx);
                     sum = a;
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -162,13 +168,18 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                     for (int j = 0; j < LP; ++j) sum += exp((CT)ld(attn + g0 + j) - mx);
                     a = exp(a - mx);
                 }
-                a = a / sum;
+                if constexpr (kFast) a = a * __builtin_amdgcn_rcpf(sum); else a = a / sum;
                 if (live) {
-                    const int q = pair / dm.M;
+                    const int q = dm.m_shift >= 0 ? (pair >> dm.m_shift) : pair / dm.M;
                     const CT* r = ref + (((long)b * (dm.pairs_per_batch / dm.M) + q) * dm.L + l) * dm.ref_dim;
                     if (dm.ref_dim == 2) {
-                        x = r[0] + x / (CT)meta[kMaxLevels + l];
-                        y = r[1] + y / (CT)meta[l];
+                        if constexpr (kFast) {
+                            x = r[0] + x * __uint_as_float((unsigned)meta[3 * kMaxLevels + l]);
+                            y = r[1] + y * __uint_as_float((unsigned)meta[4 * kMaxLevels + l]);
+                        } else {
+                            x = r[0] + x / (CT)meta[kMaxLevels + l];
+                            y = r[1] + y / (CT)meta[l];
+                        }
                     } else {
                         x = r[0] + x / (CT)dm.P * r[2] * (CT)0.5;
                         y = r[1] + y / (CT)dm.P * r[3] * (CT)0.5;
@@ -179,10 +190,11 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                 const Tap<CT> t = make_tap<CT>(x, y, meta[l], meta[kMaxLevels + l], meta[2 * kMaxLevels + l]);
                 const CT hh = (CT)1 - t.lh, hw = (CT)1 - t.lw;
                 const CT w[4] = {hh * hw, hh * t.lw, t.lh * hw, t.lh * t.lw};
-                const int px[4] = {t.base, t.base + 1, t.base + t.W, t.base + t.W + 1};
+                const unsigned o0 = (unsigned)t.base * row_bytes, dy = (unsigned)t.W * row_bytes;
+                const unsigned po[4] = {o0, o0 + row_bytes, o0 + dy, o0 + dy + row_bytes};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (t.ok[k]) { d.off[k] = (unsigned)px[k] * row_bytes; d.w[k] = w[k] * a; }
+                    if (t.ok[k]) { d.off[k] = po[k]; d.w[k] = w[k] * a; }
                 }
             }
             *reinterpret_cast<Desc*>(dbase + pl * pair_stride + s * (int)sizeof(Desc)) = d;
@@ -194,7 +206,7 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
             const int pl = tid / G, lane = tid % G;
             const int pair = pair0 + pl;
             if (pair < dm.pairs_per_batch) {
-                const int m = pair % dm.M;
+                const int m = dm.m_shift >= 0 ? (pair & (dm.M - 1)) : pair % dm.M;
                 const unsigned char* dp = dbase + pl * pair_stride;
                 for (int c0 = lane * VEC; c0 < dm.D; c0 += G * VEC) {
                     const unsigned coff = (unsigned)(m * dm.D + c0) * (unsigned)sizeof(T);
@@ -411,6 +423,8 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
     d.S = S; d.M = M; d.D = D; d.L = L; d.P = P;
     d.pairs_per_batch = Lq * M;
     d.ref_dim = 0;
+    d.p_shift = (P & (P - 1)) == 0 ? __builtin_ctz((unsigned)P) : -1;
+    d.m_shift = (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1;
     const int pairs = kThreads / G;
     const long iters_total = ((long)d.pairs_per_batch + pairs - 1) / pairs;
     long ipb = iters_total * N / 4096;  // keep >= ~4096 workgroups in flight when the problem allows it
