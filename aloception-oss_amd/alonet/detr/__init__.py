@@ -1,3 +1,6 @@
 from .backbone import Backbone, FrozenBatchNorm2d, Joiner
+from .transformer import Transformer
+from .detr import Detr
+from .detr_r50 import DetrR50
 
-__all__ = ["Backbone", "FrozenBatchNorm2d", "Joiner"]
+__all__ = ["Backbone", "FrozenBatchNorm2d", "Joiner", "Transformer", "Detr", "DetrR50"]

@@ -23,6 +23,7 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
                          hs, inter_references_out, memory per level.  Weights come from helpers.formula_state_dict.
   g7_raft.npz            full RAFT forward on a 128x160 pair (images stored as fp16, used as such), 4 iterations, fp32: per-iteration flow, up_flow
   g8_known_answers.npz   hand-checkable micro cases (pixel-centre sample, corner sample)
+  g10_detr_transformer.npz   the reference's vanilla DETR Transformer (2 enc + 2 dec layers, d_model 64), fp64
   g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
@@ -330,12 +331,34 @@ def g9(ref):
     np.savez_compressed(os.path.join(OUT, "g9_posenc.npz"), mask=_np(mask), centered=_np(out_c), default=_np(out_d))
 
 
+def g10(ref):
+    """Vanilla DETR transformer of the reference (post-norm, 2 + 2 layers) with padding mask, fp64."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from helpers import formula_state_dict
+
+    _shell("alonet.detr", REF + "/alonet/detr")
+    TR = importlib.import_module("alonet.detr.transformer")
+    torch.manual_seed(1010)
+    tr = TR.Transformer(d_model=64, nhead=4, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=96,
+                        dropout=0.0, return_intermediate_dec=True).double().eval()
+    tr.load_state_dict(formula_state_dict(tr.state_dict()))
+    src = torch.randn(2, 64, 5, 7, dtype=torch.float64)
+    pos = torch.randn(2, 64, 5, 7, dtype=torch.float64) * 0.5
+    mask = torch.zeros(2, 5, 7, dtype=torch.bool)
+    mask[1, :, 5:] = True
+    query = torch.randn(9, 64, dtype=torch.float64)
+    with torch.no_grad():
+        out = tr(src, mask, query, pos)
+    np.savez_compressed(os.path.join(OUT, "g10_detr_transformer.npz"), src=_np(src), pos=_np(pos), mask=_np(mask),
+                        query=_np(query), hs=_np(out["hs"]), memory=_np(out["memory"]))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
     torch.set_num_threads(4)
     ref = load_reference()
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         fn(ref)
         print("wrote", fn.__name__)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))

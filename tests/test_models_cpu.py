@@ -115,3 +115,39 @@ def test_frame_io_contract():
     assert m[0].sum() == 0 and m[1, 0, :12, :18].sum() == 0 and m[1].sum() == 20 * 30 - 12 * 18
     assert torch.all(batch.as_tensor()[1, :, 12:, :] == 0)
     assert type(batch.as_tensor()) is torch.Tensor
+
+
+def test_detr_transformer_graph_matches_reference(golden):
+    from alonet.detr import Transformer
+
+    g = golden("g10_detr_transformer.npz")
+    tr = Transformer(d_model=64, nhead=4, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=96, dropout=0.0,
+                     return_intermediate_dec=True).double().eval()
+    res = tr.load_state_dict(formula_state_dict(tr.state_dict()))
+    assert not res.missing_keys and not res.unexpected_keys
+    with torch.no_grad():
+        out = tr(t(g["src"]), t(g["mask"]), t(g["query"]), t(g["pos"]))
+    np.testing.assert_allclose(out["hs"].numpy(), g["hs"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out["memory"].numpy(), g["memory"], rtol=1e-9, atol=1e-10)
+
+
+def test_detr_r50_cpu_plumbing():
+    """BASELINE configs[0]: DetrR50 inference on a Frame on the CPU (smaller frame here to keep the suite fast)."""
+    from alonet.detr import DetrR50
+
+    torch.manual_seed(0)
+    model = DetrR50(num_classes=91, aux_loss=True).eval()  # default device: cpu
+    keys = set(model.state_dict())
+    for k in ("backbone.0.body.layer4.2.bn3.running_var", "input_proj.weight", "query_embed.weight",
+              "transformer.encoder.layers.5.self_attn.in_proj_weight", "transformer.decoder.layers.0.multihead_attn.out_proj.bias",
+              "transformer.decoder.norm.weight", "class_embed.weight", "bbox_embed.layers.2.bias"):
+        assert k in keys, k
+    assert model.state_dict()["class_embed.weight"].shape == (92, 256) and model.state_dict()["query_embed.weight"].shape == (100, 256)
+    frame = aloscene.Frame(torch.rand(3, 160, 224) * 255, normalization="255").norm_resnet()
+    frames = aloscene.Frame.batch_list([frame, aloscene.Frame(torch.rand(3, 128, 192) * 255).norm_resnet()])
+    with torch.no_grad():
+        out = model(frames)
+    assert out["pred_logits"].shape == (2, 100, 92) and out["pred_boxes"].shape == (2, 100, 4)
+    assert len(out["aux_outputs"]) == 5 and torch.isfinite(out["pred_logits"]).all()
+    boxes = model.inference(out, threshold=0.0, background_class=-1)
+    assert len(boxes) == 2 and isinstance(boxes[0], aloscene.BoundingBoxes2D) and boxes[0].shape[1] == 4
