@@ -77,3 +77,38 @@ class BoundingBoxes2D(AugmentedTensor):
     def area(self):
         x1, y1, x2, y2 = self._as("xyxy").unbind(-1)
         return (x2 - x1) * (y2 - y1)
+
+    def remove_padding(self):
+        """Boxes relative to the un-padded frame (identity here: boxes are stored relative to their own frame)."""
+        return self
+
+    def _pair(self, other):
+        a = self._as("xyxy")
+        if other.absolute != self.absolute:
+            other = other.abs_pos(self.frame_size) if self.absolute else other.rel_pos()
+        return a, other._as("xyxy")
+
+    def iou_with(self, boxes2, ret_union=False):
+        """Pairwise IoU matrix (N, M) with another set of boxes."""
+        a, b = self._pair(boxes2)
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt = torch.max(a[:, None, :2], b[None, :, :2])
+        rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        union = area_a[:, None] + area_b[None, :] - inter
+        iou = inter / union
+        return (iou, union) if ret_union else iou
+
+    def giou_with(self, boxes2):
+        """Pairwise generalised IoU (https://giou.stanford.edu/) matrix (N, M)."""
+        a, b = self._pair(boxes2)
+        assert (a[:, 2:] >= a[:, :2]).all(), f"degenerate boxes {a}"
+        assert (b[:, 2:] >= b[:, :2]).all(), f"degenerate boxes {b}"
+        iou, union = self.iou_with(boxes2, ret_union=True)
+        lt = torch.min(a[:, None, :2], b[None, :, :2])
+        rb = torch.max(a[:, None, 2:], b[None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        hull = wh[..., 0] * wh[..., 1]
+        return iou - (hull - union) / hull

@@ -91,8 +91,19 @@ class AugmentedTensor(torch.Tensor):
         res._inherit(src)
         if name in ("to", "cpu", "cuda"):  # children travel with the data (reference :369-397)
             moved = {}
+            def move(c):
+                if not isinstance(c, torch.Tensor):
+                    return c
+                if name == "to":
+                    dev_args = [a for a in args[1:] if isinstance(a, (str, torch.device))]
+                    dev = kwargs.get("device", dev_args[0] if dev_args else None)
+                    return c.to(dev) if dev is not None else c
+                return getattr(c, name)()
+
             for key, child in res._children.items():
-                if isinstance(child, torch.Tensor) and name == "to":
+                if isinstance(child, (list, tuple)):
+                    moved[key] = [move(c) for c in child]
+                elif isinstance(child, torch.Tensor) and name == "to":
                     dev_args = [a for a in args[1:] if isinstance(a, (str, torch.device))]
                     dev = kwargs.get("device", dev_args[0] if dev_args else None)
                     moved[key] = child.to(dev) if dev is not None else child
@@ -177,5 +188,11 @@ class SpatialAugmentedTensor(AugmentedTensor):
             mask[tuple(mregion)] = 0
         out = data.as_subclass(type(first))
         out._inherit(first, names)
+        # per-frame labels (boxes2d, labels, ...) become one entry per batch item, as in the reference
+        for key in list(out._children):
+            if key == "mask":
+                continue
+            per_item = [t._children.get(key) for t in batched]
+            out._children[key] = per_item if any(c is not None for c in per_item) else None
         out._children["mask"] = Mask(mask, names=names)
         return out

@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--no-raft", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames in the bounded CPU sample")
+    ap.add_argument("--train-steps", type=int, default=0,
+                    help="also time K training steps of DeformableDETR-R50 (BASELINE configs[3]: fp32, 4 frames per GPU, "
+                         "DDP over RCCL when N > 1); off by default")
+    ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--selftest", action="store_true",
                     help="CPU/gloo dry run of the launch, sharding, fencing and max-over-ranks logic (no GPU, no kernels)")
     return ap.parse_args()
@@ -247,6 +251,39 @@ def main():
         del rmodel, f1, f2
         torch.cuda.empty_cache()
 
+    # ---- training step (opt-in) ---------------------------------------------------------------------------------------
+    train = None
+    if a.train_steps > 0:
+        from alonet.deformable_detr.training import build_criterion, configure_optimizers, training_step, wrap_ddp
+
+        torch.manual_seed(0)
+        tmodel = DeformableDetrR50(num_classes=91, aux_loss=True, device=device).train()
+        step_model = wrap_ddp(tmodel, local) if world > 1 else tmodel
+        gen = torch.Generator().manual_seed(777 + rank)
+        names = [f"class_{i}" for i in range(91)]
+        tframes = []
+        for _ in range(a.train_batch):
+            lab = aloscene.Labels(torch.randint(0, 91, (10,), generator=gen).float(), encoding="id", labels_names=names)
+            cxcy = torch.rand(10, 2, generator=gen) * 0.6 + 0.2
+            wh = torch.rand(10, 2, generator=gen) * 0.3 + 0.05
+            bx = aloscene.BoundingBoxes2D(torch.cat([cxcy, wh], 1), "xcyc", False, labels=lab)
+            tframes.append(aloscene.Frame(torch.rand(3, 800, 1333, generator=gen) * 255, normalization="255",
+                                          boxes2d=bx).norm_resnet())
+        tframes = aloscene.Frame.batch_list(tframes).to(device)
+        crit, opt = build_criterion(), configure_optimizers(tmodel)
+        with alo_hip.LaunchTimer() as ttimer:
+            tsec = timed_steps(lambda: training_step(step_model, crit, opt, tframes)[0].item(), a.train_steps, 1, world, device)
+        tk = kernel_report(ttimer.summary())
+        kernels.update({k + "[train]": v for k, v in tk.items()})
+        train = {"metric": "frames/sec (whole node) DeformableDETR-R50 training step", "unit": "frames/s",
+                 "value": round(a.train_batch * world * a.train_steps / tsec, 3), "steps": a.train_steps, "warmup": 1,
+                 "ms_per_step": round(tsec / a.train_steps * 1e3, 2), "dtype": "f32",
+                 "config": {"workload": f"forward + Hungarian match + set loss + backward (alo_msda_backward) + clip + AdamW, "
+                                        f"{a.train_batch} synthetic 1333x800 frames x 10 boxes per GPU, global batch {a.train_batch * world}",
+                            "parallelism": "DDP over RCCL" if world > 1 else "single GPU"}}
+        del tmodel, step_model, tframes, opt
+        torch.cuda.empty_cache()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -272,6 +309,8 @@ def main():
     }
     if raft is not None:
         line["raft"] = raft
+    if train is not None:
+        line["train"] = train
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.cpu_frames)
     print(json.dumps(line), flush=True)

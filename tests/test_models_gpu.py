@@ -89,3 +89,31 @@ def test_deformable_detr_r50_bf16_runs_and_tracks_fp32():
     assert out["pred_boxes"].dtype == torch.bfloat16 and torch.isfinite(out["pred_logits"].float()).all()
     # reduced precision end to end (backbone included): boxes are sigmoids in [0,1]; a loose sanity band only
     assert (out["pred_boxes"].float() - ref["pred_boxes"]).abs().mean().item() < 0.05
+
+
+def test_training_step_end_to_end_on_hip():
+    """BASELINE configs[3] in miniature: forward, Hungarian matching, set loss, backward through alo_msda_backward,
+    gradient clipping, AdamW with the reference's parameter groups."""
+    from alonet.deformable_detr.training import build_criterion, configure_optimizers, training_step
+    import alo_hip
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=5, aux_loss=True, device=torch.device(DEV)).train()
+    names = [f"c{i}" for i in range(5)]
+    frs = []
+    for i, (h, w) in enumerate([(192, 256), (160, 224)]):
+        lab = aloscene.Labels(torch.tensor([1.0, 3.0][: i + 1]), encoding="id", labels_names=names)
+        bx = aloscene.BoundingBoxes2D(torch.tensor([[0.3, 0.4, 0.2, 0.3], [0.7, 0.6, 0.2, 0.2]][: i + 1]), "xcyc", False, labels=lab)
+        frs.append(aloscene.Frame(torch.rand(3, h, w) * 255, normalization="255", boxes2d=bx).norm_resnet())
+    frames = aloscene.Frame.batch_list(frs).to(DEV)
+    crit, opt = build_criterion(), configure_optimizers(model)
+    before = model.transformer.encoder.layers[0].self_attn.value_proj.weight.detach().clone()
+    with alo_hip.LaunchTimer() as t:
+        loss0, parts = training_step(model, crit, opt, frames)
+        loss1, _ = training_step(model, crit, opt, frames)
+    tags = t.summary()
+    assert any(k.startswith("msda_bwd") for k in tags) and any(k.startswith("msda_fwd/") for k in tags)
+    assert torch.isfinite(loss0) and torch.isfinite(loss1)
+    assert {"loss_focal_label", "loss_bbox", "loss_giou", "loss_bbox_4"} <= set(parts)
+    after = model.transformer.encoder.layers[0].self_attn.value_proj.weight.detach()
+    assert not torch.equal(before, after)  # gradients reached the attention's value projection through the HIP backward
