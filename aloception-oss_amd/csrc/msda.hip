@@ -386,11 +386,13 @@ struct Plan {
 struct Tuning {
     int fwd_batch = 4;
     int iters = 0;
+    int bwd_lanes = 1;     // ALO_MSDA_BWD_LANES=0: vector lanes (16 B per lane) in backward; 1: one channel per lane
 };
 const Tuning& tuning() {
     static const Tuning t = [] {
         Tuning x;
         if (const char* e = getenv("ALO_MSDA_FWD_BATCH")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_batch = v; }
+        if (const char* e = getenv("ALO_MSDA_BWD_LANES")) x.bwd_lanes = atoi(e);
         if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
         return x;
     }();
@@ -474,7 +476,7 @@ int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char*
 #define ALO_ALL_CASES(CASE, T, LT, CT, VECW)                                                       \
     CASE(T, LT, CT, VECW, 4, 16) CASE(T, LT, CT, VECW, 8, 16) CASE(T, LT, CT, VECW, 16, 16)         \
     CASE(T, LT, CT, VECW, 4, 0) CASE(T, LT, CT, VECW, 8, 0) CASE(T, LT, CT, VECW, 16, 0)            \
-    CASE(T, LT, CT, VECW, 64, 0) CASE(T, LT, CT, 1, 8, 0) CASE(T, LT, CT, 1, 64, 0)
+    CASE(T, LT, CT, VECW, 64, 0) CASE(T, LT, CT, 1, 8, 0) CASE(T, LT, CT, 1, 32, 0) CASE(T, LT, CT, 1, 64, 0)
 
 int validate(const void* value, const int32_t* shapes, const int32_t* lstart, const void* loc, const void* attn,
              int N, int S, int M, int D, int L, int Lq, int P, int vdt, int ldt, size_t* elem_out) {
@@ -557,7 +559,14 @@ extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shape
     hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * gelem, stream);
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: memset: %s", hipGetErrorString(e));
     const bool aligned = (((uintptr_t)value | (uintptr_t)grad_out) & 15) == 0;
-    const Plan plan = make_plan(D, L, P, elem, aligned);
+    Plan plan = make_plan(D, L, P, elem, aligned);
+    if (tuning().bwd_lanes == 1 && D <= 64) {
+        // one channel per lane: each of the four atomics of a sampling point then covers D consecutive elements of ONE row
+        // (a whole 128-byte line for D = 32 fp32) instead of every VEC-th element of it
+        plan.vec = 1;
+        plan.g = D <= 8 ? 8 : (D <= 32 ? 32 : 64);
+        plan.lp16 = false;
+    }
     Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
     void* args[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &grad_out,
                     &grad_value, &grad_sampling_loc, &grad_attn_weight, &dm};
