@@ -54,6 +54,10 @@ def parse():
                     help="also time K training steps of DeformableDETR-R50 (BASELINE configs[3]: fp32, 4 frames per GPU, "
                          "DDP over RCCL when N > 1); off by default")
     ap.add_argument("--train-batch", type=int, default=4)
+    ap.add_argument("--panoptic-steps", type=int, default=0,
+                    help="also time K steps of PanopticHead over DeformableDETR-R50 (BASELINE configs[4]: --batch frames "
+                         "per GPU, --panoptic-queries kept queries per frame)")
+    ap.add_argument("--panoptic-queries", type=int, default=16)
     ap.add_argument("--selftest", action="store_true",
                     help="CPU/gloo dry run of the launch, sharding, fencing and max-over-ranks logic (no GPU, no kernels)")
     return ap.parse_args()
@@ -284,6 +288,34 @@ def main():
         del tmodel, step_model, tframes, opt
         torch.cuda.empty_cache()
 
+    # ---- panoptic head (opt-in) ---------------------------------------------------------------------------------------
+    panoptic = None
+    if a.panoptic_steps > 0:
+        from alonet.deformable_detr_panoptic import DeformableDetrR50Panoptic
+
+        torch.manual_seed(0)
+        pmodel = DeformableDetrR50Panoptic(num_classes=250, device=device).eval().to(dtype).to(memory_format=torch.channels_last)
+        pframes = detection_inputs(a.batch, rank, device, dtype)
+        keep = [torch.zeros(300, dtype=torch.bool, device=device) for _ in range(a.batch)]
+        for k in keep:  # random-init scores never pass the detector's threshold: keep a fixed, realistic query count
+            k[torch.arange(a.panoptic_queries, device=device) * (300 // a.panoptic_queries)] = True
+
+        def pan_step():
+            with torch.no_grad():
+                out = pmodel(pframes, filters=keep)
+                return pmodel.inference(out, filters=keep)
+
+        psec = timed_steps(pan_step, a.panoptic_steps, 1, world, device)
+        panoptic = {"metric": "frames/sec (whole node) PanopticHead on DeformableDETR-R50", "unit": "frames/s",
+                    "value": round(a.batch * world * a.panoptic_steps / psec, 3), "steps": a.panoptic_steps, "warmup": 1,
+                    "ms_per_step": round(psec / a.panoptic_steps * 1e3, 2), "dtype": a.dtype if a.dtype != "fp32" else "f32",
+                    "config": {"workload": f"PanopticHead (MHAttentionMap + FPNstyleCNN) over DeformableDETR-R50, forward + "
+                                           f"inference() to aloscene.Mask, batch {a.batch} synthetic 1333x800 frames per GPU, "
+                                           f"{a.panoptic_queries} kept queries per frame",
+                               "per_gpu_batch": a.batch}}
+        del pmodel, pframes
+        torch.cuda.empty_cache()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -311,6 +343,8 @@ def main():
         line["raft"] = raft
     if train is not None:
         line["train"] = train
+    if panoptic is not None:
+        line["panoptic"] = panoptic
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.cpu_frames)
     print(json.dumps(line), flush=True)

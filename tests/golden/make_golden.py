@@ -24,6 +24,7 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
   g7_raft.npz            full RAFT forward on a 128x160 pair (images stored as fp16, used as such), 4 iterations, fp32: per-iteration flow, up_flow
   g8_known_answers.npz   hand-checkable micro cases (pixel-centre sample, corner sample)
   g10_detr_transformer.npz   the reference's vanilla DETR Transformer (2 enc + 2 dec layers, d_model 64), fp64
+  g11_panoptic_nn.npz    MHAttentionMap + FPNstyleCNN of the reference's PanopticHead (fp64)
   g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
@@ -353,12 +354,40 @@ def g10(ref):
                         query=_np(query), hs=_np(out["hs"]), memory=_np(out["memory"]))
 
 
+def g11(ref):
+    """PanopticHead building blocks of the reference: MHAttentionMap and FPNstyleCNN (fp64, formula weights)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from helpers import formula_state_dict
+
+    _shell("alonet.detr_panoptic", REF + "/alonet/detr_panoptic")
+    _shell("alonet.detr_panoptic.nn", REF + "/alonet/detr_panoptic/nn")
+    MH = importlib.import_module("alonet.detr_panoptic.nn.MHAttention")
+    FP = importlib.import_module("alonet.detr_panoptic.nn.FPNstyle")
+    torch.manual_seed(1111)
+    att = MH.MHAttentionMap(32, 32, 8, dropout=0.0).double().eval()
+    att.load_state_dict(formula_state_dict(att.state_dict()))
+    q = torch.randn(2, 5, 32, dtype=torch.float64)
+    k = torch.randn(2, 32, 4, 6, dtype=torch.float64)
+    mask = torch.zeros(2, 4, 6, dtype=torch.bool)
+    mask[1, :, 4:] = True
+    head = FP.FPNstyleCNN(32 + 8, [48, 24, 16], 32 * 4).double().eval()  # context_dim 128 -> inter dims 64,32,16,8
+    head.load_state_dict(formula_state_dict(head.state_dict()))
+    x = torch.randn(2, 32, 4, 6, dtype=torch.float64)
+    fpns = [torch.randn(2, 48, 8, 12, dtype=torch.float64), torch.randn(2, 24, 16, 24, dtype=torch.float64),
+            torch.randn(2, 16, 32, 48, dtype=torch.float64)]
+    with torch.no_grad():
+        w = att(q, k, mask=mask)
+        seg = head(x, w, fpns)
+    np.savez_compressed(os.path.join(OUT, "g11_panoptic_nn.npz"), q=_np(q), k=_np(k), mask=_np(mask), weights=_np(w),
+                        x=_np(x), fpn0=_np(fpns[0]), fpn1=_np(fpns[1]), fpn2=_np(fpns[2]), seg=_np(seg))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
     torch.set_num_threads(4)
     ref = load_reference()
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         fn(ref)
         print("wrote", fn.__name__)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))

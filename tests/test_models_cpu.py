@@ -151,3 +151,42 @@ def test_detr_r50_cpu_plumbing():
     assert len(out["aux_outputs"]) == 5 and torch.isfinite(out["pred_logits"]).all()
     boxes = model.inference(out, threshold=0.0, background_class=-1)
     assert len(boxes) == 2 and isinstance(boxes[0], aloscene.BoundingBoxes2D) and boxes[0].shape[1] == 4
+
+
+def test_panoptic_head_blocks_match_reference(golden):
+    from alonet.detr_panoptic import FPNstyleCNN, MHAttentionMap
+
+    g = golden("g11_panoptic_nn.npz")
+    att = MHAttentionMap(32, 32, 8, dropout=0.0).double().eval()
+    assert not att.load_state_dict(formula_state_dict(att.state_dict())).missing_keys
+    head = FPNstyleCNN(32 + 8, [48, 24, 16], 128).double().eval()
+    assert not head.load_state_dict(formula_state_dict(head.state_dict())).missing_keys
+    with torch.no_grad():
+        w = att(t(g["q"]), t(g["k"]), mask=t(g["mask"]))
+        seg = head(t(g["x"]), w, [t(g["fpn0"]), t(g["fpn1"]), t(g["fpn2"])])
+    np.testing.assert_allclose(w.numpy(), g["weights"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(seg.numpy(), g["seg"], rtol=1e-8, atol=1e-9)
+    assert abs(float(w[0, 0].sum()) - 1.0) < 1e-9 and float(w[1, :, :, :, 4:].abs().max()) == 0.0  # padded columns get 0
+
+
+def test_panoptic_head_over_detr_r50_cpu():
+    """PanopticHead wiring on the CPU-runnable detector (DetrR50): shapes, state-dict prefixes, inference products."""
+    from alonet.detr import DetrR50
+    from alonet.detr_panoptic import PanopticHead
+
+    torch.manual_seed(0)
+    model = PanopticHead(DetrR50(num_classes=91, aux_loss=False), fpn_list=[1024, 512, 256]).eval()
+    keys = set(model.state_dict())
+    assert {"detr.input_proj.weight", "bbox_attention.q_linear.weight", "mask_head.lay1.weight", "mask_head.adapter3.bias"} <= keys
+    assert not any(p.requires_grad for p in model.detr.parameters())  # freeze_detr default
+    frames = aloscene.Frame.batch_list([aloscene.Frame(torch.rand(3, 128, 160) * 255).norm_resnet(),
+                                        aloscene.Frame(torch.rand(3, 96, 128) * 255).norm_resnet()])
+    keep = [torch.zeros(100, dtype=torch.bool), torch.zeros(100, dtype=torch.bool)]
+    keep[0][[3, 7, 50]] = True
+    keep[1][[1]] = True
+    with torch.no_grad():
+        out = model(frames, filters=keep)
+    assert out["pred_masks"].shape == (2, 3, 32, 40) and out["pred_logits"].shape == (2, 100, 92)
+    boxes, masks = model.inference(out, filters=keep)
+    assert [m.shape for m in masks] == [(3, 128, 160), (1, 128, 160)] and isinstance(masks[0], aloscene.Mask)
+    assert boxes[0].shape == (3, 4) and int(masks[0].as_tensor().sum(0).max()) <= 1  # one-hot across queries

@@ -117,3 +117,32 @@ def test_training_step_end_to_end_on_hip():
     assert {"loss_focal_label", "loss_bbox", "loss_giou", "loss_bbox_4"} <= set(parts)
     after = model.transformer.encoder.layers[0].self_attn.value_proj.weight.detach()
     assert not torch.equal(before, after)  # gradients reached the attention's value projection through the HIP backward
+
+
+def test_panoptic_head_on_deformable_detr_hip_vs_torch_branch():
+    """BASELINE configs[4] in miniature: PanopticHead over Deformable-DETR R50; detector attention on the HIP op vs the
+    pure-torch branch, same weights and same kept queries, then masks through ``inference``."""
+    from alonet.deformable_detr_panoptic import DeformableDetrR50Panoptic
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50Panoptic(num_classes=250, device=torch.device(DEV)).eval()
+    assert {"detr.transformer.encoder.layers.0.self_attn.value_proj.weight", "bbox_attention.k_linear.weight",
+            "mask_head.out_lay.bias"} <= set(model.state_dict())
+    frames = aloscene.Frame.batch_list(_frames([(192, 256), (160, 224)], seed=5)).to(DEV)
+    keep = [torch.zeros(300, dtype=torch.bool, device=DEV) for _ in range(2)]
+    keep[0][[0, 17, 120, 299]] = True
+    keep[1][[5, 6]] = True
+    with torch.no_grad():
+        out = model(frames, filters=keep)
+        ref = model(frames, filters=keep, is_tracing=None)
+    assert out["pred_masks"].shape == (2, 4, 48, 64)
+    scale = ref["pred_masks"].abs().max().item()
+    assert (out["pred_masks"] - ref["pred_masks"]).abs().max().item() <= 1e-3 * max(scale, 1.0)
+    boxes, masks = model.inference(out, filters=keep)
+    assert [tuple(m.shape) for m in masks] == [(4, 192, 256), (2, 192, 256)]
+    assert isinstance(masks[0], aloscene.Mask) and boxes[1].shape == (2, 4)
+    assert int(masks[0].as_tensor().sum(0).max()) <= 1
+    # default query selection: the detector's own score filter
+    with torch.no_grad():
+        out2 = model(frames, threshold=0.0)
+    assert out2["pred_masks"].shape[:2] == (2, 300)
