@@ -90,6 +90,85 @@ __device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, cons
     }
 }
 
+// Sampling point -> gather descriptor: 4 corner byte offsets (out-of-range for corners that are not read) and 4 corner
+// weights already multiplied by the attention weight.
+template <typename CT>
+__device__ __forceinline__ FwdDesc<CT> make_desc(CT x, CT y, CT a, int H, int W, int start, unsigned row_bytes) {
+    FwdDesc<CT> d;
+    const Tap<CT> t = make_tap<CT>(x, y, H, W, start);
+    const CT hh = (CT)1 - t.lh, hw = (CT)1 - t.lw;
+    const CT w[4] = {hh * hw, hh * t.lw, t.lh * hw, t.lh * t.lw};
+    const unsigned o0 = (unsigned)t.base * row_bytes, dy = (unsigned)t.W * row_bytes;
+    const unsigned po[4] = {o0, o0 + row_bytes, o0 + dy, o0 + dy + row_bytes};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d.off[k] = t.ok[k] ? po[k] : kOutOfRange;
+        d.w[k] = t.ok[k] ? w[k] * a : (CT)0;
+    }
+    return d;
+}
+
+// (x, y) of one sampling location / offset: one 4-byte load for bf16, one 8- / 16-byte load otherwise.
+__device__ __forceinline__ void ld2(const float* p, float& x, float& y) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    x = v.x; y = v.y;
+}
+__device__ __forceinline__ void ld2(const double* p, double& x, double& y) {
+    const double2 v = *reinterpret_cast<const double2*>(p);
+    x = v.x; y = v.y;
+}
+__device__ __forceinline__ void ld2(const bf16_t* p, float& x, float& y) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(p);
+    x = __uint_as_float(v << 16); y = __uint_as_float(v & 0xffff0000u);
+}
+
+// All-reduce over an aligned row of 16 lanes.  fp32: four DPP row rotations (pure VALU, no LDS round trips).
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ double row16_max(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double row16_sum(double v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// acc[0..VEC) += w * widen(row).  fp32 arithmetic is written on explicit 2-vectors so that every pair of channels is one
+// v_pk_fma_f32 (left to itself the compiler packs three quarters of them and emits mul + mov + add for the rest).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <typename Ld, typename CT, int VEC>
+__device__ __forceinline__ void fma_row(const typename Ld::raw_t& raw, CT w, CT (&acc)[VEC]) {
+    CT v[VEC];
+    Ld::widen(raw, v);
+    if constexpr (std::is_same<CT, float>::value && VEC % 2 == 0) {
+        const f32x2 ww = {w, w};
+#pragma unroll
+        for (int i = 0; i < VEC; i += 2) {
+            const f32x2 r = __builtin_elementwise_fma(ww, f32x2{v[i], v[i + 1]}, f32x2{acc[i], acc[i + 1]});
+            acc[i] = r.x;
+            acc[i + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += w * v[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
@@ -98,8 +177,14 @@ __device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, cons
 //                `ref` the reference points (N, Lq, L, ref_dim) of type CT; stage 1 evaluates what MSDeformAttn.forward
 //                does between its linear layers and the op (ms_deform_attn.py:119-133): softmax over the L*P logits and
 //                loc = ref + off / (W_l, H_l)   or   ref_xy + off / P * ref_wh * 0.5.
+#ifndef ALO_FWD_WAVES
+#define ALO_FWD_WAVES 1
+#endif
+#ifndef ALO_EXP
+#define ALO_EXP 0
+#endif
 template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, int SB, bool FUSED>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, ALO_FWD_WAVES)
 msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
                 const void* __restrict__ loc_, const void* __restrict__ attn_, const CT* __restrict__ ref,
                 T* __restrict__ out, const Dims dm) {
@@ -112,6 +197,7 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
     using Desc = FwdDesc<CT>;
     using Ld = Loader<T, CT, VEC>;
     constexpr int PAIRS = kThreads / G;
+    constexpr bool kPipelined = LP_CT == 16 && SB == 2;
     const int LP = LP_CT ? LP_CT : dm.L * dm.P;
     const int pair_stride = LP * (int)sizeof(Desc) + 16;  // +16 B: pairs of one wave land on distinct LDS slots
 
@@ -134,6 +220,66 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
         if (pair0 >= dm.pairs_per_batch) break;  // uniform
 
         // ---- stage 1: one descriptor per (pair, level, point) ------------------------------------------------------
+        if constexpr (LP_CT == 16) {
+            // L*P = 16: a thread keeps the same (level, point) slot s for every pair it serves, the 16 samples of a pair
+            // sit in one aligned row of 16 lanes, and a thread serves NS pairs per run.  All global loads of the NS
+            // samples are issued before the first is used (one memory latency per run, not 3*NS dependent ones);
+            // indices of pairs past the end are clamped so no load is predicated, their descriptors are nulled below.
+            constexpr int NS = PAIRS * 16 / kThreads;
+            const int s = tid & 15;
+            const int l = dm.p_shift >= 0 ? (s >> dm.p_shift) : s / dm.P;
+            const int Hl = meta[l], Wl = meta[kMaxLevels + l], start = meta[2 * kMaxLevels + l];
+            CT x[NS], y[NS], a[NS], r[NS][4];
+            const int last_pair = dm.pairs_per_batch - 1;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int pair = min(pair0 + (tid >> 4) + j * (kThreads / 16), last_pair);
+                const long g = (batch_pair0 + pair) * 16 + s;
+                ld2(loc + 2 * g, x[j], y[j]);
+                a[j] = (CT)ld(attn + g);
+                if constexpr (FUSED) {
+                    const int q = dm.m_shift >= 0 ? (pair >> dm.m_shift) : pair / dm.M;
+                    const CT* rp = ref + (((long)b * (dm.pairs_per_batch / dm.M) + q) * dm.L + l) * dm.ref_dim;
+                    r[j][0] = rp[0];
+                    r[j][1] = rp[1];
+                    if (dm.ref_dim == 4) { r[j][2] = rp[2]; r[j][3] = rp[3]; }  // uniform branch
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int pl = (tid >> 4) + j * (kThreads / 16);
+                CT xx = x[j], yy = y[j], aa = a[j];
+                if constexpr (FUSED) {
+                    // softmax over the pair's 16 logits, then loc = ref + off / (W_l, H_l)  |  ref_xy + off / P * ref_wh / 2.
+                    // Storage narrower than fp32 (bf16) carries 2^-9 relative error in the logits and offsets themselves,
+                    // so the hardware exp and reciprocal multiplies (<= 2 ulp) are used there; fp32 / fp64 keep the exact
+                    // library exp and true divisions of the unfused path.
+                    constexpr bool kFast = sizeof(T) < 4;
+                    const CT mx = row16_max(aa);
+                    if constexpr (kFast) aa = __expf(aa - mx); else aa = exp(aa - mx);
+                    const CT sum = row16_sum(aa);
+                    if constexpr (kFast) aa = aa * __builtin_amdgcn_rcpf(sum); else aa = aa / sum;
+                    if (dm.ref_dim == 2) {
+                        if constexpr (kFast) {
+                            xx = r[j][0] + xx * __uint_as_float((unsigned)meta[3 * kMaxLevels + l]);
+                            yy = r[j][1] + yy * __uint_as_float((unsigned)meta[4 * kMaxLevels + l]);
+                        } else {
+                            xx = r[j][0] + xx / (CT)Wl;
+                            yy = r[j][1] + yy / (CT)Hl;
+                        }
+                    } else {
+                        xx = r[j][0] + xx / (CT)dm.P * r[j][2] * (CT)0.5;
+                        yy = r[j][1] + yy / (CT)dm.P * r[j][3] * (CT)0.5;
+                    }
+                }
+                Desc d = make_desc<CT>(xx, yy, aa, Hl, Wl, start, row_bytes);
+                if (pair0 + pl > last_pair) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { d.off[k] = kOutOfRange; d.w[k] = (CT)0; }
+                }
+                *reinterpret_cast<Desc*>(dbase + pl * pair_stride + s * (int)sizeof(Desc)) = d;
+            }
+        } else {
         const int nsamp = PAIRS * LP;
         for (int si = tid; si < nsamp; si += kThreads) {
             const int pl = si / LP, s = si - pl * LP;
@@ -147,57 +293,27 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
             const int l = dm.p_shift >= 0 ? (s >> dm.p_shift) : s / dm.P;  // wave-uniform choice, shift in the common case
             if (live) { x = (CT)ld(loc + 2 * g); y = (CT)ld(loc + 2 * g + 1); a = (CT)ld(attn + g); }
             if constexpr (FUSED) {
-                // softmax over the pair's L*P logits.  Storage narrower than fp32 (bf16) carries 2^-9 relative error in the
-                // logits and offsets themselves, so the hardware exp and reciprocal multiplies (<= 2 ulp) are used there;
-                // fp32 / fp64 keep the exact library exp and true divisions of the unfused path.
-                constexpr bool kFast = sizeof(T) < 4;
-                CT mx, sum;
-                if constexpr (LP_CT == 16) {  // the 16 samples of a pair sit in 16 consecutive, aligned lanes
-                    mx = a;
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-                    if constexpr (kFast) a = __expf(a - mx); else a = exp(a - mx);
-                    sum = a;
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-                } else {
-                    const long g0 = g - s;
-                    mx = (CT)ld(attn + g0);
-                    for (int j = 1; j < LP; ++j) mx = fmax(mx, (CT)ld(attn + g0 + j));
-                    sum = (CT)0;
-                    for (int j = 0; j < LP; ++j) sum += exp((CT)ld(attn + g0 + j) - mx);
-                    a = exp(a - mx);
-                }
-                if constexpr (kFast) a = a * __builtin_amdgcn_rcpf(sum); else a = a / sum;
+                const long g0 = g - s;
+                CT mx = (CT)ld(attn + g0);
+                for (int j = 1; j < LP; ++j) mx = fmax(mx, (CT)ld(attn + g0 + j));
+                CT sum = (CT)0;
+                for (int j = 0; j < LP; ++j) sum += exp((CT)ld(attn + g0 + j) - mx);
+                a = exp(a - mx) / sum;
                 if (live) {
                     const int q = dm.m_shift >= 0 ? (pair >> dm.m_shift) : pair / dm.M;
                     const CT* r = ref + (((long)b * (dm.pairs_per_batch / dm.M) + q) * dm.L + l) * dm.ref_dim;
                     if (dm.ref_dim == 2) {
-                        if constexpr (kFast) {
-                            x = r[0] + x * __uint_as_float((unsigned)meta[3 * kMaxLevels + l]);
-                            y = r[1] + y * __uint_as_float((unsigned)meta[4 * kMaxLevels + l]);
-                        } else {
-                            x = r[0] + x / (CT)meta[kMaxLevels + l];
-                            y = r[1] + y / (CT)meta[l];
-                        }
+                        x = r[0] + x / (CT)meta[kMaxLevels + l];
+                        y = r[1] + y / (CT)meta[l];
                     } else {
                         x = r[0] + x / (CT)dm.P * r[2] * (CT)0.5;
                         y = r[1] + y / (CT)dm.P * r[3] * (CT)0.5;
                     }
                 }
             }
-            if (live) {
-                const Tap<CT> t = make_tap<CT>(x, y, meta[l], meta[kMaxLevels + l], meta[2 * kMaxLevels + l]);
-                const CT hh = (CT)1 - t.lh, hw = (CT)1 - t.lw;
-                const CT w[4] = {hh * hw, hh * t.lw, t.lh * hw, t.lh * t.lw};
-                const unsigned o0 = (unsigned)t.base * row_bytes, dy = (unsigned)t.W * row_bytes;
-                const unsigned po[4] = {o0, o0 + row_bytes, o0 + dy, o0 + dy + row_bytes};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (t.ok[k]) { d.off[k] = po[k]; d.w[k] = w[k] * a; }
-                }
-            }
+            if (live) d = make_desc<CT>(x, y, a, meta[l], meta[kMaxLevels + l], meta[2 * kMaxLevels + l], row_bytes);
             *reinterpret_cast<Desc*>(dbase + pl * pair_stride + s * (int)sizeof(Desc)) = d;
+        }
         }
         __syncthreads();
 
@@ -215,10 +331,7 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                     for (int i = 0; i < VEC; ++i) acc[i] = (CT)0;
                     // SB sampling points (4*SB corner rows) are requested before the first one is consumed; the
                     // outer loop stays rolled so the register allocator sees exactly that much in flight.
-#pragma unroll 1
-                    for (int s0 = 0; s0 < LP; s0 += SB) {
-                        Desc d[SB];
-                        typename Ld::raw_t raw[SB][4];
+                    auto issue = [&](int s0, Desc (&d)[SB], typename Ld::raw_t (&raw)[SB][4]) {
 #pragma unroll
                         for (int j = 0; j < SB; ++j) {
                             if (LP_CT || s0 + j < LP) {
@@ -230,15 +343,41 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
 #pragma unroll
                             for (int k = 0; k < 4; ++k) raw[j][k] = Ld::load(rsrc, d[j].off[k] + coff);
                         }
+                    };
+                    auto consume = [&](const Desc (&d)[SB], const typename Ld::raw_t (&raw)[SB][4]) {
 #pragma unroll
                         for (int j = 0; j < SB; ++j) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                CT v[VEC];
-                                Ld::widen(raw[j][k], v);
-#pragma unroll
-                                for (int i = 0; i < VEC; ++i) acc[i] += d[j].w[k] * v[i];
-                            }
+                            for (int k = 0; k < 4; ++k) fma_row<Ld, CT, VEC>(raw[j][k], d[j].w[k], acc);
+                        }
+                    };
+                    if constexpr (kPipelined) {
+                        // two register buffers: the rows of batch i+1 are requested before batch i is consumed, so a
+                        // wave keeps 4*SB loads in flight while its own VALU work runs (LP is a multiple of 2*SB here)
+                        Desc da[SB], db[SB];
+                        typename Ld::raw_t ra[SB][4], rb[SB][4];
+                        issue(0, da, ra);
+#pragma unroll 1
+                        for (int s0 = 0; s0 < LP; s0 += 2 * SB) {
+                            issue(s0 + SB, db, rb);
+                            __builtin_amdgcn_sched_barrier(0);
+                            consume(da, ra);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (s0 + 2 * SB < LP) issue(s0 + 2 * SB, da, ra);
+                            __builtin_amdgcn_sched_barrier(0);
+                            consume(db, rb);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int s0 = 0; s0 < LP; s0 += SB) {
+                            Desc d[SB];
+                            typename Ld::raw_t raw[SB][4];
+                            issue(s0, d, raw);
+#if ALO_EXP == 1
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                            consume(d, raw);
                         }
                     }
                     store_vec<T, CT, VEC>(out + (batch_pair0 + pair) * dm.D + c0, acc);
