@@ -177,14 +177,8 @@ __device__ __forceinline__ void fma_row(const typename Ld::raw_t& raw, CT w, CT 
 //                `ref` the reference points (N, Lq, L, ref_dim) of type CT; stage 1 evaluates what MSDeformAttn.forward
 //                does between its linear layers and the op (ms_deform_attn.py:119-133): softmax over the L*P logits and
 //                loc = ref + off / (W_l, H_l)   or   ref_xy + off / P * ref_wh * 0.5.
-#ifndef ALO_FWD_WAVES
-#define ALO_FWD_WAVES 1
-#endif
-#ifndef ALO_EXP
-#define ALO_EXP 0
-#endif
 template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, int SB, bool FUSED>
-__global__ void __launch_bounds__(kThreads, ALO_FWD_WAVES)
+__global__ void __launch_bounds__(kThreads)
 msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
                 const void* __restrict__ loc_, const void* __restrict__ attn_, const CT* __restrict__ ref,
                 T* __restrict__ out, const Dims dm) {
@@ -197,7 +191,6 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
     using Desc = FwdDesc<CT>;
     using Ld = Loader<T, CT, VEC>;
     constexpr int PAIRS = kThreads / G;
-    constexpr bool kPipelined = LP_CT == 16 && SB == 2;
     const int LP = LP_CT ? LP_CT : dm.L * dm.P;
     const int pair_stride = LP * (int)sizeof(Desc) + 16;  // +16 B: pairs of one wave land on distinct LDS slots
 
@@ -351,32 +344,12 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                             for (int k = 0; k < 4; ++k) fma_row<Ld, CT, VEC>(raw[j][k], d[j].w[k], acc);
                         }
                     };
-                    if constexpr (kPipelined) {
-                        // two register buffers: the rows of batch i+1 are requested before batch i is consumed, so a
-                        // wave keeps 4*SB loads in flight while its own VALU work runs (LP is a multiple of 2*SB here)
-                        Desc da[SB], db[SB];
-                        typename Ld::raw_t ra[SB][4], rb[SB][4];
-                        issue(0, da, ra);
-#pragma unroll 1
-                        for (int s0 = 0; s0 < LP; s0 += 2 * SB) {
-                            issue(s0 + SB, db, rb);
-                            __builtin_amdgcn_sched_barrier(0);
-                            consume(da, ra);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (s0 + 2 * SB < LP) issue(s0 + 2 * SB, da, ra);
-                            __builtin_amdgcn_sched_barrier(0);
-                            consume(db, rb);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    } else {
+                    {
 #pragma unroll 1
                         for (int s0 = 0; s0 < LP; s0 += SB) {
                             Desc d[SB];
                             typename Ld::raw_t raw[SB][4];
                             issue(s0, d, raw);
-#if ALO_EXP == 1
-                            __builtin_amdgcn_sched_barrier(0);
-#endif
                             consume(d, raw);
                         }
                     }
@@ -385,6 +358,222 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
             }
         }
         __syncthreads();  // descriptors are rewritten by the next run
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward, bf16 values, L = P = 4, D <= 32 (the DETR-family configuration): wave-autonomous, weighted sum on the matrix pipe.
+//
+// What bounds the bf16 gather (measured, profiles/r01_pmc_counters.md): every (pair, corner) request is a 64-byte half
+// of a 128-byte L1 line and the vector L1 serves one LINE per 2 clocks per CU — 91 M line reads per encoder launch =
+// 0.29 ms at 2.4 GHz, whatever the kernel does around them.  The generic kernel sat at 0.31 ms with its VALU 78 % busy
+// (1.5 instructions per gathered value: a shift/and to widen each bf16 + half a v_pk_fma_f32) and its two stages
+// serialised by block barriers.  This kernel removes both side costs so that only the L1 line rate is left:
+//   * v_mfma_f32_4x4x4_16B_bf16 multiplies 16 independent 4x4 blocks per wave — one block per (query, head) pair, i.e.
+//     exactly the 4 lanes that serve a pair — consumes the bf16 rows as they come out of memory (no widening) and
+//     accumulates in fp32:
+//     D_pair[i][j] += sum_{k<4} A_pair[i][k] * B_pair[k][j]          k = the 4 corners of one sampling point
+//     B[k][j]: lane j's channel of corner k (4 bf16 = one 64-bit operand; a 2-byte transpose of the loaded rows, v_perm)
+//     A[i][k]: the corner weights.  They are fp32, the operand is bf16, so stage 1 splits every weight EXACTLY into three
+//              bf16 terms w = hi + mid + lo (8 + 8 + 8 significant bits, truncation) and rows i = 0, 1, 2 carry one
+//              term each (row 3 is zero).  Every product bf16 x bf16 is exact in fp32, so D[0] + D[1] + D[2] is the
+//              fp32 weighted sum up to the order of the additions.
+// Per sampling point a lane then issues 4 row loads, 16 v_perm and 8 MFMA instead of 32 widen + 16 v_pk_fma.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+struct alignas(16) MfmaDesc {
+    unsigned off[4];      // corner byte offsets (kOutOfRange = not read)
+    unsigned arow[4][2];  // A rows: {hi, mid, lo, 0} x 4 corners, bf16 pairs packed low-half-first
+};
+constexpr int kMfmaPairStride = 16 * (int)sizeof(MfmaDesc) + 16;
+
+__device__ __forceinline__ s16x4 as_s16x4(unsigned lo, unsigned hi) {
+    union { unsigned u[2]; s16x4 v; } x;
+    x.u[0] = lo; x.u[1] = hi;
+    return x.v;
+}
+
+__device__ __forceinline__ float quad_max(float v) {  // all-reduce over the 4 lanes of a quad, DPP quad_perm
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));  // [1,0,3,2]
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));  // [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+    return v;
+}
+
+// One WAVE is the unit of work (64-thread workgroups, no block barrier anywhere): its 16 quads serve 16 consecutive
+// (query, head) pairs.  In stage 1 lane q of a quad turns the pair's 4 sampling points of level q into descriptors — its
+// inputs are one 16-byte (offsets), one 8-byte (logits) and one 8/16-byte (reference point) load instead of 16 narrow
+// ones, which matters because the texture path charges per instruction — and parks them in the wave's own LDS slice; in
+// stage 2 the same quad gathers the pair's 64 corner rows.  Waves drift apart freely, so the VALU work of one wave's
+// stage 1 overlaps the gathers of the others.  L = P = 4 and D <= 32 (the DETR-family configuration) only.
+constexpr int kWaveLds = 16 * kMfmaPairStride;
+
+template <int SB, bool FUSED>
+__global__ void __launch_bounds__(64)
+msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __restrict__ shapes,
+                          const int32_t* __restrict__ lstart, const void* __restrict__ loc_,
+                          const void* __restrict__ attn_, const float* __restrict__ ref, bf16_t* __restrict__ out,
+                          const Dims dm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Ld = Loader<bf16_t, float, 8>;
+
+    const unsigned lb = xcd_contiguous_block(blockIdx.x, dm.nblocks);
+    const int b = lb / dm.blocks_per_batch;
+    const int chunk = lb % dm.blocks_per_batch;
+    const int pl = threadIdx.x >> 2, lane = threadIdx.x & 3;  // pair slot in the wave, lane in the quad (= level in stage 1)
+
+    const unsigned row_elems = (unsigned)dm.M * dm.D;
+    const unsigned row_bytes = row_elems * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(value + (size_t)b * dm.S * row_elems, (unsigned)dm.S * row_bytes);
+    const long batch_pair0 = (long)b * dm.pairs_per_batch;
+    const int last_pair = dm.pairs_per_batch - 1;
+
+    const int Hl = shapes[2 * lane], Wl = shapes[2 * lane + 1], start = lstart[lane];
+    const float inv_w = 1.0f / (float)Wl, inv_h = 1.0f / (float)Hl;
+    unsigned char* dp = smem + pl * kMfmaPairStride;
+    const int c0 = lane * 8;  // lanes with c0 >= D only feed the A rows
+
+    for (int it = 0; it < dm.iters_per_block; ++it) {
+        const int pair0 = (chunk * dm.iters_per_block + it) * 16;
+        if (pair0 >= dm.pairs_per_batch) break;  // uniform
+        const int pair = pair0 + pl;
+        const bool dead = pair > last_pair;
+        const long g0 = (batch_pair0 + min(pair, last_pair)) * 16 + 4 * lane;
+
+        // ---- stage 1: the 4 points of level `lane` of this quad's pair ------------------------------------------------
+        {
+            float x[4], y[4], a[4];
+            if constexpr (FUSED) {
+                const u32x4 lr = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(loc_) + 2 * g0);
+                const u32x2 ar = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(attn_) + g0);
+                const int q = dm.m_shift >= 0 ? (min(pair, last_pair) >> dm.m_shift) : min(pair, last_pair) / dm.M;
+                const float* rp = ref + (((long)b * (dm.pairs_per_batch / dm.M) + q) * dm.L + lane) * dm.ref_dim;
+                float r0, r1, r2 = 0.f, r3 = 0.f;
+                if (dm.ref_dim == 2) {
+                    const float2 rv = *reinterpret_cast<const float2*>(rp);
+                    r0 = rv.x; r1 = rv.y;
+                } else {
+                    const float4 rv = *reinterpret_cast<const float4*>(rp);
+                    r0 = rv.x; r1 = rv.y; r2 = rv.z; r3 = rv.w;
+                }
+                const unsigned lw[4] = {lr.x, lr.y, lr.z, lr.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    x[i] = __uint_as_float(lw[i] << 16);
+                    y[i] = __uint_as_float(lw[i] & 0xffff0000u);
+                }
+                a[0] = __uint_as_float(ar.x << 16); a[1] = __uint_as_float(ar.x & 0xffff0000u);
+                a[2] = __uint_as_float(ar.y << 16); a[3] = __uint_as_float(ar.y & 0xffff0000u);
+                // softmax over the pair's 16 logits (4 here, 12 in the other lanes of the quad); bf16 inputs carry 2^-9
+                // relative error themselves, so the hardware exp / reciprocal (<= 2 ulp) are used, as in the generic kernel
+                const float mx = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = __expf(a[i] - mx);
+                const float inv = __builtin_amdgcn_rcpf(quad_sum((a[0] + a[1]) + (a[2] + a[3])));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[i] *= inv;
+                    if (dm.ref_dim == 2) {
+                        x[i] = r0 + x[i] * inv_w;
+                        y[i] = r1 + y[i] * inv_h;
+                    } else {
+                        x[i] = r0 + x[i] / (float)dm.P * r2 * 0.5f;
+                        y[i] = r1 + y[i] / (float)dm.P * r3 * 0.5f;
+                    }
+                }
+            } else {
+                const float* lp = static_cast<const float*>(loc_) + 2 * g0;
+                const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp), l1 = *reinterpret_cast<const f32x4*>(lp + 4);
+                const f32x4 av = *reinterpret_cast<const f32x4*>(static_cast<const float*>(attn_) + g0);
+                x[0] = l0[0]; y[0] = l0[1]; x[1] = l0[2]; y[1] = l0[3];
+                x[2] = l1[0]; y[2] = l1[1]; x[3] = l1[2]; y[3] = l1[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = av[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const FwdDesc<float> fd = make_desc<float>(x[i], y[i], a[i], Hl, Wl, start, row_bytes);
+                MfmaDesc d;
+                unsigned wb[4], r1b[4], r2b[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d.off[k] = dead ? kOutOfRange : fd.off[k];
+                    const float w = dead ? 0.0f : fd.w[k];
+                    wb[k] = __float_as_uint(w);
+                    const float r1 = w - __uint_as_float(wb[k] & 0xffff0000u);    // exact: the low 16 mantissa bits
+                    r1b[k] = __float_as_uint(r1);
+                    const float r2 = r1 - __uint_as_float(r1b[k] & 0xffff0000u);  // exact: <= 8 significant bits left
+                    r2b[k] = __float_as_uint(r2);
+                }
+                // bf16(x) by truncation = the upper half of x; v_perm packs two upper halves into one register
+                d.arow[0][0] = __builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u);
+                d.arow[0][1] = __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u);
+                d.arow[1][0] = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u);
+                d.arow[1][1] = __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u);
+                d.arow[2][0] = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u);
+                d.arow[2][1] = __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u);
+                d.arow[3][0] = 0u;
+                d.arow[3][1] = 0u;
+                *reinterpret_cast<MfmaDesc*>(dp + (4 * lane + i) * (int)sizeof(MfmaDesc)) = d;
+            }
+        }
+        // descriptors are exchanged inside the wave only: LDS operations of one wave execute in order, the fence keeps the
+        // compiler from moving the reads below above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- stage 2: gather + MFMA accumulate -----------------------------------------------------------------------
+        {
+            const int m = dm.m_shift >= 0 ? (pair & (dm.M - 1)) : pair % dm.M;
+            const unsigned coff = (unsigned)(m * dm.D + c0) * 2u;
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int s0 = 0; s0 < 16; s0 += SB) {
+                u32x4 raw[SB][4];
+                s16x4 arow[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const unsigned char* e = dp + (s0 + j) * (int)sizeof(MfmaDesc);
+                    const u32x4 off = *reinterpret_cast<const u32x4*>(e);
+                    const u32x2 ar = *reinterpret_cast<const u32x2*>(e + 16 + 8 * lane);
+                    arow[j] = as_s16x4(ar.x, ar.y);
+                    raw[j][0] = Ld::load(rsrc, off.x + coff);
+                    raw[j][1] = Ld::load(rsrc, off.y + coff);
+                    raw[j][2] = Ld::load(rsrc, off.z + coff);
+                    raw[j][3] = Ld::load(rsrc, off.w + coff);
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned t0 = raw[j][0][q], t1 = raw[j][1][q], t2 = raw[j][2][q], t3 = raw[j][3][q];
+                        const s16x4 b_even = as_s16x4(__builtin_amdgcn_perm(t1, t0, 0x05040100u),
+                                                      __builtin_amdgcn_perm(t3, t2, 0x05040100u));
+                        const s16x4 b_odd = as_s16x4(__builtin_amdgcn_perm(t1, t0, 0x07060302u),
+                                                     __builtin_amdgcn_perm(t3, t2, 0x07060302u));
+                        acc[2 * q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[j], b_even, acc[2 * q], 0, 0, 0);
+                        acc[2 * q + 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[j], b_odd, acc[2 * q + 1], 0, 0, 0);
+                    }
+                }
+            }
+            if (!dead && c0 < dm.D) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (acc[i][0] + acc[i][1]) + acc[i][2];
+                store_vec<bf16_t, float, 8>(out + (batch_pair0 + pair) * dm.D + c0, o);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -526,12 +715,14 @@ struct Tuning {
     int fwd_batch = 4;
     int iters = 0;
     int bwd_lanes = 1;     // ALO_MSDA_BWD_LANES=0: vector lanes (16 B per lane) in backward; 1: one channel per lane
+    int mfma = 1;          // ALO_MSDA_MFMA=0: keep bf16 forward on the VALU kernel
 };
 const Tuning& tuning() {
     static const Tuning t = [] {
         Tuning x;
         if (const char* e = getenv("ALO_MSDA_FWD_BATCH")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_batch = v; }
         if (const char* e = getenv("ALO_MSDA_BWD_LANES")) x.bwd_lanes = atoi(e);
+        if (const char* e = getenv("ALO_MSDA_MFMA")) x.mfma = atoi(e);
         if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
         return x;
     }();
@@ -559,7 +750,7 @@ Plan make_plan(int D, int L, int P, size_t elem, bool aligned16) {
     return p;
 }
 
-Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
+Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G, long target_blocks = 4096) {
     Dims d;
     d.S = S; d.M = M; d.D = D; d.L = L; d.P = P;
     d.pairs_per_batch = Lq * M;
@@ -568,7 +759,7 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
     d.m_shift = (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1;
     const int pairs = kThreads / G;
     const long iters_total = ((long)d.pairs_per_batch + pairs - 1) / pairs;
-    long ipb = iters_total * N / 4096;  // keep >= ~4096 workgroups in flight when the problem allows it
+    long ipb = iters_total * N / target_blocks;  // keep >= ~4096 workgroups of 4 waves in flight when the problem allows it
     if (ipb < 1) ipb = 1;
     if (ipb > 8) ipb = 8;
     if (tuning().iters > 0) ipb = tuning().iters;
@@ -579,14 +770,14 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G) {
 }
 
 template <typename K>
-int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char* what, void** args) {
+int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char* what, void** args, int threads = kThreads) {
     if (lds > 160 * 1024) return fail(ALO_ERR_UNSUPPORTED, "%s: L*P too large for LDS (%zu bytes)", what, lds);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     }
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(dm.nblocks), dim3(kThreads), args, lds,
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(dm.nblocks), dim3(threads), args, lds,
                                    stream);
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return check_launch(what);
@@ -656,6 +847,20 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
     dm.ref_dim = ref_dim;
     const int sb = tuning().fwd_batch;
     void* args[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm};
+    const bool in_aligned = (((uintptr_t)loc | (uintptr_t)attn | (uintptr_t)(fused ? ref : nullptr)) & 15) == 0;
+    if (value_dtype == ALO_BF16 && aligned && in_aligned && L == 4 && P == 4 && D % 8 == 0 && D <= 32 && tuning().mfma &&
+        (size_t)M * D * 2 < (1u << 24)) {
+        // bf16 rows go to the matrix pipe untouched, one wave per 16 pairs (see msda_fwd_bf16_mfma_kernel)
+        dm = make_dims(N, S, M, D, L, Lq, P, 16, 16384);
+        dm.ref_dim = ref_dim;
+        const char* what = fused ? "alo_msda_forward_fused" : "alo_msda_forward";
+        if (fused) {
+            if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, true>, dm, kWaveLds, stream, what, args, 64);
+            return launch(msda_fwd_bf16_mfma_kernel<4, true>, dm, kWaveLds, stream, what, args, 64);
+        }
+        if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, false>, dm, kWaveLds, stream, what, args, 64);
+        return launch(msda_fwd_bf16_mfma_kernel<4, false>, dm, kWaveLds, stream, what, args, 64);
+    }
     if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_FWD_CASE, double, double, double, 2) }
     if (value_dtype == ALO_BF16) { ALO_ALL_CASES(ALO_FWD_CASE, bf16_t, float, float, 8) }

@@ -331,7 +331,7 @@ def main():
                                "MSDeformAttn on HIP kernels; random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": None if enc is None else {
-            "bound": "hbm", "kernel": "msda_fwd_kernel, fused prologue (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
+            "bound": "hbm", "kernel": "msda_fwd_bf16_mfma_kernel<4, fused> (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
             "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc["hbm_frac"],
             # HBM-side bytes per launch from the PMC passes (profiles/r01_pmc_counters.md): FETCH_SIZE 384.6 MB (raw,
             # gather pattern uncalibrated: lower bound) + WRITE_SIZE 88.9 MB; measured offline, not in this run
