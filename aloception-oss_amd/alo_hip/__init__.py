@@ -56,6 +56,10 @@ def _declare(lib):
     lib.alo_corr_build.argtypes = [vp, vp, c.POINTER(vp), vp, sz] + [ip] * 5 + [vp]
     lib.alo_corr_lookup.restype = ip
     lib.alo_corr_lookup.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
+    lib.alo_add_layernorm.restype = ip
+    lib.alo_add_layernorm.argtypes = [vp] * 7 + [c.c_long, ip, c.c_float, ip, vp]
+    lib.alo_bias_act.restype = ip
+    lib.alo_bias_act.argtypes = [vp] * 4 + [c.c_long, ip, ip, ip, vp]
 
 
 def lib():
@@ -328,3 +332,61 @@ def corr_lookup(levels, coords, radius=4):
     with torch.cuda.device(coords.device), _timed("corr_lookup", nbytes):
         _check(lib().alo_corr_lookup(ptrs, _ptr(coords), _ptr(out), B, H, W, radius, L, _stream(coords.device)))
     return out
+
+
+# ---- one-pass epilogues around the attention op (alo_add_layernorm / alo_bias_act) ---------------------------------------
+def fusable(*tensors):
+    """True when the fused epilogues may replace the stock ops: inference (no autograd graph), CUDA, fp32 or bf16."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return False
+    first = tensors[0]
+    return first.is_cuda and first.dtype in (torch.float32, torch.bfloat16)
+
+
+def add_layernorm(x, residual, weight, bias, eps=1e-5, pos=None):
+    """``LayerNorm(x + residual)`` over the last dim in one pass; with ``pos`` also returns ``out + pos`` (the next
+    layer's ``with_pos_embed``).  Replaces ``norm(src + dropout(src2))`` of the (de)formable transformer layers at
+    inference.  -> out  |  (out, out_plus_pos)"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    x = x.contiguous()
+    residual = None if residual is None else residual.contiguous()
+    pos = None if pos is None else pos.contiguous()
+    for name, t in (("residual", residual), ("pos", pos)):
+        if t is not None and (t.shape != x.shape or t.dtype != x.dtype):
+            raise RuntimeError(f"add_layernorm: {name} must have the shape and dtype of x")
+    weight, bias = weight.to(x.dtype).contiguous(), bias.to(x.dtype).contiguous()
+    out = torch.empty_like(x)
+    out_pos = None if pos is None else torch.empty_like(x)
+    nbytes = x.element_size() * x.numel() * (2 + (residual is not None) + 2 * (pos is not None))
+    with torch.cuda.device(x.device), _timed(f"add_layernorm/rows={rows}", nbytes):
+        _check(lib().alo_add_layernorm(_ptr(x), None if residual is None else _ptr(residual), _ptr(weight), _ptr(bias),
+                                       _ptr(out), None if pos is None else _ptr(pos),
+                                       None if pos is None else _ptr(out_pos), rows, C, float(eps),
+                                       _DTYPE_CODE[x.dtype], _stream(x.device)))
+    return out if pos is None else (out, out_pos)
+
+
+def bias_act_(x, bias, residual=None, relu=True):
+    """In place on a channels-last activation ``x`` (N,C,H,W with NHWC strides) or a (rows, C) matrix:
+    ``x = act(x + bias[c] (+ residual))``.  Replaces folded FrozenBatchNorm bias -> (+ identity) -> ReLU of the ResNet."""
+    if x.dim() == 4:
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError("bias_act_: 4-D input must be channels_last")
+        C = x.shape[1]
+        if residual is not None and not (residual.shape == x.shape and residual.is_contiguous(memory_format=torch.channels_last)):
+            raise RuntimeError("bias_act_: residual must be channels_last with the shape of x")
+    else:
+        if not x.is_contiguous():
+            raise RuntimeError("bias_act_: matrix input must be contiguous")
+        C = x.shape[-1]
+        if residual is not None and not (residual.shape == x.shape and residual.is_contiguous()):
+            raise RuntimeError("bias_act_: residual must be contiguous with the shape of x")
+    if residual is not None and residual.dtype != x.dtype:
+        raise RuntimeError("bias_act_: residual must have the dtype of x")
+    bias = bias.to(x.dtype).contiguous()
+    nbytes = x.element_size() * x.numel() * (2 + (residual is not None))
+    with torch.cuda.device(x.device), _timed(f"bias_act/C={C}", nbytes):
+        _check(lib().alo_bias_act(_ptr(x), _ptr(bias), None if residual is None else _ptr(residual), _ptr(x),
+                                  x.numel() // C, C, 1 if relu else 0, _DTYPE_CODE[x.dtype], _stream(x.device)))
+    return x

@@ -129,7 +129,8 @@ class DeformableDETR(nn.Module):
         if "is_tracing" not in kwargs:  # the pure-torch export branch may run anywhere; the HIP op may not
             assert next(self.parameters()).is_cuda, "DeformableDETR cannot run on CPU (due to MSdeformable op)"
         frame_masks = frames.mask.as_tensor()
-        features, pos = self.backbone(frames, **kwargs)
+        # the stride-4 positional encoding is only ever an output (bb_lvl0_pos_outputs), never an input of the transformer
+        features, pos = self.backbone(frames, skip_pos_levels=() if self.return_bb_outputs else (0,), **kwargs)
 
         srcs, masks = [], []
         for lvl, (src, mask) in enumerate(features[1:]):
@@ -219,10 +220,14 @@ class DeformableDETR(nn.Module):
         if filters is None:
             filters = self.get_outs_filter(outs_scores=scores_all, outs_labels=labels_all, threshold=threshold,
                                            activation_fn=activation_fn, **kwargs)
+        # one device -> host transfer per tensor; the per-image boolean selection then runs on the host (on the device every
+        # `x[keep]` is a nonzero + a synchronisation: 3 per image)
+        keep_all = torch.stack(list(filters)) if not torch.is_tensor(filters) else filters
+        scores_all, labels_all, boxes_all, keep_all = (t.cpu() for t in (scores_all, labels_all, boxes_all.float(), keep_all))
         preds = []
-        for scores, labels, boxes, keep in zip(scores_all, labels_all, boxes_all, filters):
+        for scores, labels, boxes, keep in zip(scores_all, labels_all, boxes_all, keep_all):
             lab = aloscene.Labels(labels[keep].type(torch.float32), encoding="id", scores=scores[keep], names=("N",))
-            preds.append(aloscene.BoundingBoxes2D(boxes[keep].float().cpu(), boxes_format="xcyc", absolute=False,
+            preds.append(aloscene.BoundingBoxes2D(boxes[keep], boxes_format="xcyc", absolute=False,
                                                   names=("N", None), labels=lab))
         return preds
 

@@ -12,8 +12,20 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
+import alo_hip
+
 from .ops.modules import MSDeformAttn
 from .utils import inverse_sigmoid
+
+
+def _fused_ok(module, kwargs, *tensors):
+    """The one-pass HIP epilogues (alo_add_layernorm) stand in for ``norm(x + dropout(y))`` when nothing is lost: eval mode
+    (dropout is the identity), no autograd graph, CUDA, fp32 / bf16, and not the pure-torch export branch."""
+    return not module.training and "is_tracing" not in kwargs and alo_hip.fusable(*tensors)
+
+
+def _add_norm(norm, x, residual, pos=None):
+    return alo_hip.add_layernorm(x, residual, norm.weight, norm.bias, norm.eps, pos=pos)
 
 
 def _get_clones(module, n):
@@ -54,6 +66,17 @@ class DeformableTransformerEncoderLayer(nn.Module):
         src = self.norm1(src + self.dropout1(src2))
         return self.forward_ffn(src)
 
+    def forward_fused(self, src, query, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None,
+                      next_query=True, **kwargs):
+        """Inference form of ``forward``: ``query = src + pos`` comes in ready-made, both residual + LayerNorm pairs are
+        one HIP pass each, and the second one also emits the next layer's query.  -> (src', src' + pos | None)"""
+        src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask, **kwargs)
+        src = _add_norm(self.norm1, src2, src)
+        src2 = self.linear2(self.activation(self.linear1(src)))
+        if next_query and pos is not None:
+            return _add_norm(self.norm2, src2, src, pos=pos)
+        return _add_norm(self.norm2, src2, src), None
+
 
 class DeformableTransformerEncoder(nn.Module):
     def __init__(self, encoder_layer, num_layers):
@@ -65,8 +88,9 @@ class DeformableTransformerEncoder(nn.Module):
     def get_reference_points(spatial_shapes, valid_ratios, device, **kwargs):
         """Every pixel centre of every level, normalised by the valid (un-padded) extent: (B, S, L, 2)."""
         per_level = []
+        host_shapes = getattr(spatial_shapes, "_alo_shapes", None)  # python copy set by DeformableTransformer: no device sync
         for lvl in range(spatial_shapes.shape[0]):
-            h, w = int(spatial_shapes[lvl, 0]), int(spatial_shapes[lvl, 1])
+            h, w = host_shapes[lvl] if host_shapes is not None else (int(spatial_shapes[lvl, 0]), int(spatial_shapes[lvl, 1]))
             ys = torch.arange(h, dtype=torch.float32, device=device) + 0.5
             xs = torch.arange(w, dtype=torch.float32, device=device) + 0.5
             ref_y, ref_x = torch.meshgrid(ys, xs, indexing="ij")
@@ -79,6 +103,14 @@ class DeformableTransformerEncoder(nn.Module):
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None, **kwargs):
         output = src
         reference_points = self.get_reference_points(spatial_shapes, valid_ratios, device=src.device, **kwargs)
+        if _fused_ok(self, kwargs, output, pos) and all(hasattr(layer, "forward_fused") for layer in self.layers):
+            query = output if pos is None else output + pos
+            for i, layer in enumerate(self.layers):
+                output, query = layer.forward_fused(output, query, pos, reference_points, spatial_shapes, level_start_index,
+                                                    padding_mask, next_query=i + 1 < len(self.layers), **kwargs)
+                if query is None:
+                    query = output
+            return output
         for layer in self.layers:
             output = layer(output, pos, reference_points, spatial_shapes, level_start_index, padding_mask, **kwargs)
         return output
@@ -117,6 +149,15 @@ class DeformableTransformerDecoderLayer(nn.Module):
         q = k = self.with_pos_embed(tgt, query_pos)  # self-attention among the queries (sequence-first API)
         tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
                               key_padding_mask=tgt_key_padding_mask)[0].transpose(0, 1)
+        if _fused_ok(self, kwargs, tgt, tgt2, query_pos):  # inference: residual + LayerNorm (+ query_pos) in one pass each
+            if query_pos is None:
+                tgt = query = _add_norm(self.norm2, tgt2, tgt)
+            else:
+                tgt, query = _add_norm(self.norm2, tgt2, tgt, pos=query_pos.expand_as(tgt))
+            tgt2 = self.cross_attn(query, reference_points, src, src_spatial_shapes, level_start_index,
+                                   src_padding_mask, **kwargs)
+            tgt = _add_norm(self.norm1, tgt2, tgt)
+            return _add_norm(self.norm3, self.linear2(self.activation(self.linear1(tgt))), tgt)
         tgt = self.norm2(tgt + self.dropout2(tgt2))
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
                                level_start_index, src_padding_mask, **kwargs)
@@ -246,6 +287,8 @@ class DeformableTransformer(nn.Module):
         # int32 metadata on the device: what this fork of the op reads (ms_deform_attn_cuda.cu:67-68)
         spatial_shapes = torch.tensor(shapes, dtype=torch.int32, device=device)
         sizes = [h * w for h, w in shapes]
+        spatial_shapes._alo_total = sum(sizes)  # host-side copies: shape checks / loops downstream need no device sync
+        spatial_shapes._alo_shapes = list(shapes)
         level_start_index = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int32, device=device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 

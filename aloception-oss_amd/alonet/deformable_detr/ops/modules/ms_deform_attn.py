@@ -87,12 +87,18 @@ class MSDeformAttn(nn.Module):
         """
         N, Lq, _ = query.shape
         _, S, _ = input_flatten.shape
-        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == S
+        total = getattr(input_spatial_shapes, "_alo_total", None)  # set by DeformableTransformer: no device sync
+        if total is None:
+            total = int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum())
+        assert total == S
         M, L, P = self.n_heads, self.n_levels, self.n_points
 
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
+            if torch.is_grad_enabled() and value.requires_grad:
+                value = value.masked_fill(input_padding_mask[..., None], float(0))
+            else:  # the projection's output is a fresh tensor: mask it in place, no clone
+                value.masked_fill_(input_padding_mask[..., None], float(0))
         value = value.view(N, S, M, self.d_model // M)
 
         if reference_points.shape[-1] not in (2, 4):

@@ -9,6 +9,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+import alo_hip
+
 from .misc import assert_and_export_onnx
 
 
@@ -35,8 +37,8 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.reshape(1, -1, 1, 1).to(x.dtype) + shift.reshape(1, -1, 1, 1).to(x.dtype)
 
 
-def conv_bn(x, conv, bn, relu=False):
-    """``bn(conv(x))`` with the frozen batch-norm folded into the convolution's weight and bias.
+def conv_bn(x, conv, bn, relu=False, residual=None):
+    """``act(bn(conv(x)) [+ residual])`` with the frozen batch-norm folded into the convolution's weight and bias.
 
     A FrozenBatchNorm2d is a fixed per-channel affine map, so ``bn(conv(x)) == conv'(x)`` with
     ``w' = w * scale[:, None, None, None]`` and ``b' = shift``: two full passes over the activation (multiply, add)
@@ -57,9 +59,19 @@ def conv_bn(x, conv, bn, relu=False):
                 conv.__dict__["_folded"] = (key, w.detach(), b.detach())
         else:
             _, w, b = cached
-        out = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if (relu or residual is not None) and alo_hip.fusable(x, w) and x.is_contiguous(memory_format=torch.channels_last):
+            # inference on the GPU: bias (+ identity) + ReLU are ONE in-place pass over the NHWC convolution output
+            # instead of MIOpen's separate bias kernel followed by add / relu kernels
+            out = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if out.is_contiguous(memory_format=torch.channels_last) and out.shape[1] % 4 == 0:
+                return alo_hip.bias_act_(out, b, residual, relu)
+            out = out + b.view(1, -1, 1, 1)
+        else:
+            out = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
     else:
         out = bn(conv(x))
+    if residual is not None:
+        out = out + residual
     return F.relu_(out) if relu else out
 
 
@@ -81,8 +93,7 @@ class Bottleneck(nn.Module):
         identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
         out = conv_bn(x, self.conv1, self.bn1, relu=True)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
-        out = conv_bn(out, self.conv3, self.bn3)
-        return F.relu_(out + identity)
+        return conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity)
 
 
 _DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
@@ -182,9 +193,11 @@ class Joiner(nn.Sequential):
         super().__init__(backbone, position_embedding)
 
     @assert_and_export_onnx()
-    def forward(self, frames, **kwargs):
+    def forward(self, frames, skip_pos_levels=(), **kwargs):
+        """``skip_pos_levels``: indices of returned stages whose positional encoding the caller will not read (``None`` is
+        returned in their place; the stride-4 map of Deformable-DETR costs as much as all the others together)."""
         out, pos = [], []
-        for _, x in self[0](frames, **kwargs).items():
+        for i, (_, x) in enumerate(self[0](frames, **kwargs).items()):
             out.append(x)
-            pos.append(self[1](x).to(x[0].dtype))
+            pos.append(None if i in skip_pos_levels else self[1](x).to(x[0].dtype))
         return out, pos

@@ -1,0 +1,214 @@
+// Streaming epilogues of the layers either side of the attention op, each one pass over HBM:
+//   alo_add_layernorm   out = LayerNorm(x + residual) * gamma + beta   [, out_pos = out + pos]
+//   alo_bias_act        y   = act(x + bias[c] [+ residual])            channels-last rows, in place allowed
+// Stock PyTorch runs these as 2-3 separate elementwise / normalisation kernels (and its LayerNorm kernel reaches a fifth of
+// the HBM rate on (177784, 256) bf16 rows); here one wave owns one row of the normalisation, the row lives in registers,
+// both reductions are wave-level DPP/shuffle reductions, and every byte is read and written once.
+#include "common.hpp"
+
+namespace alo {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxChunks = 4;  // C <= 64 lanes * 4 elements * 4 chunks = 1024
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    const u32x2 x = *reinterpret_cast<const u32x2*>(p);
+    v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xffff0000u);
+    v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    u32x2 o;
+    o.x = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<u32x2*>(p) = o;
+}
+
+// One wave per row; lane i holds elements [256*k + 4*i, +4) of the row for k < CHUNKS (coalesced 8-/16-byte accesses).
+template <typename T, int CHUNKS, bool HAS_RES, bool HAS_POS>
+__global__ void __launch_bounds__(kThreads)
+add_layernorm_kernel(const T* x, const T* res, const T* __restrict__ gamma, const T* __restrict__ beta, T* out,
+                     const T* pos, T* out_pos, long rows, int C, float eps) {  // out may alias x / res: no restrict there
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (kThreads / 64);
+    float g[CHUNKS][4], b[CHUNKS][4];
+#pragma unroll
+    for (int k = 0; k < CHUNKS; ++k) {
+        const int c = 256 * k + 4 * lane;
+        if (c < C) { load4(gamma + c, g[k]); load4(beta + c, b[k]); }
+    }
+    const float inv_c = 1.0f / (float)C;
+    for (long r = wave; r < rows; r += nwaves) {
+        const long base = r * C;
+        float v[CHUNKS][4];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < CHUNKS; ++k) {
+            const int c = 256 * k + 4 * lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[k][i] = 0.f;
+            if (c < C) {
+                load4(x + base + c, v[k]);
+                if constexpr (HAS_RES) {
+                    float t[4];
+                    load4(res + base + c, t);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[k][i] += t[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s += v[k][i];
+            }
+        }
+        const float mean = wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CHUNKS; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float d = v[k][i] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+#pragma unroll
+        for (int k = 0; k < CHUNKS; ++k) {
+            const int c = 256 * k + 4 * lane;
+            if (c < C) {
+                float y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = (v[k][i] - mean) * rstd * g[k][i] + b[k][i];
+                store4(out + base + c, y);
+                if constexpr (HAS_POS) {
+                    float p[4];
+                    load4(pos + base + c, p);
+                    // the sum is taken on the value the caller will see in `out` (rounded to T), as `out + pos` would be
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) y[i] = bf16_to_f32(f32_to_bf16(y[i]));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] += p[i];
+                    store4(out_pos + base + c, y);
+                }
+            }
+        }
+    }
+}
+
+// y[r, c] = act(x[r, c] + bias[c] (+ residual[r, c])), 4 elements per thread, rows*C % 4 == 0 and C % 4 == 0.
+template <typename T, bool HAS_RES, bool RELU>
+__global__ void __launch_bounds__(kThreads)
+bias_act_kernel(const T* x, const T* __restrict__ bias, const T* res, T* y,  // y may alias x
+                long n4, int C) {
+    const long stride = (long)gridDim.x * kThreads;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const long e = i * 4;
+        const int c = (int)(e % C);
+        float v[4], bb[4];
+        load4(x + e, v);
+        load4(bias + c, bb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += bb[k];
+        if constexpr (HAS_RES) {
+            float t[4];
+            load4(res + e, t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += t[k];
+        }
+        if constexpr (RELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        store4(y + e, v);
+    }
+}
+
+template <typename K>
+int launch(K kernel, unsigned blocks, hipStream_t stream, const char* what, void** args) {
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(blocks), dim3(kThreads), args, 0, stream);
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return check_launch(what);
+}
+
+template <typename T>
+int add_layernorm_t(const void* x, const void* res, const void* gamma, const void* beta, void* out, const void* pos,
+                    void* out_pos, long rows, int C, float eps, hipStream_t stream) {
+    const int chunks = (C + 255) / 256;
+    long blocks = (rows + 3) / 4;
+    if (blocks > 256L * 32) blocks = 256L * 32;
+    void* args[] = {&x, &res, &gamma, &beta, &out, &pos, &out_pos, &rows, &C, &eps};
+    const char* what = "alo_add_layernorm";
+#define ALO_LN_CASE(CH)                                                                                            \
+    if (chunks == CH) {                                                                                            \
+        if (res && pos) return launch(add_layernorm_kernel<T, CH, true, true>, (unsigned)blocks, stream, what, args);   \
+        if (res) return launch(add_layernorm_kernel<T, CH, true, false>, (unsigned)blocks, stream, what, args);         \
+        if (pos) return launch(add_layernorm_kernel<T, CH, false, true>, (unsigned)blocks, stream, what, args);         \
+        return launch(add_layernorm_kernel<T, CH, false, false>, (unsigned)blocks, stream, what, args);                 \
+    }
+    ALO_LN_CASE(1) ALO_LN_CASE(2) ALO_LN_CASE(3) ALO_LN_CASE(4)
+#undef ALO_LN_CASE
+    return fail(ALO_ERR_UNSUPPORTED, "alo_add_layernorm: C = %d is above %d", C, 256 * kMaxChunks);
+}
+
+template <typename T>
+int bias_act_t(const void* x, const void* bias, const void* res, void* y, long rows, int C, int relu, hipStream_t stream) {
+    long n4 = rows * C / 4;
+    long blocks = (n4 + kThreads - 1) / kThreads;
+    if (blocks > 256L * 64) blocks = 256L * 64;
+    void* args[] = {&x, &bias, &res, &y, &n4, &C};
+    const char* what = "alo_bias_act";
+    if (res) {
+        if (relu) return launch(bias_act_kernel<T, true, true>, (unsigned)blocks, stream, what, args);
+        return launch(bias_act_kernel<T, true, false>, (unsigned)blocks, stream, what, args);
+    }
+    if (relu) return launch(bias_act_kernel<T, false, true>, (unsigned)blocks, stream, what, args);
+    return launch(bias_act_kernel<T, false, false>, (unsigned)blocks, stream, what, args);
+}
+
+}  // namespace
+}  // namespace alo
+
+using namespace alo;
+
+extern "C" int alo_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta, void* out,
+                                 const void* pos, void* out_pos, long rows, int C, float eps, int dtype, void* stream) {
+    ALO_REQUIRE(x && gamma && beta && out, ALO_ERR_INVALID_ARGUMENT, "alo_add_layernorm: null pointer argument");
+    ALO_REQUIRE((pos == nullptr) == (out_pos == nullptr), ALO_ERR_INVALID_ARGUMENT,
+                "alo_add_layernorm: pos and out_pos go together");
+    ALO_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_add_layernorm: rows must be positive and C a positive multiple of 4 (rows=%ld C=%d)", rows, C);
+    const uintptr_t all = (uintptr_t)x | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out |
+                          (uintptr_t)pos | (uintptr_t)out_pos;
+    ALO_REQUIRE((all & 15) == 0, ALO_ERR_INVALID_ARGUMENT, "alo_add_layernorm: pointers must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ALO_F32) return add_layernorm_t<float>(x, residual, gamma, beta, out, pos, out_pos, rows, C, eps, s);
+    if (dtype == ALO_BF16) return add_layernorm_t<bf16_t>(x, residual, gamma, beta, out, pos, out_pos, rows, C, eps, s);
+    return fail(ALO_ERR_UNSUPPORTED, "alo_add_layernorm: dtype %d (F32 and BF16 are supported)", dtype);
+}
+
+extern "C" int alo_bias_act(const void* x, const void* bias, const void* residual, void* y, long rows, int C, int relu,
+                            int dtype, void* stream) {
+    ALO_REQUIRE(x && bias && y, ALO_ERR_INVALID_ARGUMENT, "alo_bias_act: null pointer argument");
+    ALO_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_bias_act: rows must be positive and C a positive multiple of 4 (rows=%ld C=%d)", rows, C);
+    const uintptr_t all = (uintptr_t)x | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)y;
+    ALO_REQUIRE((all & 15) == 0, ALO_ERR_INVALID_ARGUMENT, "alo_bias_act: pointers must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ALO_F32) return bias_act_t<float>(x, bias, residual, y, rows, C, relu, s);
+    if (dtype == ALO_BF16) return bias_act_t<bf16_t>(x, bias, residual, y, rows, C, relu, s);
+    return fail(ALO_ERR_UNSUPPORTED, "alo_bias_act: dtype %d (F32 and BF16 are supported)", dtype);
+}

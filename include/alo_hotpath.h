@@ -162,6 +162,27 @@ int alo_corr_build(const float* fmap1, const float* fmap2, float* const* levels,
 int alo_corr_lookup(const float* const* levels, const float* coords, float* out,
                     int B, int H, int W, int radius, int num_levels, void* stream);
 
+/*
+ * ---- Extensions: one-pass epilogues of the layers that call the attention op -------------------------------------------
+ * The reference evaluates these as separate PyTorch ops; they have no counterpart in its native code.  Both read and
+ * write every byte once; all pointers 16-byte aligned; dtype ALO_F32 or ALO_BF16 (arithmetic in fp32 either way).
+ *
+ * alo_add_layernorm: out = LayerNorm_C(x + residual) * gamma + beta, and optionally out_pos = out + pos
+ *   replaces  `src = self.norm1(src + self.dropout1(src2))` (+ the next layer's `with_pos_embed(src, pos)`) at inference
+ *             alonet/deformable_detr/deformable_transformer.py:311-352,417-487
+ *   x, residual (nullable), out, pos / out_pos (both or neither)   (rows, C) contiguous;  gamma, beta (C,)
+ *   C % 4 == 0, C <= 1024.  `out` may alias `x` or `residual`.  Biased variance, eps inside the square root (torch.nn.LayerNorm).
+ *
+ * alo_bias_act: y = act(x + bias[c] [+ residual]),  act = ReLU when relu != 0, identity otherwise
+ *   replaces  FrozenBatchNorm2d (folded into the convolution weights + this bias) -> [+ identity] -> ReLU of the ResNet
+ *             bottleneck, alonet/detr/backbone.py:19-47 + torchvision Bottleneck.forward, on channels-last activations
+ *   x, residual (nullable), y   (rows, C) contiguous = NHWC flattened;  bias (C,);  C % 4 == 0.  `y` may alias `x`.
+ */
+int alo_add_layernorm(const void* x, const void* residual, const void* gamma, const void* beta, void* out,
+                      const void* pos, void* out_pos, long rows, int C, float eps, int dtype, void* stream);
+int alo_bias_act(const void* x, const void* bias, const void* residual, void* y, long rows, int C, int relu,
+                 int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

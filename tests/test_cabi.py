@@ -20,7 +20,7 @@ def declared_functions():
 def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted(
         ["alo_abi_version", "alo_last_error", "alo_msda_forward", "alo_msda_forward_fused", "alo_msda_backward", "alo_corr_level_shape",
-         "alo_corr_build_workspace_bytes", "alo_corr_build", "alo_corr_lookup"]
+         "alo_corr_build_workspace_bytes", "alo_corr_build", "alo_corr_lookup", "alo_add_layernorm", "alo_bias_act"]
     )
 
 
@@ -57,6 +57,12 @@ def test_argument_errors_are_reported_before_any_launch():
     rc = lib.alo_msda_forward(one, one, one, one, one, one, 1, 1, 1, 0, 1, 1, 1, 0, 0, None)
     assert rc == 1 and b"positive" in lib.alo_last_error()
     rc = lib.alo_msda_forward(one, one, one, one, one, one, 1, 1, 1, 1, 1, 1, 1, 2, 2, None)
+    assert rc == 2 and b"dtype" in lib.alo_last_error()
+    rc = lib.alo_add_layernorm(one, None, one, one, one, one, None, 4, 256, 1e-5, 0, None)
+    assert rc == 1 and b"go together" in lib.alo_last_error()
+    rc = lib.alo_add_layernorm(one, None, one, one, one, None, None, 4, 258, 1e-5, 0, None)
+    assert rc == 1 and b"multiple of 4" in lib.alo_last_error()
+    rc = lib.alo_bias_act(one, one, None, one, 4, 64, 1, 1, None)
     assert rc == 2 and b"dtype" in lib.alo_last_error()
     rc = lib.alo_msda_forward(one, one, one, one, one, one, 1, 1, 1, 1, 33, 1, 1, 0, 0, None)
     assert rc == 2 and b"levels" in lib.alo_last_error()

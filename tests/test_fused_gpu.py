@@ -1,0 +1,93 @@
+"""One-pass epilogues (alo_add_layernorm, alo_bias_act) against the stock PyTorch ops they replace.  GPU only."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import alo_hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("rows,C", [(1, 256), (7, 256), (300 * 8, 256), (22223, 256), (33, 64), (5, 768), (4, 1024), (9, 260)])
+@pytest.mark.parametrize("with_res,with_pos", [(True, False), (True, True), (False, False), (False, True)])
+def test_add_layernorm_fp32(rows, C, with_res, with_pos):
+    g = torch.Generator(device=DEV).manual_seed(rows * 131 + C)
+    x = torch.randn(rows, C, device=DEV, generator=g) * 3 + 0.5
+    res = torch.randn(rows, C, device=DEV, generator=g) if with_res else None
+    pos = torch.randn(rows, C, device=DEV, generator=g) if with_pos else None
+    w, b = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
+    ref = F.layer_norm((x + res if with_res else x).double(), (C,), w.double(), b.double(), 1e-5)
+    got = alo_hip.add_layernorm(x, res, w, b, 1e-5, pos=pos)
+    out = got[0] if with_pos else got
+    assert (out.double() - ref).abs().max().item() <= 2e-5
+    if with_pos:
+        assert torch.equal(got[1], out + pos)
+
+
+def test_add_layernorm_bf16_tracks_fp32_and_allows_aliasing():
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(8, 1000, 256, device=DEV, generator=g).bfloat16()
+    res = torch.randn(8, 1000, 256, device=DEV, generator=g).bfloat16()
+    pos = torch.randn(8, 1000, 256, device=DEV, generator=g).bfloat16()
+    w = (torch.rand(256, device=DEV, generator=g) + 0.5).bfloat16()
+    b = torch.randn(256, device=DEV, generator=g).bfloat16()
+    ref = F.layer_norm(x.float() + res.float(), (256,), w.float(), b.float(), 1e-5)
+    out, out_pos = alo_hip.add_layernorm(x, res, w, b, 1e-5, pos=pos)
+    assert out.dtype == torch.bfloat16 and out.shape == x.shape
+    # fp32 arithmetic, one rounding at the end: within half a bf16 ulp of the fp32 result
+    assert ((out.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 1e-6).all()
+    assert torch.equal(out_pos, out + pos)  # computed from the rounded `out`, exactly like the unfused `out + pos`
+    stock = F.layer_norm(x + res, (256,), w, b, 1e-5)
+    assert (out.float() - stock.float()).abs().max().item() <= 0.0625
+    # `out` aliasing `x` through the raw ABI (each row is read completely before it is written)
+    x2 = x.clone()
+    rc = alo_hip.lib().alo_add_layernorm(alo_hip._ptr(x2), alo_hip._ptr(res), alo_hip._ptr(w), alo_hip._ptr(b),
+                                         alo_hip._ptr(x2), None, None, x.numel() // 256, 256, 1e-5, alo_hip.ALO_BF16,
+                                         alo_hip._stream(x.device))
+    assert rc == 0 and torch.equal(x2, out)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False), (True, False)])
+def test_bias_act_channels_last(dtype, with_res, relu):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(3, 64, 25, 42, device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(3, 64, 25, 42, device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last) if with_res else None
+    bias = torch.randn(64, device=DEV, generator=g).to(dtype)
+    ref = x.float() + bias.float().view(1, -1, 1, 1) + (res.float() if with_res else 0)
+    ref = (ref.relu() if relu else ref).to(dtype)
+    y = alo_hip.bias_act_(x.clone(memory_format=torch.preserve_format), bias, res, relu)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y, ref)  # one rounding of the exact fp32 sum
+
+
+def test_bias_act_rejects_nchw_and_fusable_gates_autograd():
+    x = torch.randn(2, 8, 4, 4, device=DEV)
+    with pytest.raises(RuntimeError, match="channels_last"):
+        alo_hip.bias_act_(x, torch.zeros(8, device=DEV))
+    p = torch.randn(4, 256, device=DEV, requires_grad=True)
+    assert not alo_hip.fusable(p)
+    with torch.no_grad():
+        assert alo_hip.fusable(p)
+    assert not alo_hip.fusable(torch.randn(4, 256))  # CPU
+
+
+def test_resnet_bottleneck_fused_vs_stock():
+    """The fused conv epilogue is what the backbone runs at inference: compare with the autograd (stock-op) path."""
+    from alonet.detr.backbone import ResNetBody
+
+    torch.manual_seed(0)
+    body = ResNetBody("resnet50", return_layers={"layer1": "0", "layer2": "1", "layer3": "2", "layer4": "3"}).to(DEV).eval()
+    for m in body.modules():  # non-trivial frozen statistics
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 2.0); m.running_mean.normal_(0, 0.2); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    x = torch.randn(2, 3, 96, 128, device=DEV)
+    with torch.no_grad():
+        fused = body(x)
+    for p in body.parameters():
+        p.requires_grad_(True)
+    stock = body(x.requires_grad_(True))  # grad mode with trainable weights: stock ops
+    for k in fused:
+        scale = stock[k].abs().max().item()
+        assert (fused[k] - stock[k]).abs().max().item() <= 2e-4 * scale, k

@@ -173,6 +173,35 @@ def bench_corr_lookup(B, reps, H=90, W=160, C=256):
     return dict(kernel="corr_lookup", B=B, ms=t * 1e3, alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
+def bench_epilogues(N, dtype, reps):
+    """alo_add_layernorm on the encoder's (N*S, 256) rows and alo_bias_act on the layer1 NHWC map, next to the stock ops."""
+    S = sum(h * w for h, w in DETR_SHAPES)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(N, S, 256, device=DEV, generator=g).to(dtype)
+    r = torch.randn(N, S, 256, device=DEV, generator=g).to(dtype)
+    pos = torch.randn(N, S, 256, device=DEV, generator=g).to(dtype)
+    w, b = torch.ones(256, device=DEV, dtype=dtype), torch.zeros(256, device=DEV, dtype=dtype)
+    e = x.element_size()
+    out = []
+    t = time_launches(lambda: alo_hip.add_layernorm(x, r, w, b, 1e-5), reps)
+    out.append({"kernel": "add_layernorm[encoder rows]", "dtype": str(dtype).split(".")[-1], "ms": t * 1e3,
+                "alg_bytes": 3 * x.numel() * e, "GBps": 3 * x.numel() * e / t / 1e9})
+    t = time_launches(lambda: alo_hip.add_layernorm(x, r, w, b, 1e-5, pos=pos), reps)
+    out.append({"kernel": "add_layernorm+pos[encoder rows]", "dtype": str(dtype).split(".")[-1], "ms": t * 1e3,
+                "alg_bytes": 5 * x.numel() * e, "GBps": 5 * x.numel() * e / t / 1e9})
+    t = time_launches(lambda: torch.nn.functional.layer_norm(x + r, (256,), w, b, 1e-5), reps)
+    out.append({"kernel": "stock add + layer_norm", "dtype": str(dtype).split(".")[-1], "ms": t * 1e3})
+    a = torch.randn(N, 256, 200, 334, device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    idn = torch.randn(N, 256, 200, 334, device=DEV, generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(256, device=DEV, generator=g).to(dtype)
+    t = time_launches(lambda: alo_hip.bias_act_(a, bias, idn, True), reps)
+    out.append({"kernel": "bias_act[+identity, relu; layer1 map]", "dtype": str(dtype).split(".")[-1], "ms": t * 1e3,
+                "alg_bytes": 3 * a.numel() * e, "GBps": 3 * a.numel() * e / t / 1e9})
+    t = time_launches(lambda: torch.relu_(a.add_(bias.view(1, -1, 1, 1)) + idn), reps)
+    out.append({"kernel": "stock bias add_ + add + relu_", "dtype": str(dtype).split(".")[-1], "ms": t * 1e3})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="msda_enc,msda_dec,msda_rand,msda_bwd,corr_build,corr_lookup")
@@ -200,6 +229,8 @@ def main():
             res = [bench_corr_build(a.B, max(3, a.reps // 4))]
         elif w == "corr_lookup":
             res = [bench_corr_lookup(a.B, a.reps)]
+        elif w == "epilogues":
+            res = [r for dt in dts for r in bench_epilogues(a.N, dt, a.reps)]
         for r in res:
             r.update(tags)
             print(json.dumps(r), flush=True)
