@@ -28,6 +28,15 @@ def _add_norm(norm, x, residual, pos=None):
     return alo_hip.add_layernorm(x, residual, norm.weight, norm.bias, norm.eps, pos=pos)
 
 
+def _ffn(linear1, activation, linear2, x):
+    """``linear2(act(linear1(x)))``; for ReLU the activation rides in the first GEMM's epilogue (hipBLASLt RELU_BIAS via
+    ``torch._addmm_activation``) instead of a separate pass over the (rows, d_ffn) intermediate."""
+    if activation is F.relu and linear1.bias is not None:
+        h = torch._addmm_activation(linear1.bias, x.reshape(-1, x.shape[-1]), linear1.weight.t(), use_gelu=False)
+        return linear2(h).view(*x.shape[:-1], -1)
+    return linear2(activation(linear1(x)))
+
+
 def _get_clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
 
@@ -72,7 +81,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         one HIP pass each, and the second one also emits the next layer's query.  -> (src', src' + pos | None)"""
         src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask, **kwargs)
         src = _add_norm(self.norm1, src2, src)
-        src2 = self.linear2(self.activation(self.linear1(src)))
+        src2 = _ffn(self.linear1, self.activation, self.linear2, src)
         if next_query and pos is not None:
             return _add_norm(self.norm2, src2, src, pos=pos)
         return _add_norm(self.norm2, src2, src), None
@@ -157,7 +166,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
             tgt2 = self.cross_attn(query, reference_points, src, src_spatial_shapes, level_start_index,
                                    src_padding_mask, **kwargs)
             tgt = _add_norm(self.norm1, tgt2, tgt)
-            return _add_norm(self.norm3, self.linear2(self.activation(self.linear1(tgt))), tgt)
+            return _add_norm(self.norm3, _ffn(self.linear1, self.activation, self.linear2, tgt), tgt)
         tgt = self.norm2(tgt + self.dropout2(tgt2))
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
                                level_start_index, src_padding_mask, **kwargs)
