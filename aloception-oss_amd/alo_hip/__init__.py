@@ -56,6 +56,10 @@ def _declare(lib):
     lib.alo_corr_build.argtypes = [vp, vp, c.POINTER(vp), vp, sz] + [ip] * 5 + [vp]
     lib.alo_corr_lookup.restype = ip
     lib.alo_corr_lookup.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
+    lib.alo_msda_forward_fused_hm.restype = ip
+    lib.alo_msda_forward_fused_hm.argtypes = [vp] * 7 + [ip] * 9 + [vp]
+    lib.alo_value_head_major.restype = ip
+    lib.alo_value_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
     lib.alo_add_layernorm.restype = ip
     lib.alo_add_layernorm.argtypes = [vp] * 7 + [c.c_long, ip, c.c_float, ip, vp]
     lib.alo_bias_act.restype = ip
@@ -253,6 +257,55 @@ def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offset
         _check(lib().alo_msda_forward_fused(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index),
                                             _ptr(sampling_offsets), _ptr(attn_logits), _ptr(reference_points), _ptr(out),
                                             N, S, M, D, L, Lq, P, ref_dim, vdt, _stream(value.device)))
+    return out
+
+
+def head_major_supported(value, L, P):
+    """The head-major fast path of the fused forward exists for the DETR-family shape only: bf16, L = P = 4, D in {8..32}."""
+    return (value.is_cuda and value.dtype == torch.bfloat16 and L == 4 and P == 4 and value.shape[-1] % 8 == 0
+            and value.shape[-1] <= 32)
+
+
+def value_head_major(value, padding_mask=None):
+    """(N, S, M, D) bf16 -> (N, M, S, D) with the rows of padded pixels zeroed: ``value.masked_fill(mask[..., None], 0)``
+    and the re-layout for ``msda_forward_fused_hm`` in one pass."""
+    _require_cuda_contiguous([("value", value)])
+    N, S, M, D = value.shape
+    if padding_mask is not None:
+        if padding_mask.dtype != torch.bool or tuple(padding_mask.shape) != (N, S) or not padding_mask.is_cuda:
+            raise RuntimeError("padding_mask must be a (N, S) bool CUDA tensor")
+        padding_mask = padding_mask.contiguous()
+    out = torch.empty((N, M, S, D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device), _timed(f"value_head_major/S={S}", 2 * value.element_size() * value.numel()):
+        _check(lib().alo_value_head_major(_ptr(value), None if padding_mask is None else _ptr(padding_mask), _ptr(out),
+                                          N, S, M, D, _DTYPE_CODE[value.dtype], _stream(value.device)))
+    return out
+
+
+def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points):
+    """``msda_forward_fused`` on a head-major value (N, M, S, D) (see ``value_head_major``): same result, bit for bit."""
+    if not value_hm.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    N, M, S, D = value_hm.shape
+    _, Lq, _, L, P, _ = sampling_offsets.shape
+    reference_points = reference_points.float().contiguous()
+    _require_cuda_contiguous([("value", value_hm), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                              ("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)])
+    if sampling_offsets.dtype != value_hm.dtype or attn_logits.dtype != value_hm.dtype:
+        raise RuntimeError("sampling_offsets and attn_logits must have the dtype of value")
+    if spatial_shapes.dtype != torch.int32 or level_start_index.dtype != torch.int32:
+        raise RuntimeError("spatial_shapes and level_start_index must be int32 tensors")
+    ref_dim = reference_points.shape[-1]
+    if tuple(reference_points.shape) != (N, Lq, L, ref_dim) or attn_logits.numel() != N * Lq * M * L * P:
+        raise RuntimeError("reference_points must be (N,Lq,L,2|4) and attn_logits (N,Lq,M,L*P)")
+    out = torch.empty((N, Lq, M * D), dtype=value_hm.dtype, device=value_hm.device)
+    e = value_hm.element_size()
+    nbytes = e * (N * S * M * D + N * Lq * M * D + N * Lq * M * L * P * 3) + 4 * reference_points.numel()
+    with torch.cuda.device(value_hm.device), _timed(f"msda_fwd_fused/Lq={Lq}", nbytes):
+        _check(lib().alo_msda_forward_fused_hm(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
+                                               _ptr(sampling_offsets), _ptr(attn_logits), _ptr(reference_points),
+                                               _ptr(out), N, S, M, D, L, Lq, P, ref_dim, _DTYPE_CODE[value_hm.dtype],
+                                               _stream(value_hm.device)))
     return out
 
 

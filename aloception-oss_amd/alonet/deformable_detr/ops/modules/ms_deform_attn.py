@@ -93,26 +93,35 @@ class MSDeformAttn(nn.Module):
         assert total == S
         M, L, P = self.n_heads, self.n_levels, self.n_points
 
-        value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            if torch.is_grad_enabled() and value.requires_grad:
-                value = value.masked_fill(input_padding_mask[..., None], float(0))
-            else:  # the projection's output is a fresh tensor: mask it in place, no clone
-                value.masked_fill_(input_padding_mask[..., None], float(0))
-        value = value.view(N, S, M, self.d_model // M)
-
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError(
                 "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1])
             )
-        low_precision = value.dtype in (torch.bfloat16, torch.float16)
-        geo = torch.float32 if low_precision else value.dtype
+        value = self.value_proj(input_flatten)
         offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
         logits = self.attention_weights(query).view(N, Lq, M, L * P)
-
         needs_grad = torch.is_grad_enabled() and any(
             t.requires_grad for t in (value, offsets, logits, reference_points))
-        if "is_tracing" not in kwargs and not needs_grad and self.fused_prologue:
+        fused = "is_tracing" not in kwargs and not needs_grad and self.fused_prologue
+
+        if fused and alo_hip.head_major_supported(value.view(N, S, M, self.d_model // M), L, P):
+            # inference, DETR-family shape: padding is zeroed while the projection's output is re-laid head-major (one pass
+            # instead of masked_fill), softmax + sampling-location arithmetic happen inside the kernel's descriptor stage
+            value = alo_hip.value_head_major(value.view(N, S, M, self.d_model // M), input_padding_mask)
+            output = alo_hip.msda_forward_fused_hm(value, input_spatial_shapes, input_level_start_index,
+                                                   offsets.contiguous(), logits.contiguous(), reference_points)
+            return self.output_proj(output)
+
+        if input_padding_mask is not None:
+            if needs_grad:
+                value = value.masked_fill(input_padding_mask[..., None], float(0))
+            else:  # the projection's output is a fresh tensor: mask it in place, no clone
+                value.masked_fill_(input_padding_mask[..., None], float(0))
+        value = value.view(N, S, M, self.d_model // M)
+        low_precision = value.dtype in (torch.bfloat16, torch.float16)
+        geo = torch.float32 if low_precision else value.dtype
+
+        if fused:
             # inference: softmax + sampling-location arithmetic happen inside the kernel's descriptor stage
             output = alo_hip.msda_forward_fused(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                                 offsets.contiguous(), logits.contiguous(), reference_points)

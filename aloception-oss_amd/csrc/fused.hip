@@ -137,6 +137,30 @@ bias_act_kernel(const T* x, const T* __restrict__ bias, const T* res, T* y,  // 
     }
 }
 
+// out[n, m, s, :] = mask[n, s] ? 0 : value[n, s, m, :]   (pixel-major -> head-major, padding zeroed on the way).
+// A workgroup moves 64 pixels: reads their (M*D)-element rows with 16-byte loads (fully coalesced), writes per head 64
+// consecutive D-element rows (64*D*2 bytes contiguous).  16 B = 8 bf16 per thread.
+__global__ void __launch_bounds__(kThreads)
+value_head_major_kernel(const bf16_t* __restrict__ value, const unsigned char* __restrict__ mask,
+                        bf16_t* __restrict__ out, int S, int M, int D) {
+    const int n = blockIdx.y;
+    const int s0 = blockIdx.x * 64;
+    const int vec_per_row = M * D / 8;            // 16-byte vectors per pixel row
+    const int vec_per_head = D / 8;
+    const int total = 64 * vec_per_row;
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+        // thread order follows the OUTPUT: (head, pixel, vector-in-head) so that stores are contiguous per head
+        const int m = i / (64 * vec_per_head);
+        const int rem = i - m * 64 * vec_per_head;
+        const int sp = rem / vec_per_head, v = rem - sp * vec_per_head;
+        const int s = s0 + sp;
+        if (s >= S) continue;
+        u32x4 x = *reinterpret_cast<const u32x4*>(value + ((size_t)n * S + s) * M * D + m * D + v * 8);
+        if (mask != nullptr && mask[(size_t)n * S + s]) x = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(out + (((size_t)n * M + m) * S + s) * D + v * 8) = x;
+    }
+}
+
 template <typename K>
 int launch(K kernel, unsigned blocks, hipStream_t stream, const char* what, void** args) {
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(blocks), dim3(kThreads), args, 0, stream);
@@ -211,4 +235,19 @@ extern "C" int alo_bias_act(const void* x, const void* bias, const void* residua
     if (dtype == ALO_F32) return bias_act_t<float>(x, bias, residual, y, rows, C, relu, s);
     if (dtype == ALO_BF16) return bias_act_t<bf16_t>(x, bias, residual, y, rows, C, relu, s);
     return fail(ALO_ERR_UNSUPPORTED, "alo_bias_act: dtype %d (F32 and BF16 are supported)", dtype);
+}
+
+extern "C" int alo_value_head_major(const void* value, const void* padding_mask, void* out, int N, int S, int M, int D,
+                                    int dtype, void* stream) {
+    ALO_REQUIRE(value && out, ALO_ERR_INVALID_ARGUMENT, "alo_value_head_major: null pointer argument");
+    ALO_REQUIRE(N > 0 && S > 0 && M > 0 && D > 0 && D % 8 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_value_head_major: dimensions must be positive and D a multiple of 8 (N=%d S=%d M=%d D=%d)", N, S, M, D);
+    ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_value_head_major: bf16 only (dtype %d)", dtype);
+    ALO_REQUIRE((((uintptr_t)value | (uintptr_t)out) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_value_head_major: pointers must be 16-byte aligned");
+    void* args[] = {&value, &padding_mask, &out, &S, &M, &D};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(value_head_major_kernel), dim3((S + 63) / 64, N),
+                                   dim3(kThreads), args, 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_value_head_major: %s", hipGetErrorString(e));
+    return check_launch("alo_value_head_major");
 }

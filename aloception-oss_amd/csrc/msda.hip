@@ -45,6 +45,7 @@ struct Dims {
     int pairs_per_batch;   // Lq * M
     int blocks_per_batch;  // workgroups per batch item
     int iters_per_block;   // runs of (256 / G) pairs handled by one workgroup
+    int runs_per_batch;    // wave kernel: runs of 16 pairs per batch item (head-major: ceil(Lq / 16) * M)
     unsigned nblocks;
     int ref_dim;           // fused prologue only: last dim of reference_points (2 or 4)
     int p_shift, m_shift;  // log2(P), log2(M) when they are powers of two, else -1 (integer division fallback)
@@ -58,7 +59,9 @@ struct Tap {
     int W;
     CT lh, lw;
 };
-template <typename CT>
+// MUL24: index arithmetic on the full-rate 24-bit integer multiplier (v_mul_lo_u32 is quarter rate); the caller
+// guarantees S < 2^23 and row_bytes < 2^23.
+template <typename CT, bool MUL24 = false>
 __device__ __forceinline__ Tap<CT> make_tap(CT loc_x, CT loc_y, int H, int W, int start) {
     Tap<CT> t;
     const CT h_im = loc_y * (CT)H - (CT)0.5;
@@ -74,7 +77,7 @@ __device__ __forceinline__ Tap<CT> make_tap(CT loc_x, CT loc_y, int H, int W, in
     t.ok[1] = t.valid && hl && wh;
     t.ok[2] = t.valid && hh && wl;
     t.ok[3] = t.valid && hh && wh;
-    t.base = start + h_low * W + w_low;
+    t.base = start + (MUL24 ? __mul24(h_low, W) : h_low * W) + w_low;
     t.W = W;
     return t;
 }
@@ -92,13 +95,15 @@ __device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, cons
 
 // Sampling point -> gather descriptor: 4 corner byte offsets (out-of-range for corners that are not read) and 4 corner
 // weights already multiplied by the attention weight.
-template <typename CT>
+template <typename CT, bool MUL24 = false>
 __device__ __forceinline__ FwdDesc<CT> make_desc(CT x, CT y, CT a, int H, int W, int start, unsigned row_bytes) {
     FwdDesc<CT> d;
-    const Tap<CT> t = make_tap<CT>(x, y, H, W, start);
+    const Tap<CT> t = make_tap<CT, MUL24>(x, y, H, W, start);
     const CT hh = (CT)1 - t.lh, hw = (CT)1 - t.lw;
     const CT w[4] = {hh * hw, hh * t.lw, t.lh * hw, t.lh * t.lw};
-    const unsigned o0 = (unsigned)t.base * row_bytes, dy = (unsigned)t.W * row_bytes;
+    // t.base may be negative (h_low = -1 with the lower corners still inside): signed multiply, wraps like the 32-bit one
+    const unsigned o0 = MUL24 ? (unsigned)__mul24(t.base, (int)row_bytes) : (unsigned)t.base * row_bytes;
+    const unsigned dy = MUL24 ? (unsigned)__mul24(t.W, (int)row_bytes) : (unsigned)t.W * row_bytes;
     const unsigned po[4] = {o0, o0 + row_bytes, o0 + dy, o0 + dy + row_bytes};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -413,7 +418,11 @@ __device__ __forceinline__ float quad_sum(float v) {
 // stage 1 overlaps the gathers of the others.  L = P = 4 and D <= 32 (the DETR-family configuration) only.
 constexpr int kWaveLds = 16 * kMfmaPairStride;
 
-template <int SB, bool FUSED>
+// HM = true: `value` is HEAD-major, (N, M, S, D) — what alo_value_head_major writes — and a wave serves 16 CONSECUTIVE
+// QUERIES of ONE head instead of 2 queries x 8 heads.  A head's row is D*2 = 64 bytes, half an L1 line: in the
+// pixel-major layout every request of a wave instruction lands in its own line (16 line reads), in the head-major one
+// neighbouring queries read neighbouring pixels of the same head, i.e. the same or the adjacent line.
+template <int SB, bool FUSED, bool HM>
 __global__ void __launch_bounds__(64)
 msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __restrict__ shapes,
                           const int32_t* __restrict__ lstart, const void* __restrict__ loc_,
@@ -428,10 +437,10 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
     const int pl = threadIdx.x >> 2, lane = threadIdx.x & 3;  // pair slot in the wave, lane in the quad (= level in stage 1)
 
     const unsigned row_elems = (unsigned)dm.M * dm.D;
-    const unsigned row_bytes = row_elems * 2u;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(value + (size_t)b * dm.S * row_elems, (unsigned)dm.S * row_bytes);
+    const unsigned row_bytes = HM ? (unsigned)dm.D * 2u : row_elems * 2u;  // bytes between neighbouring pixels of a head
     const long batch_pair0 = (long)b * dm.pairs_per_batch;
     const int last_pair = dm.pairs_per_batch - 1;
+    const int Lq = dm.pairs_per_batch / dm.M;
 
     const int Hl = shapes[2 * lane], Wl = shapes[2 * lane + 1], start = lstart[lane];
     const float inv_w = 1.0f / (float)Wl, inv_h = 1.0f / (float)Hl;
@@ -439,11 +448,25 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
     const int c0 = lane * 8;  // lanes with c0 >= D only feed the A rows
 
     for (int it = 0; it < dm.iters_per_block; ++it) {
-        const int pair0 = (chunk * dm.iters_per_block + it) * 16;
-        if (pair0 >= dm.pairs_per_batch) break;  // uniform
-        const int pair = pair0 + pl;
-        const bool dead = pair > last_pair;
-        const long g0 = (batch_pair0 + min(pair, last_pair)) * 16 + 4 * lane;
+        const int run = chunk * dm.iters_per_block + it;
+        if (run >= dm.runs_per_batch) break;  // uniform
+        int pair, m;
+        bool dead;
+        if constexpr (HM) {
+            m = dm.m_shift >= 0 ? (run & (dm.M - 1)) : run % dm.M;
+            const int q = (dm.m_shift >= 0 ? (run >> dm.m_shift) : run / dm.M) * 16 + pl;
+            dead = q >= Lq;
+            pair = min(q, Lq - 1) * dm.M + m;
+        } else {
+            pair = run * 16 + pl;
+            dead = pair > last_pair;
+            pair = min(pair, last_pair);
+            m = dm.m_shift >= 0 ? (pair & (dm.M - 1)) : pair % dm.M;
+        }
+        const __amdgpu_buffer_rsrc_t rsrc =
+            HM ? make_rsrc(value + ((size_t)b * dm.M + m) * dm.S * dm.D, (unsigned)dm.S * row_bytes)
+               : make_rsrc(value + (size_t)b * dm.S * row_elems, (unsigned)dm.S * row_bytes);
+        const long g0 = (batch_pair0 + pair) * 16 + 4 * lane;
 
         // ---- stage 1: the 4 points of level `lane` of this quad's pair ------------------------------------------------
         {
@@ -451,8 +474,8 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
             if constexpr (FUSED) {
                 const u32x4 lr = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(loc_) + 2 * g0);
                 const u32x2 ar = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(attn_) + g0);
-                const int q = dm.m_shift >= 0 ? (min(pair, last_pair) >> dm.m_shift) : min(pair, last_pair) / dm.M;
-                const float* rp = ref + (((long)b * (dm.pairs_per_batch / dm.M) + q) * dm.L + lane) * dm.ref_dim;
+                const int q = dm.m_shift >= 0 ? (pair >> dm.m_shift) : pair / dm.M;
+                const float* rp = ref + (((long)b * Lq + q) * dm.L + lane) * dm.ref_dim;
                 float r0, r1, r2 = 0.f, r3 = 0.f;
                 if (dm.ref_dim == 2) {
                     const float2 rv = *reinterpret_cast<const float2*>(rp);
@@ -497,13 +520,15 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const FwdDesc<float> fd = make_desc<float>(x[i], y[i], a[i], Hl, Wl, start, row_bytes);
+                // a pair past the end samples far outside the map: every corner becomes "not read, weight 0" by itself
+                const FwdDesc<float> fd = make_desc<float, true>(dead ? -8.0f : x[i], dead ? -8.0f : y[i], a[i], Hl, Wl,
+                                                                 start, row_bytes);
                 MfmaDesc d;
                 unsigned wb[4], r1b[4], r2b[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    d.off[k] = dead ? kOutOfRange : fd.off[k];
-                    const float w = dead ? 0.0f : fd.w[k];
+                    d.off[k] = fd.off[k];
+                    const float w = fd.w[k];
                     wb[k] = __float_as_uint(w);
                     const float r1 = w - __uint_as_float(wb[k] & 0xffff0000u);    // exact: the low 16 mantissa bits
                     r1b[k] = __float_as_uint(r1);
@@ -530,8 +555,7 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 
         // ---- stage 2: gather + MFMA accumulate -----------------------------------------------------------------------
         {
-            const int m = dm.m_shift >= 0 ? (pair & (dm.M - 1)) : pair % dm.M;
-            const unsigned coff = (unsigned)(m * dm.D + c0) * 2u;
+            const unsigned coff = HM ? (unsigned)c0 * 2u : (unsigned)(m * dm.D + c0) * 2u;
             f32x4 acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -764,6 +788,7 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G, long tar
     if (ipb > 8) ipb = 8;
     if (tuning().iters > 0) ipb = tuning().iters;
     d.iters_per_block = (int)ipb;
+    d.runs_per_batch = (int)iters_total;
     d.blocks_per_batch = (int)((iters_total + ipb - 1) / ipb);
     d.nblocks = (unsigned)(d.blocks_per_batch * N);
     return d;
@@ -833,7 +858,7 @@ using namespace alo;
 namespace {
 int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
                  const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
-                 int P, int value_dtype, int loc_dtype, void* stream_) {
+                 int P, int value_dtype, int loc_dtype, void* stream_, bool head_major = false) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
                           loc_dtype, &elem))
@@ -848,18 +873,32 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
     const int sb = tuning().fwd_batch;
     void* args[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm};
     const bool in_aligned = (((uintptr_t)loc | (uintptr_t)attn | (uintptr_t)(fused ? ref : nullptr)) & 15) == 0;
-    if (value_dtype == ALO_BF16 && aligned && in_aligned && L == 4 && P == 4 && D % 8 == 0 && D <= 32 && tuning().mfma &&
-        (size_t)M * D * 2 < (1u << 24)) {
+    const bool wave_kernel = value_dtype == ALO_BF16 && aligned && in_aligned && L == 4 && P == 4 && D % 8 == 0 &&
+                             D <= 32 && (size_t)M * D * 2 < (1u << 23) && S < (1 << 23);
+    if (head_major) {
+        ALO_REQUIRE(wave_kernel && fused, ALO_ERR_UNSUPPORTED,
+                    "alo_msda_forward_fused_hm: needs bf16, L = P = 4, D %% 8 == 0, D <= 32 and 16-byte aligned pointers");
+        dm = make_dims(N, S, M, D, L, Lq, P, 16, 16384);
+        dm.ref_dim = ref_dim;
+        // runs are (16 consecutive queries, head) tiles; heads of one query block stay on neighbouring waves
+        const long runs = (long)((Lq + 15) / 16) * M;
+        dm.runs_per_batch = (int)runs;
+        dm.blocks_per_batch = (int)((runs + dm.iters_per_block - 1) / dm.iters_per_block);
+        dm.nblocks = (unsigned)(dm.blocks_per_batch * N);
+        if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, true, true>, dm, kWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
+        return launch(msda_fwd_bf16_mfma_kernel<4, true, true>, dm, kWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
+    }
+    if (wave_kernel && tuning().mfma) {
         // bf16 rows go to the matrix pipe untouched, one wave per 16 pairs (see msda_fwd_bf16_mfma_kernel)
         dm = make_dims(N, S, M, D, L, Lq, P, 16, 16384);
         dm.ref_dim = ref_dim;
         const char* what = fused ? "alo_msda_forward_fused" : "alo_msda_forward";
         if (fused) {
-            if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, true>, dm, kWaveLds, stream, what, args, 64);
-            return launch(msda_fwd_bf16_mfma_kernel<4, true>, dm, kWaveLds, stream, what, args, 64);
+            if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, true, false>, dm, kWaveLds, stream, what, args, 64);
+            return launch(msda_fwd_bf16_mfma_kernel<4, true, false>, dm, kWaveLds, stream, what, args, 64);
         }
-        if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, false>, dm, kWaveLds, stream, what, args, 64);
-        return launch(msda_fwd_bf16_mfma_kernel<4, false>, dm, kWaveLds, stream, what, args, 64);
+        if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, false, false>, dm, kWaveLds, stream, what, args, 64);
+        return launch(msda_fwd_bf16_mfma_kernel<4, false, false>, dm, kWaveLds, stream, what, args, 64);
     }
     if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_FWD_CASE, double, double, double, 2) }
@@ -886,6 +925,17 @@ extern "C" int alo_msda_forward_fused(const void* value, const int32_t* spatial_
     const int loc_dtype = value_dtype == ALO_F64 ? ALO_F64 : ALO_F32;
     return forward_impl(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
                         ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, stream_);
+}
+
+extern "C" int alo_msda_forward_fused_hm(const void* value_hm, const int32_t* spatial_shapes,
+                                         const int32_t* level_start_index, const void* sampling_offsets,
+                                         const void* attn_logits, const void* reference_points, void* out, int N, int S,
+                                         int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype, void* stream_) {
+    ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm: reference_points is null");
+    ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_forward_fused_hm: last dim of reference_points must be 2 or 4, got %d", ref_dim);
+    return forward_impl(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
+                        ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true);
 }
 
 extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,

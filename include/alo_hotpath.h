@@ -103,6 +103,25 @@ int alo_msda_forward_fused(const void* value, const int32_t* spatial_shapes, con
                            int value_dtype, void* stream);
 
 /*
+ * Head-major variant of alo_msda_forward_fused (extension).  `value_hm` is (N, M, S, D): what alo_value_head_major
+ * writes from the boundary layout.  Everything else as above; results are bit-identical to alo_msda_forward_fused on
+ * the same data.  bf16, L = P = 4, D % 8 == 0, D <= 32 only (ALO_ERR_UNSUPPORTED otherwise).  Why it exists: a head's
+ * row is 64 bytes = half an L1 line; head-major rows of neighbouring pixels share lines, pixel-major ones never do.
+ */
+int alo_msda_forward_fused_hm(const void* value_hm, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                              const void* sampling_offsets, const void* attn_logits, const void* reference_points,
+                              void* out, int N, int S, int M, int D, int L, int Lq, int P, int ref_dim,
+                              int value_dtype, void* stream);
+
+/*
+ * value (N, S, M, D) -> out (N, M, S, D), rows of padded pixels zeroed (padding_mask (N, S) uint8/bool, nullable):
+ * MSDeformAttn's `value.masked_fill(input_padding_mask[..., None], 0)` (ms_deform_attn.py:112-113) and the re-layout
+ * in one pass.  bf16, D % 8 == 0.
+ */
+int alo_value_head_major(const void* value, const void* padding_mask, void* out, int N, int S, int M, int D,
+                         int dtype, void* stream);
+
+/*
  * Multi-scale deformable attention, backward (gradients of the forward above w.r.t. value, sampling_loc, attn_weight).
  *
  *   grad_out            (N, Lq, M*D)        value_dtype

@@ -303,3 +303,40 @@ def test_module_uses_fused_prologue_in_inference_and_unfused_under_grad(golden):
     np.testing.assert_allclose(plain.detach().cpu().numpy(), g["out4"], rtol=1e-10, atol=1e-11)
     plain.sum().backward()
     assert m.sampling_offsets.weight.grad is not None and torch.isfinite(m.value_proj.weight.grad).all()
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("N,M,D,Lq", [(2, 8, 32, 77), (1, 8, 32, 16), (3, 4, 16, 301), (1, 2, 8, 5)])
+def test_head_major_path_is_bit_identical_and_masks_padding(N, M, D, Lq, ref_dim):
+    """alo_value_head_major + alo_msda_forward_fused_hm == masked_fill + alo_msda_forward_fused, bit for bit."""
+    shapes_l = [(16, 21), (8, 11), (4, 6), (2, 3)]
+    gen = torch.Generator(device=DEV).manual_seed(7 + D + Lq)
+    shapes = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
+    start = dev(level_start(shapes_l))
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = torch.randn(N, S, M, D, generator=gen, device=DEV).bfloat16()
+    offsets = (torch.randn(N, Lq, M, 4, 4, 2, generator=gen, device=DEV) * 2.5).bfloat16()
+    logits = (torch.randn(N, Lq, M, 16, generator=gen, device=DEV) * 2.0).bfloat16()
+    ref = torch.rand(N, Lq, 4, ref_dim, generator=gen, device=DEV)
+    if ref_dim == 4:
+        ref[..., 2:] *= 0.4
+    mask = torch.rand(N, S, generator=gen, device=DEV) < 0.3
+    assert alo_hip.head_major_supported(value, 4, 4)
+    vhm = alo_hip.value_head_major(value, mask)
+    assert vhm.shape == (N, M, S, D)
+    assert torch.equal(vhm, value.masked_fill(mask[..., None, None], 0).permute(0, 2, 1, 3))
+    assert torch.equal(alo_hip.value_head_major(value, None), value.permute(0, 2, 1, 3))
+    got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    want = alo_hip.msda_forward_fused(value.masked_fill(mask[..., None, None], 0), shapes, start, offsets, logits, ref)
+    assert torch.equal(got, want)
+
+
+def test_head_major_rejects_other_shapes():
+    shapes = torch.tensor([(4, 4), (2, 2)], dtype=torch.int32, device=DEV)
+    start = dev(level_start([(4, 4), (2, 2)]))
+    v = torch.randn(1, 2, 20, 32, device=DEV).bfloat16()  # (N, M, S, D) but L = 2
+    off = torch.zeros(1, 3, 2, 2, 4, 2, device=DEV).bfloat16()
+    lg = torch.zeros(1, 3, 2, 8, device=DEV).bfloat16()
+    with pytest.raises(RuntimeError, match="L = P = 4"):
+        alo_hip.msda_forward_fused_hm(v, shapes, start, off, lg, torch.rand(1, 3, 2, 2, device=DEV))
+    assert not alo_hip.head_major_supported(torch.zeros(1, 4, 2, 32, device=DEV), 4, 4)  # fp32

@@ -123,6 +123,21 @@ def bench_msda_fused(N, dtype, reps):
                 alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
+def bench_msda_fused_hm(N, reps):
+    """Head-major path: the re-layout (+ padding mask) pass and the gather, separately."""
+    value, shapes, start, offsets, logits, ref = fused_inputs(N, torch.bfloat16)
+    S = value.shape[1]
+    mask = torch.zeros(N, S, dtype=torch.bool, device=DEV)
+    t0 = time_launches(lambda: alo_hip.value_head_major(value, mask), reps)
+    vhm = alo_hip.value_head_major(value, mask)
+    t = time_launches(lambda: alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref), reps)
+    nbytes = 2 * (N * S * 256 * 2 + N * S * 8 * 16 * 3) + ref.numel() * 4
+    return [dict(kernel="value_head_major[+mask]", N=N, dtype="bfloat16", ms=t0 * 1e3, alg_bytes=4 * value.numel(),
+                 GBps=4 * value.numel() / t0 / 1e9),
+            dict(kernel="msda_fwd_fused_hm[encoder]", N=N, Lq=S, dtype="bfloat16", ms=t * 1e3, alg_bytes=nbytes,
+                 GBps=nbytes / t / 1e9)]
+
+
 def bench_msda_bwd(N, Lq, kind, dtype, reps):
     value, shapes, start, loc, attn = msda_inputs(N, Lq, kind, dtype)
     go = torch.randn(N, Lq, 256, device=DEV).to(dtype)
@@ -219,6 +234,8 @@ def main():
             res = [bench_msda_fwd(a.N, S, "encoder", dt, a.reps) for dt in dts]
         elif w == "msda_fused":
             res = [bench_msda_fused(a.N, dt, a.reps) for dt in dts]
+        elif w == "msda_fused_hm":
+            res = bench_msda_fused_hm(a.N, a.reps)
         elif w == "msda_rand":
             res = [bench_msda_fwd(a.N, S, "uniform", dt, a.reps) for dt in dts]
         elif w == "msda_dec":
