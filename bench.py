@@ -331,11 +331,12 @@ def main():
                                "MSDeformAttn on HIP kernels; random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": None if enc is None else {
-            "bound": "hbm", "kernel": "msda_fwd_bf16_mfma_kernel<4, fused> (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
+            "bound": "hbm", "kernel": "msda_fwd_bf16_mfma_kernel<4, fused, head-major> (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
             "achieved": enc["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc["hbm_frac"],
-            # HBM-side bytes per launch from the PMC passes (profiles/r01_pmc_counters.md): FETCH_SIZE 384.6 MB (raw,
-            # gather pattern uncalibrated: lower bound) + WRITE_SIZE 88.9 MB; measured offline, not in this run
-            "traffic": 473.5e6 if a.dtype == "bf16" and a.batch == 8 else None,
+            # HBM-side bytes per launch from the PMC passes (profiles/r01_pmc_counters.md, third collection): FETCH_SIZE
+            # 389.2 MB (raw; gather pattern uncalibrated: lower bound) + WRITE_SIZE 108.2 MB; measured offline with
+            # tools/pmc.sh on the same kernel and shape, not in this run
+            "traffic": 497.4e6 if a.dtype == "bf16" and a.batch == 8 else None,
             "alg_bytes_per_launch": enc["alg_bytes"], "ms_per_launch": enc["ms_avg"]},
         "kernels": kernels,
     }

@@ -1,6 +1,7 @@
 """Average rocprofv3 --pmc counters per kernel over the last launches of each kernel (skips warm-up launches)."""
 import collections
 import csv
+import re
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -9,7 +10,8 @@ for r in rows:
     name = r["Kernel_Name"]
     if "alo::" not in name:
         continue
-    short = name.split("alo::")[1].split("(")[0][:70]
+    m = re.search(r"(\w+_kernel(?:<[^(]*>)?)\(", name)
+    short = (m.group(1) if m else name)[:90]
     per[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in per.items():
     print(k)
