@@ -18,6 +18,25 @@ from .ops.modules import MSDeformAttn
 from .utils import inverse_sigmoid
 
 
+_GEOMETRY = {}
+
+
+def _level_geometry(shapes, device):
+    """int32 ``spatial_shapes`` (L,2) / ``level_start_index`` (L,) on the device — what this fork of the op reads
+    (ms_deform_attn_cuda.cu:67-68) — built once per (pyramid, device): a host->device copy per forward would also make the
+    forward impossible to capture in a HIP graph.  The host-side copies ride along as attributes so that shape checks
+    and loops downstream need no device synchronisation."""
+    key = (shapes, str(device))
+    if key not in _GEOMETRY:
+        sizes = [h * w for h, w in shapes]
+        spatial_shapes = torch.tensor(shapes, dtype=torch.int32, device=device)
+        level_start_index = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int32, device=device)
+        spatial_shapes._alo_total = sum(sizes)
+        spatial_shapes._alo_shapes = list(shapes)
+        _GEOMETRY[key] = (spatial_shapes, level_start_index)
+    return _GEOMETRY[key]
+
+
 def _fused_ok(module, kwargs, *tensors):
     """The one-pass HIP epilogues (alo_add_layernorm) stand in for ``norm(x + dropout(y))`` when nothing is lost: eval mode
     (dropout is the identity), no autograd graph, CUDA, fp32 / bf16, and not the pure-torch export branch."""
@@ -293,12 +312,8 @@ class DeformableTransformer(nn.Module):
         src_flatten = torch.cat(src_flatten, 1)
         mask_flatten = torch.cat(mask_flatten, 1)
         pos_flatten = torch.cat(pos_flatten, 1).to(src_flatten.dtype)
-        # int32 metadata on the device: what this fork of the op reads (ms_deform_attn_cuda.cu:67-68)
-        spatial_shapes = torch.tensor(shapes, dtype=torch.int32, device=device)
+        spatial_shapes, level_start_index = _level_geometry(tuple(shapes), device)
         sizes = [h * w for h, w in shapes]
-        spatial_shapes._alo_total = sum(sizes)  # host-side copies: shape checks / loops downstream need no device sync
-        spatial_shapes._alo_shapes = list(shapes)
-        level_start_index = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int32, device=device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, pos_flatten, mask_flatten,
