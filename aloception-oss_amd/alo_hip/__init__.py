@@ -60,6 +60,12 @@ def _declare(lib):
     lib.alo_msda_forward_fused_hm.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_value_head_major.restype = ip
     lib.alo_value_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
+    lib.alo_bias_act_nchw.restype = ip
+    lib.alo_bias_act_nchw.argtypes = [vp] * 3 + [ip] * 4 + [vp]
+    lib.alo_gru_gate.restype = ip
+    lib.alo_gru_gate.argtypes = [vp] * 4 + [ip] * 3 + [c.c_long, c.c_long, vp]
+    lib.alo_gru_update.restype = ip
+    lib.alo_gru_update.argtypes = [vp] * 5 + [ip] * 3 + [c.c_long, vp]
     lib.alo_add_layernorm.restype = ip
     lib.alo_add_layernorm.argtypes = [vp] * 7 + [c.c_long, ip, c.c_float, ip, vp]
     lib.alo_bias_act.restype = ip
@@ -443,3 +449,43 @@ def bias_act_(x, bias, residual=None, relu=True):
         _check(lib().alo_bias_act(_ptr(x), _ptr(bias), None if residual is None else _ptr(residual), _ptr(x),
                                   x.numel() // C, C, 1 if relu else 0, _DTYPE_CODE[x.dtype], _stream(x.device)))
     return x
+
+
+# ---- RAFT update block glue (fp32, NCHW) ------------------------------------------------------------------------------------
+def _require_f32_nchw(name, t):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.is_contiguous()):
+        raise RuntimeError(f"{name} must be a contiguous float32 CUDA tensor (B, C, H, W)")
+
+
+def bias_act_nchw_(x, bias, relu=True):
+    """In place: ``x = act(x + bias[None, :, None, None])`` — the bias MIOpen would add in a second kernel plus the ReLU."""
+    _require_f32_nchw("x", x)
+    B, C, H, W = x.shape
+    with torch.cuda.device(x.device), _timed(f"bias_act_nchw/C={C}", 8.0 * x.numel()):
+        _check(lib().alo_bias_act_nchw(_ptr(x), _ptr(bias.float().contiguous()), _ptr(x), B, C, H * W, 1 if relu else 0,
+                                       _stream(x.device)))
+    return x
+
+
+def gru_gate_(zr, bias_zr, hx, rhx, C):
+    """``zr`` (B,2C,H,W): pre-activations [z | r].  z <- sigmoid(z + b) in place; ``rhx[:, :C] <- sigmoid(r + b) * hx[:, :C]``."""
+    _require_f32_nchw("zr", zr); _require_f32_nchw("hx", hx); _require_f32_nchw("rhx", rhx)
+    B, C2, H, W = zr.shape
+    if C2 != 2 * C or hx.shape != rhx.shape or hx.shape[0] != B or hx.shape[2:] != zr.shape[2:] or hx.shape[1] < C:
+        raise RuntimeError("gru_gate_: zr must be (B,2C,H,W) and hx / rhx (B,C+Cx,H,W)")
+    with torch.cuda.device(zr.device), _timed(f"gru_gate/C={C}", 4.0 * B * C * H * W * 5):
+        _check(lib().alo_gru_gate(_ptr(zr), _ptr(bias_zr), _ptr(hx), _ptr(rhx), B, C, H * W, hx.stride(0), rhx.stride(0),
+                                  _stream(zr.device)))
+
+
+def gru_update_(q, bias_q, zr, hx, C, net=None):
+    """``hx[:, :C] <- (1 - z) * hx[:, :C] + z * tanh(q + b)`` with z = ``zr[:, :C]``; ``net`` (B,C,H,W) also receives the result."""
+    _require_f32_nchw("q", q); _require_f32_nchw("zr", zr); _require_f32_nchw("hx", hx)
+    B, Cq, H, W = q.shape
+    if Cq != C or zr.shape != (B, 2 * C, H, W) or hx.shape[0] != B or hx.shape[2:] != q.shape[2:]:
+        raise RuntimeError("gru_update_: q must be (B,C,H,W), zr (B,2C,H,W), hx (B,C+Cx,H,W)")
+    if net is not None:
+        _require_f32_nchw("net", net)
+    with torch.cuda.device(q.device), _timed(f"gru_update/C={C}", 4.0 * B * C * H * W * (4 + (net is not None))):
+        _check(lib().alo_gru_update(_ptr(q), _ptr(bias_q), _ptr(zr), _ptr(hx), None if net is None else _ptr(net), B, C,
+                                    H * W, hx.stride(0), _stream(q.device)))

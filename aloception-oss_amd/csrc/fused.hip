@@ -161,6 +161,79 @@ value_head_major_kernel(const bf16_t* __restrict__ value, const unsigned char* _
     }
 }
 
+// ---- RAFT update block (fp32, NCHW planes of HW elements) --------------------------------------------------------------
+// y[b, c, :] = act(x[b, c, :] + bias[c]); HW % 4 == 0; 4 elements per thread.
+template <bool RELU>
+__global__ void __launch_bounds__(kThreads)
+bias_act_nchw_kernel(const float* x, const float* __restrict__ bias, float* y, long n4, int C, int HW4) {
+    const long stride = (long)gridDim.x * kThreads;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const int c = (int)((i / HW4) % C);
+        float v[4];
+        load4(x + i * 4, v);
+        const float b = bias[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += b; if (RELU) v[k] = fmaxf(v[k], 0.f); }
+        store4(y + i * 4, v);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// GRU gates (alonet/raft/update.py:27-33): zr holds the pre-activations of the update gate z (channels [0,C)) and the
+// reset gate r (channels [C,2C)) of ONE convolution over [h | x].  Writes z = sigmoid(.) back over its own slot and
+// r * h into the first C channels of the [r*h | x] buffer.  h and rh are channel slices of (B, C + Cx, H, W) buffers:
+// `hb` / `rb` are their batch strides in elements.
+__global__ void __launch_bounds__(kThreads)
+gru_gate_kernel(float* zr, const float* __restrict__ bias_zr, const float* h, float* rh, long n4, int C, int HW4,
+                long hb, long rb) {
+    const long stride = (long)gridDim.x * kThreads;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const long plane = i / HW4;                 // b * C + c
+        const int p4 = (int)(i - plane * HW4);
+        const int b = (int)(plane / C), c = (int)(plane - (long)b * C);
+        const long zoff = (((long)b * 2 * C + c) * HW4 + p4) * 4;
+        const long roff = zoff + (long)C * HW4 * 4;
+        const long hoff = (long)b * hb + ((long)c * HW4 + p4) * 4;
+        const long rhoff = (long)b * rb + ((long)c * HW4 + p4) * 4;
+        float z[4], r[4], hv[4];
+        load4(zr + zoff, z);
+        load4(zr + roff, r);
+        load4(h + hoff, hv);
+        const float bz = bias_zr[c], br = bias_zr[C + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            z[k] = sigmoidf_(z[k] + bz);
+            r[k] = sigmoidf_(r[k] + br) * hv[k];
+        }
+        store4(zr + zoff, z);
+        store4(rh + rhoff, r);
+    }
+}
+
+// h <- (1 - z) * h + z * tanh(q + bias_q), in place in the [h | x] buffer; optionally also to a contiguous copy `net`.
+__global__ void __launch_bounds__(kThreads)
+gru_update_kernel(const float* q, const float* __restrict__ bias_q, const float* zr, float* h, float* net, long n4, int C,
+                  int HW4, long hb) {
+    const long stride = (long)gridDim.x * kThreads;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const long plane = i / HW4;
+        const int p4 = (int)(i - plane * HW4);
+        const int b = (int)(plane / C), c = (int)(plane - (long)b * C);
+        const long zoff = (((long)b * 2 * C + c) * HW4 + p4) * 4;
+        const long hoff = (long)b * hb + ((long)c * HW4 + p4) * 4;
+        float qv[4], z[4], hv[4];
+        load4(q + i * 4, qv);
+        load4(zr + zoff, z);
+        load4(h + hoff, hv);
+        const float bq = bias_q[c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hv[k] = (1.0f - z[k]) * hv[k] + z[k] * tanhf(qv[k] + bq);
+        store4(h + hoff, hv);
+        if (net != nullptr) store4(net + i * 4, hv);
+    }
+}
+
 template <typename K>
 int launch(K kernel, unsigned blocks, hipStream_t stream, const char* what, void** args) {
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(blocks), dim3(kThreads), args, 0, stream);
@@ -250,4 +323,50 @@ extern "C" int alo_value_head_major(const void* value, const void* padding_mask,
                                    dim3(kThreads), args, 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_value_head_major: %s", hipGetErrorString(e));
     return check_launch("alo_value_head_major");
+}
+
+static unsigned stream_blocks(long n4) {
+    long blocks = (n4 + kThreads - 1) / kThreads;
+    return (unsigned)(blocks > 256L * 64 ? 256L * 64 : blocks);
+}
+
+extern "C" int alo_bias_act_nchw(const float* x, const float* bias, float* y, int B, int C, int HW, int relu, void* stream) {
+    ALO_REQUIRE(x && bias && y, ALO_ERR_INVALID_ARGUMENT, "alo_bias_act_nchw: null pointer argument");
+    ALO_REQUIRE(B > 0 && C > 0 && HW > 0 && HW % 4 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_bias_act_nchw: dimensions must be positive and H*W a multiple of 4 (B=%d C=%d HW=%d)", B, C, HW);
+    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_bias_act_nchw: pointers must be 16-byte aligned");
+    long n4 = (long)B * C * HW / 4;
+    int hw4 = HW / 4;
+    void* args[] = {&x, &bias, &y, &n4, &C, &hw4};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (relu) return launch(bias_act_nchw_kernel<true>, stream_blocks(n4), s, "alo_bias_act_nchw", args);
+    return launch(bias_act_nchw_kernel<false>, stream_blocks(n4), s, "alo_bias_act_nchw", args);
+}
+
+extern "C" int alo_gru_gate(float* zr, const float* bias_zr, const float* h, float* rh, int B, int C, int HW,
+                            long h_batch_stride, long rh_batch_stride, void* stream) {
+    ALO_REQUIRE(zr && bias_zr && h && rh, ALO_ERR_INVALID_ARGUMENT, "alo_gru_gate: null pointer argument");
+    ALO_REQUIRE(B > 0 && C > 0 && HW > 0 && HW % 4 == 0 && h_batch_stride % 4 == 0 && rh_batch_stride % 4 == 0,
+                ALO_ERR_INVALID_ARGUMENT, "alo_gru_gate: H*W and the batch strides must be multiples of 4 (B=%d C=%d HW=%d)",
+                B, C, HW);
+    ALO_REQUIRE((((uintptr_t)zr | (uintptr_t)h | (uintptr_t)rh) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_gru_gate: pointers must be 16-byte aligned");
+    long n4 = (long)B * C * HW / 4;
+    int hw4 = HW / 4;
+    void* args[] = {&zr, &bias_zr, &h, &rh, &n4, &C, &hw4, &h_batch_stride, &rh_batch_stride};
+    return launch(gru_gate_kernel, stream_blocks(n4), static_cast<hipStream_t>(stream), "alo_gru_gate", args);
+}
+
+extern "C" int alo_gru_update(const float* q, const float* bias_q, const float* zr, float* h, float* net, int B, int C,
+                              int HW, long h_batch_stride, void* stream) {
+    ALO_REQUIRE(q && bias_q && zr && h, ALO_ERR_INVALID_ARGUMENT, "alo_gru_update: null pointer argument");
+    ALO_REQUIRE(B > 0 && C > 0 && HW > 0 && HW % 4 == 0 && h_batch_stride % 4 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_gru_update: H*W and the batch stride must be multiples of 4 (B=%d C=%d HW=%d)", B, C, HW);
+    ALO_REQUIRE((((uintptr_t)q | (uintptr_t)zr | (uintptr_t)h | (uintptr_t)net) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_gru_update: pointers must be 16-byte aligned");
+    long n4 = (long)B * C * HW / 4;
+    int hw4 = HW / 4;
+    void* args[] = {&q, &bias_q, &zr, &h, &net, &n4, &C, &hw4, &h_batch_stride};
+    return launch(gru_update_kernel, stream_blocks(n4), static_cast<hipStream_t>(stream), "alo_gru_update", args);
 }

@@ -202,6 +202,23 @@ int alo_add_layernorm(const void* x, const void* residual, const void* gamma, co
 int alo_bias_act(const void* x, const void* bias, const void* residual, void* y, long rows, int C, int relu,
                  int dtype, void* stream);
 
+/*
+ * ---- Extensions: elementwise glue of RAFT's update block (alonet/raft/update.py:27-33,83-101), fp32, NCHW ------------------
+ * One pass each; H*W % 4 == 0; pointers 16-byte aligned.  The convolutions stay on MIOpen and are called WITHOUT bias.
+ *
+ * alo_bias_act_nchw: y[b,c,:] = act(x[b,c,:] + bias[c])            (convolution bias + ReLU; y may alias x)
+ * alo_gru_gate:      zr (B, 2C, H, W) = pre-activations [z | r] of one convolution over [h | x]
+ *                    z  <- sigmoid(z + bias_zr[:C])                 written back over its own slot in zr
+ *                    rh <- sigmoid(r + bias_zr[C:]) * h             written into the first C channels of the [r*h | x] buffer
+ * alo_gru_update:    h  <- (1 - z) * h + z * tanh(q + bias_q)       in place in the [h | x] buffer (+ contiguous copy `net`)
+ *   h / rh are channel slices of (B, C + Cx, H, W) buffers: *_batch_stride = (C + Cx) * H * W elements.
+ */
+int alo_bias_act_nchw(const float* x, const float* bias, float* y, int B, int C, int HW, int relu, void* stream);
+int alo_gru_gate(float* zr, const float* bias_zr, const float* h, float* rh, int B, int C, int HW,
+                 long h_batch_stride, long rh_batch_stride, void* stream);
+int alo_gru_update(const float* q, const float* bias_q, const float* zr, float* h, float* net, int B, int C, int HW,
+                   long h_batch_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

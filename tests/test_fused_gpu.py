@@ -91,3 +91,29 @@ def test_resnet_bottleneck_fused_vs_stock():
     for k in fused:
         scale = stock[k].abs().max().item()
         assert (fused[k] - stock[k]).abs().max().item() <= 2e-4 * scale, k
+
+
+def test_raft_update_block_fused_glue_matches_stock_ops():
+    """BasicUpdateBlock at inference (merged z/r convolution, HIP gate / update / bias passes, 0.25 folded into the mask
+    head) against the same module evaluated through the stock PyTorch ops (autograd path)."""
+    from alonet.raft.update import BasicUpdateBlock
+
+    torch.manual_seed(3)
+    blk = BasicUpdateBlock(corr_levels=4, corr_radius=4).to(DEV).eval()
+    B, H, W = 2, 12, 18
+    net = torch.tanh(torch.randn(B, 128, H, W, device=DEV))
+    inp = torch.relu(torch.randn(B, 128, H, W, device=DEV))
+    corr = torch.randn(B, 324, H, W, device=DEV)
+    flow = torch.randn(B, 2, H, W, device=DEV) * 3
+    with alo_hip.LaunchTimer() as t, torch.no_grad():
+        n1, m1, d1 = blk(net, inp, corr, flow)
+    tags = set(t.summary())
+    assert {"gru_gate/C=128", "gru_update/C=128"} <= tags and any(k.startswith("bias_act_nchw") for k in tags)
+    n0, m0, d0 = blk(net, inp, corr, flow)  # parameters require grad: stock ops
+    assert n0.requires_grad
+    for a, b in ((n1, n0), (m1, m0), (d1, d0)):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    # odd H*W: the stock path is used (the kernels want H*W % 4 == 0)
+    with alo_hip.LaunchTimer() as t2, torch.no_grad():
+        blk(*(t[..., :11, :17].contiguous() for t in (net, inp, corr, flow)))  # 11 * 17 = 187
+    assert not t2.summary()
