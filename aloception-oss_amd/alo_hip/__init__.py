@@ -48,8 +48,6 @@ def _declare(lib):
     lib.alo_msda_forward_fused.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_msda_backward.restype = ip
     lib.alo_msda_backward.argtypes = [vp] * 9 + [ip] * 9 + [vp]
-    lib.alo_msda_backward_grid.restype = ip
-    lib.alo_msda_backward_grid.argtypes = [vp] * 9 + [ip] * 9 + [c.POINTER(c.c_int32), vp]
     lib.alo_corr_level_shape.restype = None
     lib.alo_corr_level_shape.argtypes = [ip, ip, ip, c.POINTER(ip), c.POINTER(ip)]
     lib.alo_corr_build_workspace_bytes.restype = sz
@@ -317,12 +315,8 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     return out
 
 
-def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64,
-                  query_grid_shapes=None):
-    """-> [grad_value, grad_sampling_loc, grad_attn_weight].  Replaces ``alonet_custom::ms_deform_attn_backward``.
-
-    ``query_grid_shapes``: host list [(H_l, W_l), ...] when the queries are the pixels of the value pyramid in order
-    (encoder self-attention); a pure performance hint (2-D query tiles for the LDS accumulation of grad_value)."""
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight].  Replaces ``alonet_custom::ms_deform_attn_backward``."""
     dims, vdt, ldt, loc, attn = _msda_prepare(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                                               im2col_step, extra=[("grad_output", grad_output)])
     N, S, M, D, L, Lq, P = dims
@@ -333,20 +327,10 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
     grad_loc = torch.empty(loc.shape, dtype=gdt, device=value.device)
     grad_attn = torch.empty(attn.shape, dtype=gdt, device=value.device)
     nbytes = msda_backward_bytes(N, S, M, D, L, Lq, P, value.element_size(), loc.element_size())
-    grid = None
-    if query_grid_shapes is not None and len(query_grid_shapes) == L <= 8 and Lq == S \
-            and sum(int(h) * int(w) for h, w in query_grid_shapes) == S:
-        grid = (ctypes.c_int32 * (2 * L))(*[int(v) for hw in query_grid_shapes for v in hw])
     with torch.cuda.device(value.device), _timed(f"msda_bwd/Lq={Lq}", nbytes):
-        if grid is not None:
-            _check(lib().alo_msda_backward_grid(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
-                                                _ptr(attn), _ptr(grad_output), _ptr(grad_value), _ptr(grad_loc),
-                                                _ptr(grad_attn), N, S, M, D, L, Lq, P, vdt, ldt, grid,
-                                                _stream(value.device)))
-        else:
-            _check(lib().alo_msda_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc),
-                                           _ptr(attn), _ptr(grad_output), _ptr(grad_value), _ptr(grad_loc),
-                                           _ptr(grad_attn), N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
+        _check(lib().alo_msda_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
+                                       _ptr(grad_output), _ptr(grad_value), _ptr(grad_loc), _ptr(grad_attn),
+                                       N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
     return [grad_value.to(value.dtype), grad_loc.to(sampling_loc.dtype), grad_attn.to(attn_weight.dtype)]
 
 

@@ -84,9 +84,6 @@ class MSDeformAttnFunction(Function):
                 im2col_step):
         load_ops()
         ctx.im2col_step = im2col_step
-        # host copy of the level shapes (set by DeformableTransformer): lets the backward tile the queries in 2-D when they
-        # are the pyramid's own pixels, without reading the device tensor
-        ctx.host_shapes = getattr(value_spatial_shapes, "_alo_shapes", None)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                               attention_weights)
         return torch.ops.alonet_custom.ms_deform_attn_forward(
@@ -97,14 +94,9 @@ class MSDeformAttnFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         value, shapes, start, loc, attn = ctx.saved_tensors
-        if ctx.host_shapes is not None and loc.shape[1] == value.shape[1] and value.is_cuda:
-            # encoder self-attention (queries = pixels): same kernels as the dispatcher op, plus the tiling hint
-            g_value, g_loc, g_attn = alo_hip.msda_backward(value, shapes, start, loc, attn, grad_output.contiguous(),
-                                                           ctx.im2col_step, query_grid_shapes=ctx.host_shapes)
-        else:
-            g_value, g_loc, g_attn = torch.ops.alonet_custom.ms_deform_attn_backward(
-                value, shapes, start, loc, attn, grad_output.contiguous(), ctx.im2col_step
-            )
+        g_value, g_loc, g_attn = torch.ops.alonet_custom.ms_deform_attn_backward(
+            value, shapes, start, loc, attn, grad_output.contiguous(), ctx.im2col_step
+        )
         return g_value, None, None, g_loc, g_attn, None
 
 

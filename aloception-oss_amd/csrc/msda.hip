@@ -56,7 +56,6 @@ template <typename CT>
 struct Tap {
     bool valid, ok[4];
     int base;  // pixel index (within the batch item's S rows) of the (h_low, w_low) corner
-    int h_low, w_low;
     int W;
     CT lh, lw;
 };
@@ -79,8 +78,6 @@ __device__ __forceinline__ Tap<CT> make_tap(CT loc_x, CT loc_y, int H, int W, in
     t.ok[2] = t.valid && hh && wl;
     t.ok[3] = t.valid && hh && wh;
     t.base = start + (MUL24 ? __mul24(h_low, W) : h_low * W) + w_low;
-    t.h_low = h_low;
-    t.w_low = w_low;
     t.W = W;
     return t;
 }
@@ -607,9 +604,7 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 // ------------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------------
-// SCATTER = true: also accumulates grad_value with one global atomic per (sample, corner, channel) — the complete backward
-// in one kernel (fp64, D > 32 ...).  SCATTER = false: grad_loc / grad_attn only; msda_bwd_scatter_kernel does grad_value.
-template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT, bool SCATTER>
+template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
                 const LT* __restrict__ loc, const LT* __restrict__ attn, const T* __restrict__ grad_out,
@@ -699,7 +694,7 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                             const CT tgv = top * d.attn;
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
-                                if (SCATTER && d.off[k] != kNoCorner) unsafeAtomicAdd(gv + d.off[k] + ch + i, w[k] * tgv);
+                                if (d.off[k] != kNoCorner) unsafeAtomicAdd(gv + d.off[k] + ch + i, w[k] * tgv);
                             const CT val = w[0] * v[0][i] + w[1] * v[1][i] + w[2] * v[2][i] + w[3] * v[3][i];
                             const CT ghw = -hw * v[0][i] - d.lw * v[1][i] + hw * v[2][i] + d.lw * v[3][i];
                             const CT gww = -hh * v[0][i] + hh * v[1][i] - d.lh * v[2][i] + d.lh * v[3][i];
@@ -729,185 +724,6 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------
-// backward, grad_value only: scatter with LDS privatisation (fp32 gradients, D <= 32)
-//
-// One global atomic per (sample, corner, channel) made the first backward 3x slower than everything else in it together
-// (1.46 G element atomics = 45.5 M 128-byte row requests per encoder launch at N = 4; the L2 retires ~11 G of them per
-// second).  Neighbouring queries hit the same pixels — at level 3 eight queries in a row share their four corners — so a
-// workgroup first adds the contributions of a TILE of queries into an LDS window (ds_add_f32, no bank conflicts: one lane
-// per channel) and sends every touched pixel row to memory once.
-//   * a workgroup = one head x one tile of up to 128 queries.  When the queries are the pixels of the pyramid in order
-//     (encoder self-attention; the caller says so by passing the host copy of spatial_shapes) tiles are 16 x 8 pixel
-//     blocks of one level, otherwise 128 consecutive queries.
-//   * levels are processed one after the other through the same window: bounding box of the tile's corners on that level
-//     (block reduction), zero, scatter, flush.  A box larger than the window (scattered queries, e.g. the decoder's, or
-//     very long learned offsets) falls back to direct global atomics for that level: always correct, never faster than
-//     before only in that case.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int kTileQ = 128;        // queries per tile
-constexpr int kTileW = 16, kTileH = 8;
-constexpr int kWinPix = 480;       // pixels of the LDS window (x D channels x 4 bytes = 60 KiB at D = 32)
-constexpr int kScatterMaxP = 4;    // sampling points per level the descriptor stage is sized for
-
-struct alignas(16) ScatterDesc {
-    int x0, y0;       // (w_low, h_low) of the sample, may be -1
-    unsigned ok;      // bit k: corner k is inside the map
-    unsigned pad;
-    float w[4];       // bilinear weight * attention weight
-};
-struct ScatterDims {
-    int S, M, D, L, P, Lq;
-    int tiles_per_batch;
-    int grid_levels;               // > 0: queries are the pyramid's pixels, tiles are 16x8 blocks; host_hw holds (H, W)
-    int host_hw[2 * 8];
-};
-inline size_t scatter_lds_bytes(int D, int P) {
-    return (size_t)kWinPix * D * 4 + (size_t)kTileQ * P * sizeof(ScatterDesc) + kTileQ * 4 + 16;
-}
-
-template <typename T>
-__global__ void __launch_bounds__(kThreads)
-msda_bwd_scatter_kernel(const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
-                        const float* __restrict__ loc, const float* __restrict__ attn, const T* __restrict__ grad_out,
-                        float* __restrict__ grad_value, const ScatterDims dm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* win = reinterpret_cast<float*>(smem);                                             // kWinPix * D floats
-    ScatterDesc* desc = reinterpret_cast<ScatterDesc*>(smem + (size_t)kWinPix * dm.D * 4);   // kTileQ * P
-    int* tileq = reinterpret_cast<int*>(desc + kTileQ * dm.P);                                // kTileQ query indices (-1 = none)
-    int* box = tileq + kTileQ;                                                                // xmin, ymin, xmax, ymax
-
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int m = blockIdx.x % dm.M;
-    const int tile = blockIdx.x / dm.M;
-
-    // ---- which queries ------------------------------------------------------------------------------------------------
-    if (tid < kTileQ) {
-        int q = -1;
-        if (dm.grid_levels > 0) {
-            int t = tile, start = 0;
-            for (int l = 0; l < dm.grid_levels; ++l) {
-                const int H = dm.host_hw[2 * l], W = dm.host_hw[2 * l + 1];
-                const int ntx = (W + kTileW - 1) / kTileW;
-                const int nt = ntx * ((H + kTileH - 1) / kTileH);
-                if (t < nt) {
-                    const int x = (t % ntx) * kTileW + tid % kTileW, y = (t / ntx) * kTileH + tid / kTileW;
-                    if (x < W && y < H) q = start + y * W + x;
-                    break;
-                }
-                t -= nt;
-                start += H * W;
-            }
-        } else {
-            q = tile * kTileQ + tid;
-            if (q >= dm.Lq) q = -1;
-        }
-        tileq[tid] = q;
-    }
-    __syncthreads();
-
-    const int LP = dm.L * dm.P;
-    const size_t row_elems = (size_t)dm.M * dm.D;
-    float* gv = grad_value + (size_t)b * dm.S * row_elems + (size_t)m * dm.D;  // + pixel * row_elems + channel
-    const int c = tid & 31, hw = tid >> 5;  // channel lane, half-wave id (8 per workgroup)
-    constexpr int QPH = kTileQ / (kThreads / 32);  // queries per half-wave: 16
-
-    // grad_out rows of this half-wave's queries: loaded once, all requests in flight together
-    float go[QPH];
-#pragma unroll
-    for (int j = 0; j < QPH; ++j) {
-        const int q = tileq[hw + j * (kThreads / 32)];
-        go[j] = (q >= 0 && c < dm.D) ? (float)ld(grad_out + (((size_t)b * dm.Lq + q) * dm.M + m) * dm.D + c) : 0.f;
-    }
-
-    for (int l = 0; l < dm.L; ++l) {
-        const int H = shapes[2 * l], W = shapes[2 * l + 1], start = lstart[l];
-        if (tid < 4) box[tid] = tid < 2 ? 0x7fffffff : -1;
-        __syncthreads();
-        // ---- descriptors of the tile's samples on level l + the bounding box of the corners they touch ---------------------
-        {
-            int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
-            for (int i = tid; i < kTileQ * dm.P; i += kThreads) {
-                const int q = tileq[i / dm.P];
-                ScatterDesc d;
-                d.ok = 0; d.pad = 0; d.x0 = d.y0 = 0;
-                d.w[0] = d.w[1] = d.w[2] = d.w[3] = 0.f;
-                if (q >= 0) {
-                    const long g = (((long)b * dm.Lq + q) * dm.M + m) * LP + l * dm.P + i % dm.P;
-                    const Tap<float> t = make_tap<float>(loc[2 * g], loc[2 * g + 1], H, W, 0);
-                    if (t.valid) {
-                        const float a = attn[g];
-                        const float hh = 1.f - t.lh, hw_ = 1.f - t.lw;
-                        d.w[0] = hh * hw_ * a; d.w[1] = hh * t.lw * a; d.w[2] = t.lh * hw_ * a; d.w[3] = t.lh * t.lw * a;
-                        d.ok = (t.ok[0] ? 1u : 0u) | (t.ok[1] ? 2u : 0u) | (t.ok[2] ? 4u : 0u) | (t.ok[3] ? 8u : 0u);
-                        d.y0 = t.h_low;
-                        d.x0 = t.w_low;
-                        xmin = min(xmin, max(t.w_low, 0)); ymin = min(ymin, max(t.h_low, 0));
-                        xmax = max(xmax, min(t.w_low + 1, W - 1)); ymax = max(ymax, min(t.h_low + 1, H - 1));
-                    }
-                }
-                desc[i] = d;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                xmin = min(xmin, __shfl_xor(xmin, o, 64)); ymin = min(ymin, __shfl_xor(ymin, o, 64));
-                xmax = max(xmax, __shfl_xor(xmax, o, 64)); ymax = max(ymax, __shfl_xor(ymax, o, 64));
-            }
-            if ((tid & 63) == 0) {
-                atomicMin(&box[0], xmin); atomicMin(&box[1], ymin);
-                atomicMax(&box[2], xmax); atomicMax(&box[3], ymax);
-            }
-        }
-        __syncthreads();
-        const int bx = box[0], by = box[1];
-        const int bw = box[2] - bx + 1, bh = box[3] - by + 1;
-        if (box[2] < 0) continue;                                   // no valid sample of this tile on this level (uniform)
-        const bool priv = bw * bh <= kWinPix;                       // uniform
-        if (priv) {
-            for (int i = tid; i < bw * bh * dm.D; i += kThreads) win[i] = 0.f;
-            __syncthreads();
-        }
-
-        // ---- scatter: a half-wave = one query at a time, a lane = one channel ------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < QPH; ++j) {
-            const int qi = hw + j * (kThreads / 32);
-            if (tileq[qi] < 0 || c >= dm.D) continue;
-            for (int p = 0; p < dm.P; ++p) {
-                const ScatterDesc d = desc[qi * dm.P + p];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (!(d.ok & (1u << k))) continue;
-                    const int px = d.x0 + (k & 1), py = d.y0 + (k >> 1);
-                    const float v = d.w[k] * go[j];
-                    if (priv) {
-                        atomicAdd(&win[((py - by) * bw + (px - bx)) * dm.D + c], v);  // ds_add_f32
-                    } else {
-                        unsafeAtomicAdd(gv + (size_t)(start + py * W + px) * row_elems + c, v);
-                    }
-                }
-            }
-        }
-
-        // ---- flush the window: one row of global atomics per touched pixel ---------------------------------------------------
-        if (priv) {
-            __syncthreads();
-            for (int pix = hw; pix < bw * bh; pix += kThreads / 32) {
-                const float v = c < dm.D ? win[pix * dm.D + c] : 0.f;
-                const unsigned long long any = __ballot(v != 0.f);
-                const unsigned half = (unsigned)(any >> (tid & 32));  // this half-wave's 32 lanes
-                if (half != 0u && c < dm.D) {
-                    const int py = by + pix / bw, px = bx + pix % bw;
-                    unsafeAtomicAdd(gv + (size_t)(start + py * W + px) * row_elems + c, v);
-                }
-            }
-        }
-        // the next level's first barrier orders these reads of win / desc before they are overwritten
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------------------------
@@ -924,7 +740,6 @@ struct Tuning {
     int iters = 0;
     int bwd_lanes = 1;     // ALO_MSDA_BWD_LANES=0: vector lanes (16 B per lane) in backward; 1: one channel per lane
     int mfma = 1;          // ALO_MSDA_MFMA=0: keep bf16 forward on the VALU kernel
-    int bwd_split = 1;     // ALO_MSDA_BWD_SPLIT=0: grad_value by direct global atomics inside the one backward kernel
 };
 const Tuning& tuning() {
     static const Tuning t = [] {
@@ -932,7 +747,6 @@ const Tuning& tuning() {
         if (const char* e = getenv("ALO_MSDA_FWD_BATCH")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_batch = v; }
         if (const char* e = getenv("ALO_MSDA_BWD_LANES")) x.bwd_lanes = atoi(e);
         if (const char* e = getenv("ALO_MSDA_MFMA")) x.mfma = atoi(e);
-        if (const char* e = getenv("ALO_MSDA_BWD_SPLIT")) x.bwd_split = atoi(e);
         if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
         return x;
     }();
@@ -1011,8 +825,7 @@ int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char*
 #define ALO_BWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
     if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
         const size_t lds = kMetaBytes + (size_t)(kThreads / G) * ((size_t)L * P * sizeof(BwdDesc<CT>) + 16);       \
-        if (split) return launch(msda_bwd_kernel<T, LT, CT, VEC, G, LPCT, false>, dm, lds, stream, "alo_msda_backward", args); \
-        return launch(msda_bwd_kernel<T, LT, CT, VEC, G, LPCT, true>, dm, lds, stream, "alo_msda_backward", args);       \
+        return launch(msda_bwd_kernel<T, LT, CT, VEC, G, LPCT>, dm, lds, stream, "alo_msda_backward", args);       \
     }
 // every (vector width, group) pair a plan can produce for one dtype
 #define ALO_ALL_CASES(CASE, T, LT, CT, VECW)                                                       \
@@ -1125,11 +938,10 @@ extern "C" int alo_msda_forward_fused_hm(const void* value_hm, const int32_t* sp
                         ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true);
 }
 
-namespace {
-int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                  const void* sampling_loc, const void* attn_weight, const void* grad_out, void* grad_value,
-                  void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
-                  int value_dtype, int loc_dtype, const int32_t* host_grid_shapes, void* stream_) {
+extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                 const void* sampling_loc, const void* attn_weight, const void* grad_out,
+                                 void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M,
+                                 int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P,
                           value_dtype, loc_dtype, &elem))
@@ -1149,47 +961,6 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
         plan.g = D <= 8 ? 8 : (D <= 32 ? 32 : 64);
         plan.lp16 = false;
     }
-    // fp32 gradients, D <= 32: grad_value goes through the LDS-privatised scatter kernel, the kernel below only produces
-    // grad_sampling_loc / grad_attn_weight
-    const bool split = value_dtype != ALO_F64 && D <= 32 && P <= kScatterMaxP && tuning().bwd_split;
-    if (split) {
-        ScatterDims sd;
-        sd.S = S; sd.M = M; sd.D = D; sd.L = L; sd.P = P; sd.Lq = Lq;
-        sd.grid_levels = 0;
-        long tiles = ((long)Lq + kTileQ - 1) / kTileQ;
-        if (host_grid_shapes != nullptr && L <= 8) {
-            long total = 0, t2 = 0;
-            for (int l = 0; l < L; ++l) {
-                const int H = host_grid_shapes[2 * l], W = host_grid_shapes[2 * l + 1];
-                ALO_REQUIRE(H > 0 && W > 0 && H < 32768 && W < 32768, ALO_ERR_INVALID_ARGUMENT,
-                            "alo_msda_backward_grid: bad host shape (%d, %d) at level %d", H, W, l);
-                sd.host_hw[2 * l] = H; sd.host_hw[2 * l + 1] = W;
-                total += (long)H * W;
-                t2 += (long)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
-            }
-            ALO_REQUIRE(total == Lq && total == S, ALO_ERR_INVALID_ARGUMENT,
-                        "alo_msda_backward_grid: the query grid (%ld pixels) must be the value pyramid (S = %d, Lq = %d)",
-                        total, S, Lq);
-            sd.grid_levels = L;
-            tiles = t2;
-        }
-        sd.tiles_per_batch = (int)tiles;
-        const size_t lds = scatter_lds_bytes(D, P);
-        void* sargs[] = {&spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &grad_out, &grad_value, &sd};
-        const dim3 grid((unsigned)(tiles * M), (unsigned)N);
-        const void* kern = value_dtype == ALO_BF16 ? reinterpret_cast<const void*>(msda_bwd_scatter_kernel<bf16_t>)
-                                                   : reinterpret_cast<const void*>(msda_bwd_scatter_kernel<float>);
-        static thread_local size_t lds_set[2] = {0, 0};  // the attribute call is not free: raise the limit only when it grows
-        size_t& have = lds_set[value_dtype == ALO_BF16 ? 1 : 0];
-        if (lds > have) {
-            e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: %s", hipGetErrorString(e));
-            have = lds;
-        }
-        e = hipLaunchKernel(kern, grid, dim3(kThreads), sargs, lds, stream);
-        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: %s", hipGetErrorString(e));
-        if (int rc = check_launch("alo_msda_backward (scatter)")) return rc;
-    }
     Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
     void* args[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &grad_out,
                     &grad_value, &grad_sampling_loc, &grad_attn_weight, &dm};
@@ -1197,24 +968,4 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_BWD_CASE, double, double, double, 2) }
     if (value_dtype == ALO_BF16) { ALO_ALL_CASES(ALO_BWD_CASE, bf16_t, float, float, 8) }
     return fail(ALO_ERR_UNSUPPORTED, "alo_msda_backward: no kernel for vec=%d group=%d", plan.vec, plan.g);
-}
-}  // namespace
-
-extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                                 const void* sampling_loc, const void* attn_weight, const void* grad_out,
-                                 void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M,
-                                 int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
-    return backward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
-                         grad_sampling_loc, grad_attn_weight, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, nullptr, stream_);
-}
-
-extern "C" int alo_msda_backward_grid(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                                      const void* sampling_loc, const void* attn_weight, const void* grad_out,
-                                      void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int N, int S,
-                                      int M, int D, int L, int Lq, int P, int value_dtype, int loc_dtype,
-                                      const int32_t* host_spatial_shapes, void* stream_) {
-    ALO_REQUIRE(host_spatial_shapes, ALO_ERR_INVALID_ARGUMENT, "alo_msda_backward_grid: host_spatial_shapes is null");
-    return backward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
-                         grad_sampling_loc, grad_attn_weight, N, S, M, D, L, Lq, P, value_dtype, loc_dtype,
-                         host_spatial_shapes, stream_);
 }

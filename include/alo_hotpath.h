@@ -131,27 +131,14 @@ int alo_value_head_major(const void* value, const void* padding_mask, void* out,
  *
  * grad dtype is F64 when value_dtype is F64 and F32 otherwise (bf16 storage accumulates its gradients in fp32; the
  * caller narrows afterwards).  Supported (value_dtype, loc_dtype): (F32,F32) (F64,F64) (BF16,F32).
- * grad_value is accumulated with hardware floating-point atomics (in LDS first, then one row per touched pixel to memory,
- * for fp32 gradients and D <= 32), so — exactly like the reference — its low-order bits depend on scheduling.
+ * grad_value is accumulated with hardware floating-point atomics, so — exactly like the reference — its low-order
+ * bits depend on scheduling.
  */
 int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
                       const void* sampling_loc, const void* attn_weight, const void* grad_out,
                       void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
                       int N, int S, int M, int D, int L, int Lq, int P,
                       int value_dtype, int loc_dtype, void* stream);
-
-/*
- * alo_msda_backward with a hint (extension): `host_spatial_shapes` is a HOST copy (L, 2) of spatial_shapes, passed when
- * the QUERIES are the pixels of the value pyramid in order (Lq == S: the encoder's self-attention).  grad_value is
- * accumulated tile by tile in LDS before it goes to memory (fp32 gradients, D <= 32); with the hint the tiles are 16 x 8
- * pixel blocks of one level, without it (alo_msda_backward) 128 consecutive queries.  Results are the same up to the
- * order of the floating-point additions.  L <= 8.
- */
-int alo_msda_backward_grid(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                           const void* sampling_loc, const void* attn_weight, const void* grad_out,
-                           void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
-                           int N, int S, int M, int D, int L, int Lq, int P,
-                           int value_dtype, int loc_dtype, const int32_t* host_spatial_shapes, void* stream);
 
 /* Size of level l of the correlation pyramid of an (H, W) feature grid: level 0 = (H, W), level l+1 = floor(level l / 2)
  * (F.avg_pool2d(2, stride=2), corr.py:25-27). */

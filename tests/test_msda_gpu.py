@@ -1,6 +1,4 @@
 """Parity of the HIP multi-scale deformable attention (through the C ABI) with the golden vectors and the oracle."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch
@@ -342,29 +340,3 @@ def test_head_major_rejects_other_shapes():
     with pytest.raises(RuntimeError, match="L = P = 4"):
         alo_hip.msda_forward_fused_hm(v, shapes, start, off, lg, torch.rand(1, 3, 2, 2, device=DEV))
     assert not alo_hip.head_major_supported(torch.zeros(1, 4, 2, 32, device=DEV), 4, 4)  # fp32
-
-
-@pytest.mark.parametrize("loc_range", [(-0.2, 1.2), (0.3, 0.5)], ids=["scattered", "clustered"])
-@pytest.mark.parametrize("shapes,M,D,P", [([(19, 37), (10, 19), (5, 10), (3, 5)], 8, 32, 4), ([(9, 33), (4, 5)], 2, 8, 3)])
-def test_backward_with_query_grid_hint_matches_oracle(shapes, M, D, P, loc_range):
-    """Encoder-style backward (queries = pyramid pixels): 2-D query tiles + LDS accumulation of grad_value.  Scattered
-    locations overflow the LDS window (direct-atomic fallback per level), clustered ones stay inside it."""
-    S = sum(h * w for h, w in shapes)
-    c = msda_case(4242 + D, 2, M, D, S, shapes, P, np.float32, loc_range=loc_range)
-    rgv, rgl, rga = O.msda_backward(c["value"].astype(np.float64), c["shapes"], c["level_start"],
-                                    c["loc"].astype(np.float64), c["attn"].astype(np.float64),
-                                    c["grad_out"].astype(np.float64))
-    args = (dev(c["value"]), dev(c["shapes"]), dev(c["level_start"]), dev(c["loc"]), dev(c["attn"]), dev(c["grad_out"]), 64)
-    hinted = alo_hip.msda_backward(*args, query_grid_shapes=shapes)
-    plain = alo_hip.msda_backward(*args)
-    for gv, gl, ga in (hinted, plain):
-        np.testing.assert_allclose(gv.double().cpu().numpy(), rgv, rtol=1e-4, atol=3e-5)
-        np.testing.assert_allclose(gl.double().cpu().numpy(), rgl, rtol=1e-4, atol=2e-5 * max(1.0, np.abs(rgl).max()))
-        np.testing.assert_allclose(ga.double().cpu().numpy(), rga, rtol=1e-4, atol=1e-4)
-    # a hint that does not describe the queries is ignored by the wrapper (Lq != S) or rejected by the library
-    bad = (ctypes.c_int32 * (2 * len(shapes)))(*([1] * (2 * len(shapes))))
-    n = [int(x) for x in (2, S, M, D, len(shapes), S, P)]
-    t = [torch.empty_like(args[0]), torch.empty_like(args[3]), torch.empty_like(args[4])]
-    rc = alo_hip.lib().alo_msda_backward_grid(*(alo_hip._ptr(x) for x in args[:6]), *(alo_hip._ptr(x) for x in t), *n, 0, 0,
-                                              bad, alo_hip._stream(args[0].device))
-    assert rc == 1 and b"query grid" in alo_hip.lib().alo_last_error()

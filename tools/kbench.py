@@ -141,11 +141,10 @@ def bench_msda_fused_hm(N, reps):
 def bench_msda_bwd(N, Lq, kind, dtype, reps):
     value, shapes, start, loc, attn = msda_inputs(N, Lq, kind, dtype)
     go = torch.randn(N, Lq, 256, device=DEV).to(dtype)
-    grid = DETR_SHAPES if Lq == value.shape[1] and os.environ.get("ALO_KBENCH_NO_GRID") is None else None
-    t = time_launches(lambda: alo_hip.msda_backward(value, shapes, start, loc, attn, go, query_grid_shapes=grid), reps)
+    t = time_launches(lambda: alo_hip.msda_backward(value, shapes, start, loc, attn, go), reps)
     nbytes = msda_bwd_bytes(N, value.shape[1], Lq, value.element_size())
-    return dict(kernel=f"msda_bwd[{kind}{', grid hint' if grid else ''}]", N=N, Lq=Lq, dtype=str(dtype).split(".")[-1],
-                ms=t * 1e3, alg_bytes=nbytes, GBps=nbytes / t / 1e9)
+    return dict(kernel=f"msda_bwd[{kind}]", N=N, Lq=Lq, dtype=str(dtype).split(".")[-1], ms=t * 1e3,
+                alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
 def corr_inputs(B, C=256, H=90, W=160, seed=0):
