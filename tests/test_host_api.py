@@ -97,3 +97,61 @@ def test_coords_grid_layout():
     g = coords_grid(2, 3, 5)
     assert g.shape == (2, 2, 3, 5)
     assert torch.equal(g[0, 0, 1], torch.arange(5.0)) and torch.equal(g[1, 1, :, 2], torch.arange(3.0))
+
+
+# ---- host-side plumbing of the inference fast paths (CPU) ------------------------------------------------------------
+def test_conv1x1_as_gemm_equals_conv2d_on_nhwc_rows():
+    import torch.nn.functional as F
+
+    from alonet.detr.backbone import conv1x1_as_gemm
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 12, 9, 11).contiguous(memory_format=torch.channels_last)
+    w, b = torch.randn(20, 12, 1, 1), torch.randn(20)
+    for stride in ((1, 1), (2, 2)):
+        for relu in (False, True):
+            for bias in (b, None):
+                want = F.conv2d(x, w, bias, stride)
+                want = want.relu() if relu else want
+                got = conv1x1_as_gemm(x, w, bias, stride, relu=relu)
+                assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+                assert (got - want).abs().max().item() <= 1e-5
+
+
+def test_level_geometry_is_cached_and_carries_host_copies():
+    from alonet.deformable_detr.deformable_transformer import _level_geometry
+
+    shapes = ((5, 7), (3, 4))
+    a = _level_geometry(shapes, torch.device("cpu"))
+    b = _level_geometry(shapes, torch.device("cpu"))
+    assert a[0] is b[0] and a[1] is b[1]  # no rebuild, no host->device copy per forward
+    assert a[0].dtype == torch.int32 and a[0].tolist() == [[5, 7], [3, 4]] and a[1].tolist() == [0, 35]
+    assert a[0]._alo_total == 47 and a[0]._alo_shapes == [(5, 7), (3, 4)]
+    assert _level_geometry(((5, 7),), torch.device("cpu"))[0] is not a[0]
+
+
+def test_joiner_skips_requested_positional_encodings():
+    import aloscene
+    from alonet.deformable_detr.backbone import Backbone, Joiner
+    from alonet.transformers import PositionEmbeddingSine
+
+    torch.manual_seed(0)
+    joiner = Joiner(Backbone("resnet50", False, True, False), PositionEmbeddingSine(128, normalize=True, center=True)).eval()
+    frames = aloscene.Frame.batch_list([aloscene.Frame(torch.rand(3, 64, 96) * 255).norm_resnet()])
+    with torch.no_grad():
+        feats, pos = joiner(frames, skip_pos_levels=(0,))
+        feats_all, pos_all = joiner(frames)
+    assert pos[0] is None and all(p is not None for p in pos[1:]) and len(feats) == len(feats_all) == 4
+    assert all(torch.equal(a, b) for a, b in zip(pos[1:], pos_all[1:])) and pos_all[0].shape[-2:] == feats_all[0][0].shape[-2:]
+
+
+def test_cached_derived_weights_follow_parameter_updates():
+    from alonet.raft.update import _cached
+
+    lin = torch.nn.Linear(3, 2)
+    first = _cached(lin, "_double", (lin.weight,), lambda: 2 * lin.weight)
+    assert _cached(lin, "_double", (lin.weight,), lambda: 2 * lin.weight) is first
+    with torch.no_grad():
+        lin.weight.add_(1.0)  # in-place update bumps the version counter
+    second = _cached(lin, "_double", (lin.weight,), lambda: 2 * lin.weight)
+    assert second is not first and torch.equal(second, 2 * lin.weight)
