@@ -66,6 +66,8 @@ def _declare(lib):
     lib.alo_gru_gate.argtypes = [vp] * 4 + [ip] * 3 + [c.c_long, c.c_long, vp]
     lib.alo_gru_update.restype = ip
     lib.alo_gru_update.argtypes = [vp] * 5 + [ip] * 3 + [c.c_long, vp]
+    lib.alo_pos_sine_flat.restype = ip
+    lib.alo_pos_sine_flat.argtypes = [vp] * 7 + [ip] * 6 + [c.c_float, c.c_float, ip, vp]
     lib.alo_add_layernorm.restype = ip
     lib.alo_add_layernorm.argtypes = [vp] * 7 + [c.c_long, ip, c.c_float, ip, vp]
     lib.alo_bias_act.restype = ip
@@ -489,3 +491,26 @@ def gru_update_(q, bias_q, zr, hx, C, net=None):
     with torch.cuda.device(q.device), _timed(f"gru_update/C={C}", 4.0 * B * C * H * W * (4 + (net is not None))):
         _check(lib().alo_gru_update(_ptr(q), _ptr(bias_q), _ptr(zr), _ptr(hx), None if net is None else _ptr(net), B, C,
                                     H * W, hx.stride(0), _stream(q.device)))
+
+
+def pos_sine_flat(mask_flatten, spatial_shapes, level_start_index, dim_t, level_embed, normalize, center, scale, dtype,
+                  eps=1e-6):
+    """Sine positional encoding of the flattened pyramid + level embedding -> (B, S, 2F) in ``dtype`` (two launches).
+    ``mask_flatten`` (B, S) bool, ``dim_t`` (F,) fp32, ``level_embed`` (L, 2F) or None."""
+    B, S = mask_flatten.shape
+    L, F = spatial_shapes.shape[0], dim_t.numel()
+    if mask_flatten.dtype != torch.bool or dim_t.dtype != torch.float32:
+        raise RuntimeError("pos_sine_flat: mask must be bool and dim_t float32")
+    mask_flatten, dim_t = mask_flatten.contiguous(), dim_t.contiguous()
+    if level_embed is not None:
+        level_embed = level_embed.to(dtype).contiguous()
+        if tuple(level_embed.shape) != (L, 2 * F):
+            raise RuntimeError("pos_sine_flat: level_embed must be (L, 2 * num_pos_feats)")
+    out = torch.empty((B, S, 2 * F), dtype=dtype, device=mask_flatten.device)
+    work = torch.empty((B, S, 2), dtype=torch.float32, device=mask_flatten.device)
+    with torch.cuda.device(out.device), _timed(f"pos_sine_flat/S={S}", out.element_size() * out.numel()):
+        _check(lib().alo_pos_sine_flat(_ptr(mask_flatten), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(dim_t),
+                                       None if level_embed is None else _ptr(level_embed), _ptr(out), _ptr(work), B, S, L, F,
+                                       1 if normalize else 0, 1 if center else 0, float(scale), float(eps),
+                                       _DTYPE_CODE[dtype], _stream(out.device)))
+    return out

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+import alo_hip
 import aloscene
 from alonet.common import load_weights
 from alonet.detr.misc import assert_and_export_onnx
@@ -129,8 +130,13 @@ class DeformableDETR(nn.Module):
         if "is_tracing" not in kwargs:  # the pure-torch export branch may run anywhere; the HIP op may not
             assert next(self.parameters()).is_cuda, "DeformableDETR cannot run on CPU (due to MSdeformable op)"
         frame_masks = frames.mask.as_tensor()
-        # the stride-4 positional encoding is only ever an output (bb_lvl0_pos_outputs), never an input of the transformer
-        features, pos = self.backbone(frames, skip_pos_levels=() if self.return_bb_outputs else (0,), **kwargs)
+        # the stride-4 positional encoding is only ever an output (bb_lvl0_pos_outputs), never an input of the transformer;
+        # at inference the others are produced by the transformer itself, flattened, in one pass (alo_pos_sine_flat)
+        lazy_pos = (not self.return_bb_outputs and "is_tracing" not in kwargs and not self.training
+                    and isinstance(self.backbone[1], PositionEmbeddingSine) and self.backbone[1].num_pos_feats % 4 == 0
+                    and alo_hip.fusable(frames.as_tensor(), self.transformer.level_embed))
+        skip = tuple(range(len(self.backbone.num_channels))) if lazy_pos else (() if self.return_bb_outputs else (0,))
+        features, pos = self.backbone(frames, skip_pos_levels=skip, **kwargs)
 
         srcs, masks = [], []
         for lvl, (src, mask) in enumerate(features[1:]):
@@ -139,9 +145,11 @@ class DeformableDETR(nn.Module):
         for lvl in range(len(srcs), self.num_feature_levels):  # extra, coarser levels
             src = self.input_proj[lvl](features[-1][0] if lvl == len(features) - 1 else srcs[-1])
             mask = F.interpolate(frame_masks.float(), size=src.shape[-2:]).to(torch.bool)
-            pos.append(self.backbone[1]((src, mask)).to(src.dtype))
+            pos.append(None if lazy_pos else self.backbone[1]((src, mask)).to(src.dtype))
             srcs.append(src)
             masks.append(mask[:, 0])
+        if lazy_pos:
+            kwargs = dict(kwargs, pos_encoder=self.backbone[1])
 
         transformer_out = self.transformer(srcs, masks, pos[1:], self.query_embed.weight, **kwargs)
         if self.return_bb_outputs:

@@ -303,17 +303,25 @@ class DeformableTransformer(nn.Module):
         assert query_embed is not None
         device = srcs[0].device
         src_flatten, mask_flatten, pos_flatten, shapes = [], [], [], []
+        pos_encoder = kwargs.pop("pos_encoder", None)  # set by DeformableDETR when it left the encodings to this module
         for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
             _, _, h, w = src.shape
             shapes.append((h, w))
             src_flatten.append(src.flatten(2).transpose(1, 2))
             mask_flatten.append(mask.flatten(1))
-            pos_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
+            if pos_embed is not None:
+                pos_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
         src_flatten = torch.cat(src_flatten, 1)
         mask_flatten = torch.cat(mask_flatten, 1)
-        pos_flatten = torch.cat(pos_flatten, 1).to(src_flatten.dtype)
         spatial_shapes, level_start_index = _level_geometry(tuple(shapes), device)
         sizes = [h * w for h, w in shapes]
+        if pos_flatten:
+            pos_flatten = torch.cat(pos_flatten, 1).to(src_flatten.dtype)
+        else:
+            # inference: sine encoding of all levels + level embedding in one HIP pass, straight into the flattened layout
+            pos_flatten = alo_hip.pos_sine_flat(mask_flatten, spatial_shapes, level_start_index, pos_encoder.dim_t(device),
+                                                self.level_embed, pos_encoder.normalize, pos_encoder.center,
+                                                pos_encoder.scale, src_flatten.dtype)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, pos_flatten, mask_flatten,

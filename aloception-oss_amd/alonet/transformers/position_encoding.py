@@ -21,6 +21,15 @@ class PositionEmbeddingSine(nn.Module):
         self.scale = 2 * math.pi if scale is None else scale
         self.center = center
 
+    def dim_t(self, device):
+        """``temperature ** (2 * (i // 2) / num_pos_feats)`` for i < num_pos_feats (fp32, cached per device)."""
+        cache = self.__dict__.setdefault("_dim_t", {})
+        key = str(device)
+        if key not in cache:
+            idx = torch.arange(self.num_pos_feats, dtype=torch.float32, device=device)
+            cache[key] = self.temperature ** (2 * torch.div(idx, 2, rounding_mode="floor") / self.num_pos_feats)
+        return cache[key]
+
     def forward(self, ftmap_mask):
         """``ftmap_mask = (feature_map (B,C,H,W), mask (B,1,H,W))``, mask true/1 on padding."""
         ft_maps, mask = ftmap_mask
@@ -34,8 +43,7 @@ class PositionEmbeddingSine(nn.Module):
             eps = 1e-6
             y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
             x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
-        idx = torch.arange(self.num_pos_feats, dtype=torch.float32, device=ft_maps.device)
-        dim_t = self.temperature ** (2 * torch.div(idx, 2, rounding_mode="floor") / self.num_pos_feats)
+        dim_t = self.dim_t(ft_maps.device)
 
         def expand(embed):  # even frequencies -> sin, odd -> cos, interleaved
             p = embed[..., None] / dim_t

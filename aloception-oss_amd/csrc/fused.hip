@@ -234,6 +234,67 @@ gru_update_kernel(const float* q, const float* __restrict__ bias_q, const float*
     }
 }
 
+// ---- sine positional encoding of the flattened pyramid (alonet/transformers/position_encoding.py:29-72) ---------------------
+// Pass 1: per (level, image) the cumulative count of un-padded pixels along y and along x, centred / normalised the way the
+// module does it, as (ey, ex) per pixel.  One thread walks one column (then one row): maps are at most a few hundred wide.
+__global__ void __launch_bounds__(kThreads)
+pos_prefix_kernel(const unsigned char* __restrict__ mask, const int32_t* __restrict__ shapes,
+                  const int32_t* __restrict__ lstart, float* __restrict__ emb, int S, int normalize, int center,
+                  float scale, float eps) {
+    const int l = blockIdx.x, b = blockIdx.y;
+    const int H = shapes[2 * l], W = shapes[2 * l + 1], start = lstart[l];
+    const unsigned char* mk = mask + (size_t)b * S + start;
+    float* e = emb + ((size_t)b * S + start) * 2;
+    const float shift = (normalize && center) ? 0.5f : 0.0f;
+    for (int x = threadIdx.x; x < W; x += kThreads) {
+        float cum = 0.f;
+        for (int y = 0; y < H; ++y) cum += mk[y * W + x] ? 0.f : 1.f;
+        const float denom = (cum - shift) + eps;  // y_embed[:, -1:, :] + eps
+        float run = 0.f;
+        for (int y = 0; y < H; ++y) {
+            run += mk[y * W + x] ? 0.f : 1.f;
+            e[(y * W + x) * 2] = normalize ? (run - shift) / denom * scale : run;
+        }
+    }
+    for (int y = threadIdx.x; y < H; y += kThreads) {
+        float cum = 0.f;
+        for (int x = 0; x < W; ++x) cum += mk[y * W + x] ? 0.f : 1.f;
+        const float denom = (cum - shift) + eps;
+        float run = 0.f;
+        for (int x = 0; x < W; ++x) {
+            run += mk[y * W + x] ? 0.f : 1.f;
+            e[(y * W + x) * 2 + 1] = normalize ? (run - shift) / denom * scale : run;
+        }
+    }
+}
+
+// Pass 2: out[b, s, c] = (c < F ? f(ey) : f(ex)) + level_embed[level(s), c],  f = sin on even frequencies, cos on odd ones,
+// argument = embed / dim_t[c mod F].  4 channels per thread.
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+pos_generate_kernel(const float* __restrict__ emb, const float* __restrict__ dim_t, const T* __restrict__ level_embed,
+                    const int32_t* __restrict__ lstart, T* __restrict__ out, long n4, int S, int L, int F) {
+    const int C = 2 * F, c4 = C / 4;
+    const long stride = (long)gridDim.x * kThreads;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+        const long pix = i / c4;                 // b * S + s
+        const int c0 = (int)(i - pix * c4) * 4;
+        const int s = (int)(pix % S);
+        int l = 0;
+        while (l + 1 < L && s >= lstart[l + 1]) ++l;
+        const float e = emb[pix * 2 + (c0 < F ? 0 : 1)];
+        float le[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+        if (level_embed != nullptr) load4(level_embed + (size_t)l * C + c0, le);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int f = (c0 + k) % F;
+            const float p = e / dim_t[f];
+            v[k] = ((f & 1) ? cosf(p) : sinf(p)) + le[k];
+        }
+        store4(out + pix * C + c0, v);
+    }
+}
+
 template <typename K>
 int launch(K kernel, unsigned blocks, hipStream_t stream, const char* what, void** args) {
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kernel), dim3(blocks), dim3(kThreads), args, 0, stream);
@@ -369,4 +430,28 @@ extern "C" int alo_gru_update(const float* q, const float* bias_q, const float* 
     int hw4 = HW / 4;
     void* args[] = {&q, &bias_q, &zr, &h, &net, &n4, &C, &hw4, &h_batch_stride};
     return launch(gru_update_kernel, stream_blocks(n4), static_cast<hipStream_t>(stream), "alo_gru_update", args);
+}
+
+extern "C" int alo_pos_sine_flat(const void* padding_mask, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                 const float* dim_t, const void* level_embed, void* out, float* workspace, int B, int S,
+                                 int L, int num_pos_feats, int normalize, int center, float scale, float eps, int dtype,
+                                 void* stream) {
+    ALO_REQUIRE(padding_mask && spatial_shapes && level_start_index && dim_t && out && workspace, ALO_ERR_INVALID_ARGUMENT,
+                "alo_pos_sine_flat: null pointer argument");
+    ALO_REQUIRE(B > 0 && S > 0 && L > 0 && num_pos_feats > 0 && num_pos_feats % 4 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_pos_sine_flat: sizes must be positive and num_pos_feats a multiple of 4 (B=%d S=%d L=%d F=%d)", B, S, L,
+                num_pos_feats);
+    ALO_REQUIRE(dtype == ALO_F32 || dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_pos_sine_flat: dtype %d", dtype);
+    ALO_REQUIRE((((uintptr_t)out | (uintptr_t)level_embed) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_pos_sine_flat: out / level_embed must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        void* args[] = {&padding_mask, &spatial_shapes, &level_start_index, &workspace, &S, &normalize, &center, &scale, &eps};
+        hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(pos_prefix_kernel), dim3(L, B), dim3(kThreads), args, 0, st);
+        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_pos_sine_flat: %s", hipGetErrorString(e));
+    }
+    long n4 = (long)B * S * (2 * num_pos_feats) / 4;
+    void* args[] = {&workspace, &dim_t, &level_embed, &level_start_index, &out, &n4, &S, &L, &num_pos_feats};
+    if (dtype == ALO_F32) return launch(pos_generate_kernel<float>, stream_blocks(n4), st, "alo_pos_sine_flat", args);
+    return launch(pos_generate_kernel<bf16_t>, stream_blocks(n4), st, "alo_pos_sine_flat", args);
 }

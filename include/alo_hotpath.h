@@ -203,6 +203,18 @@ int alo_bias_act(const void* x, const void* bias, const void* residual, void* y,
                  int dtype, void* stream);
 
 /*
+ * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened
+ * (B, S, 2F) layout the encoder consumes, level embedding added: what PositionEmbeddingSine.forward + the
+ * `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` / cat of DeformableTransformer.forward compute with ~15 PyTorch
+ * kernels per level (alonet/transformers/position_encoding.py:29-72, deformable_transformer.py:562-577).
+ *   padding_mask (B, S) uint8/bool (1 on padding), dim_t (F,) fp32 = temperature ** (2 * (i // 2) / F),
+ *   level_embed (L, 2F) of `dtype` or NULL, out (B, S, 2F) of `dtype`, workspace B * S * 2 floats.  F % 4 == 0.
+ */
+int alo_pos_sine_flat(const void* padding_mask, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                      const float* dim_t, const void* level_embed, void* out, float* workspace, int B, int S, int L,
+                      int num_pos_feats, int normalize, int center, float scale, float eps, int dtype, void* stream);
+
+/*
  * ---- Extensions: elementwise glue of RAFT's update block (alonet/raft/update.py:27-33,83-101), fp32, NCHW ------------------
  * One pass each; H*W % 4 == 0; pointers 16-byte aligned.  The convolutions stay on MIOpen and are called WITHOUT bias.
  *

@@ -117,3 +117,35 @@ def test_raft_update_block_fused_glue_matches_stock_ops():
     with alo_hip.LaunchTimer() as t2, torch.no_grad():
         blk(*(t[..., :11, :17].contiguous() for t in (net, inp, corr, flow)))  # 11 * 17 = 187
     assert not t2.summary()
+
+
+@pytest.mark.parametrize("dtype,normalize,center", [(torch.float32, True, True), (torch.float32, True, False),
+                                                     (torch.float32, False, False), (torch.bfloat16, True, True)])
+def test_pos_sine_flat_matches_the_module_plus_level_embed(dtype, normalize, center):
+    """alo_pos_sine_flat against PositionEmbeddingSine per level -> flatten -> + level_embed -> cat (the stock chain)."""
+    from alonet.transformers import PositionEmbeddingSine
+
+    torch.manual_seed(1)
+    shapes = [(13, 21), (7, 11), (4, 6), (2, 3)]
+    B, F = 3, 128
+    enc = PositionEmbeddingSine(F, normalize=normalize, center=center)
+    level_embed = torch.randn(len(shapes), 2 * F, device=DEV).to(dtype).float()  # a parameter of the model's dtype
+    masks, want = [], []
+    for lvl, (h, w) in enumerate(shapes):
+        m = torch.zeros(B, 1, h, w, dtype=torch.bool, device=DEV)
+        m[1, :, :, (2 * w) // 3:] = True   # right padding
+        m[2, :, h // 2:, :] = True         # bottom padding
+        masks.append(m)
+        pos = enc((torch.empty(B, 1, h, w, device=DEV), m))
+        want.append(pos.flatten(2).transpose(1, 2) + level_embed[lvl].view(1, 1, -1))
+    want = torch.cat(want, 1)
+    mask_flat = torch.cat([m[:, 0].flatten(1) for m in masks], 1)
+    sh = torch.tensor(shapes, dtype=torch.int32, device=DEV)
+    start = torch.tensor([0] + list(torch.tensor([h * w for h, w in shapes]).cumsum(0)[:-1]), dtype=torch.int32, device=DEV)
+    got = alo_hip.pos_sine_flat(mask_flat, sh, start, enc.dim_t(torch.device(DEV)), level_embed, normalize, center, enc.scale, dtype)
+    assert got.shape == want.shape and got.dtype == dtype
+    if dtype == torch.float32:
+        # sin / cos of arguments up to 2*pi (un-normalised: up to the map size): fp32 rounding of the argument only
+        assert (got - want).abs().max().item() <= (3e-6 if normalize else 3e-5)
+    else:
+        assert ((got.float() - want).abs() <= want.abs() * 2.0 ** -8 + 1e-6).all()
