@@ -20,6 +20,26 @@ if "--raft" in sys.argv:
     def step():
         with torch.no_grad():
             return model.inference(model(f1, f2, iters=32, only_last=True), only_last=True)
+elif "--train" in sys.argv:
+    import aloscene
+    from alonet.deformable_detr import DeformableDetrR50
+    from alonet.deformable_detr.training import build_criterion, configure_optimizers, training_step
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=True, device=dev).train()
+    gen = torch.Generator().manual_seed(777)
+    names = [f"class_{i}" for i in range(91)]
+    tframes = []
+    for _ in range(4):
+        lab = aloscene.Labels(torch.randint(0, 91, (10,), generator=gen).float(), encoding="id", labels_names=names)
+        bx = aloscene.BoundingBoxes2D(torch.cat([torch.rand(10, 2, generator=gen) * 0.6 + 0.2,
+                                                 torch.rand(10, 2, generator=gen) * 0.3 + 0.05], 1), "xcyc", False, labels=lab)
+        tframes.append(aloscene.Frame(torch.rand(3, 800, 1333, generator=gen) * 255, normalization="255", boxes2d=bx).norm_resnet())
+    tframes = aloscene.Frame.batch_list(tframes).to(dev)
+    crit, opt = build_criterion(), configure_optimizers(model)
+
+    def step():
+        return training_step(model, crit, opt, tframes)[0].item()
 else:
     model = bench.build_detector(dev, torch.bfloat16)
     frames = bench.detection_inputs(8, 0, dev, torch.bfloat16)
@@ -29,11 +49,11 @@ else:
             return model.inference(model(frames))
 
 
-for _ in range(2 if "--raft" in sys.argv else 3):
+for _ in range(2 if ("--raft" in sys.argv or "--train" in sys.argv) else 3):
     step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    for _ in range(1 if "--raft" in sys.argv else 3):
+    for _ in range(1 if ("--raft" in sys.argv or "--train" in sys.argv) else 3):
         step()
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=40, max_shapes_column_width=70))
