@@ -135,6 +135,7 @@ class LaunchTimer:
 
     def __init__(self):
         self.records = []
+        self.relaunch = {}  # tag -> closure that enqueues the tag's most recent launch again (same buffers)
 
     def __enter__(self):
         global _timer
@@ -144,6 +145,21 @@ class LaunchTimer:
     def __exit__(self, *exc):
         global _timer
         _timer = self._prev
+
+    def replay_ms(self, tag, reps=20):
+        """Average duration of ``reps`` back-to-back re-launches of the last launch recorded under ``tag`` (same device
+        buffers).  An event pair around ONE launch also measures the dispatch gap either side of it (tens of microseconds
+        on ROCm); a back-to-back train does not, and agrees with rocprofv3's per-kernel average."""
+        fn = self.relaunch[tag]
+        fn()
+        torch.cuda.synchronize()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(reps):
+            fn()
+        stop.record()
+        torch.cuda.synchronize()
+        return start.elapsed_time(stop) / reps
 
     def summary(self):
         torch.cuda.synchronize()
@@ -165,8 +181,8 @@ _timer = None
 
 
 class _timed:
-    def __init__(self, tag, nbytes=0.0, flops=0.0):
-        self.tag, self.nbytes, self.flops = tag, nbytes, flops
+    def __init__(self, tag, nbytes=0.0, flops=0.0, relaunch=None):
+        self.tag, self.nbytes, self.flops, self.relaunch = tag, nbytes, flops, relaunch
 
     def __enter__(self):
         if _timer is not None:
@@ -179,6 +195,8 @@ class _timed:
         if _timer is not None:
             self.stop.record()
             _timer.records.append((self.tag, self.start, self.stop, self.nbytes, self.flops))
+            if self.relaunch is not None:
+                _timer.relaunch[self.tag] = self.relaunch
 
 
 def msda_forward_bytes(N, S, M, D, L, Lq, P, elem, loc_elem=4):
@@ -309,11 +327,14 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     out = torch.empty((N, Lq, M * D), dtype=value_hm.dtype, device=value_hm.device)
     e = value_hm.element_size()
     nbytes = e * (N * S * M * D + N * Lq * M * D + N * Lq * M * L * P * 3) + 4 * reference_points.numel()
-    with torch.cuda.device(value_hm.device), _timed(f"msda_fwd_fused/Lq={Lq}", nbytes):
+    def launch():
         _check(lib().alo_msda_forward_fused_hm(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
                                                _ptr(sampling_offsets), _ptr(attn_logits), _ptr(reference_points),
                                                _ptr(out), N, S, M, D, L, Lq, P, ref_dim, _DTYPE_CODE[value_hm.dtype],
                                                _stream(value_hm.device)))
+
+    with torch.cuda.device(value_hm.device), _timed(f"msda_fwd_fused/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
+        launch()
     return out
 
 
