@@ -176,11 +176,14 @@ corr_gemm_kernel(const GemmArgs g) {
             if (i < g.HW) {
                 float* p = outp + (long)i * L.n + jc;
                 const float v0 = acc[ti][0][r] * g.scale, v1 = acc[ti][1][r] * g.scale;
+                // the volume is written once and not read again by this kernel: non-temporal stores keep the 4.4 GB stream
+                // from being read for ownership / parked in the L2
                 if (pair_ok && jc + 1 < L.n) {
-                    *reinterpret_cast<float2*>(p) = float2{v0, v1};
+                    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+                    __builtin_nontemporal_store(f32x2_t{v0, v1}, reinterpret_cast<f32x2_t*>(p));
                 } else {
-                    if (jc < L.n) p[0] = v0;
-                    if (jc + 1 < L.n) p[1] = v1;
+                    if (jc < L.n) __builtin_nontemporal_store(v0, p);
+                    if (jc + 1 < L.n) __builtin_nontemporal_store(v1, p + 1);
                 }
             }
         }
