@@ -258,12 +258,30 @@ corr_lookup_kernel(const LookupArgs a) {
                     ty = iy - (float)(yb + trow);
                 }
                 if (ry >= 0 && ry < h && xb + COLS > 0 && xb < w) {
-                    const float* src = a.lvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
+                    // the strip's COLS taps as 16-byte loads from an arbitrary 4-byte aligned start instead of COLS scalar
+                    // loads: every load instruction of a wave touches 64 different lines here (one strip per lane, strips
+                    // 4*h*w bytes apart), so the instruction count is what the L1 is charged for.  Strips that hang off the
+                    // left edge of the map or would read past the batch item's slab take the scalar path (rare).
+                    const long e0 = (long)i * h * w + (long)ry * w + xb;  // element offset of tap 0 inside the slab
                     float v[COLS];
+                    constexpr int NV = (COLS + 3) / 4;
+                    if (xb >= 0 && e0 + 4 * NV <= (long)a.HW * h * w) {
+                        const float* src = a.lvl[l] + (long)b * a.HW * ((long)h * w) + e0;
+                        f32x4 raw[NV];
 #pragma unroll
-                    for (int k = 0; k < COLS; ++k) {
-                        const int x = xb + k;
-                        v[k] = (x >= 0 && x < w) ? src[x] : 0.f;
+                        for (int j = 0; j < NV; ++j) {
+                            typedef f32x4 __attribute__((aligned(4))) f32x4_u;  // 4-byte aligned vector load
+                            raw[j] = *reinterpret_cast<const f32x4_u*>(src + 4 * j);
+                        }
+#pragma unroll
+                        for (int k = 0; k < COLS; ++k) v[k] = (xb + k < w) ? raw[k / 4][k % 4] : 0.f;
+                    } else {
+                        const float* src = a.lvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
+#pragma unroll
+                        for (int k = 0; k < COLS; ++k) {
+                            const int x = xb + k;
+                            v[k] = (x >= 0 && x < w) ? src[x] : 0.f;
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < WIN; ++k) {
