@@ -704,13 +704,28 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                         }
                     }
                 }
+                // channel sums of the group: fp32 groups of 16 / 32 lanes reduce on DPP (row rotations + one row broadcast,
+                // pure VALU), everything else through wave shuffles; `writer` is a lane that ends up with the total
+                int writer = 0;
+                if constexpr (std::is_same<CT, float>::value && (G == 32 || G == 16)) {
+                    s_attn = row16_sum(s_attn);
+                    s_w = row16_sum(s_w);
+                    s_h = row16_sum(s_h);
+                    if constexpr (G == 32) {  // second row of the group += lane 15 of its first row
+                        s_attn += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s_attn), 0x142, 0xa, 0xf, false));
+                        s_w += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s_w), 0x142, 0xa, 0xf, false));
+                        s_h += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s_h), 0x142, 0xa, 0xf, false));
+                        writer = 16;
+                    }
+                } else {
 #pragma unroll
-                for (int off = G / 2; off > 0; off >>= 1) {
-                    s_attn += __shfl_xor(s_attn, off, 64);
-                    s_w += __shfl_xor(s_w, off, 64);
-                    s_h += __shfl_xor(s_h, off, 64);
+                    for (int off = G / 2; off > 0; off >>= 1) {
+                        s_attn += __shfl_xor(s_attn, off, 64);
+                        s_w += __shfl_xor(s_w, off, 64);
+                        s_h += __shfl_xor(s_h, off, 64);
+                    }
                 }
-                if (live && lane == 0) {
+                if (live && lane == writer) {
                     const long g = (batch_pair0 + pair) * LP + s;
                     CT W = (CT)0, H = (CT)0;
                     if (d.lvl >= 0) { H = (CT)meta[d.lvl]; W = (CT)meta[kMaxLevels + d.lvl]; }

@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--raft-batch", type=int, default=4, help="frame pairs per GPU (flow)")
     ap.add_argument("--no-raft", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames in the bounded CPU sample")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the bounded CPU sample (~13 s on 32 threads)")
     ap.add_argument("--train-steps", type=int, default=0,
                     help="also time K training steps of DeformableDETR-R50 (BASELINE configs[3]: fp32, 4 frames per GPU, "
                          "DDP over RCCL when N > 1); off by default")
