@@ -1,4 +1,6 @@
 """Parity of the HIP multi-scale deformable attention (through the C ABI) with the golden vectors and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -328,7 +330,10 @@ def test_head_major_path_is_bit_identical_and_masks_padding(N, M, D, Lq, ref_dim
     assert torch.equal(alo_hip.value_head_major(value, None), value.permute(0, 2, 1, 3))
     got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
     want = alo_hip.msda_forward_fused(value.masked_fill(mask[..., None, None], 0), shapes, start, offsets, logits, ref)
-    assert torch.equal(got, want)
+    if os.environ.get("ALO_MSDA_MFMA") == "0":  # tuning knob: the pixel-major call then runs the generic (VALU) kernel
+        assert ((got.float() - want.float()).abs() <= want.float().abs() * 2.0 ** -7 + 1e-6).all()
+    else:
+        assert torch.equal(got, want)
 
 
 def test_head_major_rejects_other_shapes():
