@@ -66,6 +66,8 @@ def _declare(lib):
     lib.alo_gru_gate.argtypes = [vp] * 4 + [ip] * 3 + [c.c_long, c.c_long, vp]
     lib.alo_gru_update.restype = ip
     lib.alo_gru_update.argtypes = [vp] * 5 + [ip] * 3 + [c.c_long, vp]
+    lib.alo_linear_shortk.restype = ip
+    lib.alo_linear_shortk.argtypes = [vp] * 4 + [c.c_long, ip, ip, ip, ip, vp]
     lib.alo_pos_sine_flat.restype = ip
     lib.alo_pos_sine_flat.argtypes = [vp] * 7 + [ip] * 6 + [c.c_float, c.c_float, ip, vp]
     lib.alo_add_layernorm.restype = ip
@@ -133,9 +135,10 @@ class LaunchTimer:
     the algorithmic byte / flop counts are the SURVEY.md section 8(d) formulas evaluated on the actual launch shape.
     """
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []
         self.relaunch = {}  # tag -> closure that enqueues the tag's most recent launch again (same buffers)
+        self.only = only    # tag prefix: time just these launches (an event pair per launch is not free on the GPU either)
 
     def __enter__(self):
         global _timer
@@ -185,14 +188,15 @@ class _timed:
         self.tag, self.nbytes, self.flops, self.relaunch = tag, nbytes, flops, relaunch
 
     def __enter__(self):
-        if _timer is not None:
+        self.on = _timer is not None and (_timer.only is None or self.tag.startswith(_timer.only))
+        if self.on:
             self.start = torch.cuda.Event(enable_timing=True)
             self.stop = torch.cuda.Event(enable_timing=True)
             self.start.record()
         return self
 
     def __exit__(self, *exc):
-        if _timer is not None:
+        if self.on:
             self.stop.record()
             _timer.records.append((self.tag, self.start, self.stop, self.nbytes, self.flops))
             if self.relaunch is not None:
@@ -535,3 +539,40 @@ def pos_sine_flat(mask_flatten, spatial_shapes, level_start_index, dim_t, level_
                                        1 if normalize else 0, 1 if center else 0, float(scale), float(eps),
                                        _DTYPE_CODE[dtype], _stream(out.device)))
     return out
+
+
+# ---- short-K linear layers on the streaming MFMA kernel (alo_linear_shortk) -----------------------------------------------------
+def linear_shortk_supported(x, weight):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] in (64, 128, 256)
+            and weight.dim() == 2 and weight.shape[1] == x.shape[-1] and weight.shape[0] % 64 == 0)
+
+
+def linear_shortk(x, weight, bias=None, relu=False):
+    """``act(x @ weight.T + bias)`` over the last dim (64 / 128 / 256) of a bf16 ``x``; weight (N, K), N % 64 == 0."""
+    if not linear_shortk_supported(x, weight):
+        raise RuntimeError("linear_shortk: needs bf16 CUDA tensors, K in (64, 128, 256) and N % 64 == 0")
+    N, K = weight.shape
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
+    M = x2.shape[0]
+    if M:
+        with torch.cuda.device(x.device), _timed(f"linear_shortk/N={N},K={K}", 2.0 * (x2.numel() + y.numel()), 2.0 * M * N * K):
+            _check(lib().alo_linear_shortk(_ptr(x2), _ptr(weight.contiguous()), None if bias is None else _ptr(bias.contiguous()),
+                                           _ptr(y), M, N, K, 1 if relu else 0, ALO_BF16, _stream(x.device)))
+    return y.view(*x.shape[:-1], N)
+
+
+def linear_auto(x, weight, bias=None, relu=False):
+    """Inference-time ``act(F.linear(x, weight, bias))``: the streaming MFMA kernel when the shape allows it (bf16, K in
+    {64, 128, 256}, N % 64 == 0), otherwise the stock GEMM with the bias / ReLU epilogue."""
+    if linear_shortk_supported(x, weight) and (bias is None or bias.dtype == x.dtype):
+        return linear_shortk(x, weight, bias, relu)
+    x2 = x.reshape(-1, x.shape[-1])
+    if bias is not None:
+        y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False) if relu else torch.addmm(bias, x2, weight.t())
+    else:
+        y = torch.mm(x2, weight.t())
+        y = torch.relu_(y) if relu else y
+    return y.view(*x.shape[:-1], weight.shape[0])

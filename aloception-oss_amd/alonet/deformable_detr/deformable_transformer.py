@@ -48,11 +48,12 @@ def _add_norm(norm, x, residual, pos=None):
 
 
 def _ffn(linear1, activation, linear2, x):
-    """``linear2(act(linear1(x)))``; for ReLU the activation rides in the first GEMM's epilogue (hipBLASLt RELU_BIAS via
-    ``torch._addmm_activation``) instead of a separate pass over the (rows, d_ffn) intermediate."""
+    """``linear2(act(linear1(x)))``; for ReLU the activation rides in the first GEMM's epilogue (alo_linear_shortk when
+    d_model is 64 / 128 / 256 and the tensors are bf16, else hipBLASLt's RELU_BIAS via ``torch._addmm_activation``) instead
+    of a separate pass over the (rows, d_ffn) intermediate."""
     if activation is F.relu and linear1.bias is not None:
-        h = torch._addmm_activation(linear1.bias, x.reshape(-1, x.shape[-1]), linear1.weight.t(), use_gelu=False)
-        return linear2(h).view(*x.shape[:-1], -1)
+        h = alo_hip.linear_auto(x, linear1.weight, linear1.bias, relu=True)
+        return alo_hip.linear_auto(h, linear2.weight, linear2.bias)
     return linear2(activation(linear1(x)))
 
 

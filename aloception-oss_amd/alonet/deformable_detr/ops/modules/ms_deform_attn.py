@@ -97,12 +97,14 @@ class MSDeformAttn(nn.Module):
             raise ValueError(
                 "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1])
             )
-        value = self.value_proj(input_flatten)
-        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
-        logits = self.attention_weights(query).view(N, Lq, M, L * P)
         needs_grad = torch.is_grad_enabled() and any(
-            t.requires_grad for t in (value, offsets, logits, reference_points))
-        fused = "is_tracing" not in kwargs and not needs_grad and self.fused_prologue
+            t.requires_grad for t in (query, input_flatten, reference_points, self.value_proj.weight))
+        fused = "is_tracing" not in kwargs and not needs_grad and self.fused_prologue and query.is_cuda
+        # inference: the four K = d_model linears go through the streaming MFMA kernel when it fits (bf16, d_model = 256)
+        proj = (lambda lin, t: alo_hip.linear_auto(t, lin.weight, lin.bias)) if fused else (lambda lin, t: lin(t))
+        value = proj(self.value_proj, input_flatten)
+        offsets = proj(self.sampling_offsets, query).view(N, Lq, M, L, P, 2)
+        logits = proj(self.attention_weights, query).view(N, Lq, M, L * P)
 
         if fused and alo_hip.head_major_supported(value.view(N, S, M, self.d_model // M), L, P):
             # inference, DETR-family shape: padding is zeroed while the projection's output is re-laid head-major (one pass
@@ -110,7 +112,7 @@ class MSDeformAttn(nn.Module):
             value = alo_hip.value_head_major(value.view(N, S, M, self.d_model // M), input_padding_mask)
             output = alo_hip.msda_forward_fused_hm(value, input_spatial_shapes, input_level_start_index,
                                                    offsets.contiguous(), logits.contiguous(), reference_points)
-            return self.output_proj(output)
+            return proj(self.output_proj, output)
 
         if input_padding_mask is not None:
             if needs_grad:
@@ -125,7 +127,7 @@ class MSDeformAttn(nn.Module):
             # inference: softmax + sampling-location arithmetic happen inside the kernel's descriptor stage
             output = alo_hip.msda_forward_fused(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                                 offsets.contiguous(), logits.contiguous(), reference_points)
-            return self.output_proj(output)
+            return proj(self.output_proj, output)
 
         offsets = offsets.to(geo)
         weights = F.softmax(logits.to(geo), -1).view(N, Lq, M, L, P)

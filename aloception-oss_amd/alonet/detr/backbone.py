@@ -45,13 +45,8 @@ def conv1x1_as_gemm(x, weight, bias, stride=(1, 1), relu=False):
         x = x[:, :, ::stride[0], ::stride[1]]
     n, cin, h, w_ = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(-1, cin)  # a view for stride 1 (NHWC rows are contiguous), one gather otherwise
-    wt = weight.reshape(weight.shape[0], cin).t()
-    if bias is not None:
-        out = torch._addmm_activation(bias, rows, wt, use_gelu=False) if relu else torch.addmm(bias, rows, wt)
-    else:
-        out = torch.mm(rows, wt)
-        if relu:
-            out = torch.relu_(out)
+    # few input channels (64 / 128 / 256, bf16): the streaming MFMA kernel; otherwise hipBLASLt with the epilogue
+    out = alo_hip.linear_auto(rows, weight.reshape(weight.shape[0], cin), bias, relu)
     return out.view(n, h, w_, -1).permute(0, 3, 1, 2)
 
 

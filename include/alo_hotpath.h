@@ -203,6 +203,17 @@ int alo_bias_act(const void* x, const void* bias, const void* residual, void* y,
                  int dtype, void* stream);
 
 /*
+ * alo_linear_shortk: y (M, N) = act(x (M, K) @ weight (N, K)^T + bias), K in {64, 128, 256}, N % 64 == 0, bf16 with fp32
+ * accumulation, act = ReLU when relu != 0.  The short-K nn.Linear layers next to the op — value_proj, sampling_offsets,
+ * attention_weights, output_proj of MSDeformAttn (ms_deform_attn.py:56-59), the FFN's first layer — and the backbone's 1x1
+ * convolutions with K input channels over NHWC rows: memory-bound products; the weights stay in registers, x streams
+ * through once per 256 output columns, y is written in whole lines (v_mfma_f32_32x32x16_bf16).  bias (N,) bf16 or NULL.
+ * 16-byte aligned pointers.
+ */
+int alo_linear_shortk(const void* x, const void* weight, const void* bias, void* y, long M, int N, int K, int relu,
+                      int dtype, void* stream);
+
+/*
  * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened
  * (B, S, 2F) layout the encoder consumes, level embedding added: what PositionEmbeddingSine.forward + the
  * `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` / cat of DeformableTransformer.forward compute with ~15 PyTorch

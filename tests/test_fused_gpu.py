@@ -149,3 +149,33 @@ def test_pos_sine_flat_matches_the_module_plus_level_embed(dtype, normalize, cen
         assert (got - want).abs().max().item() <= (3e-6 if normalize else 3e-5)
     else:
         assert ((got.float() - want).abs() <= want.abs() * 2.0 ** -8 + 1e-6).all()
+
+
+@pytest.mark.parametrize("M,N,K,relu,with_bias", [(177784, 256, 256, False, True), (5000, 128, 256, False, True),
+                                                   (4099, 1024, 256, True, True), (33, 64, 64, True, False),
+                                                   (1, 320, 128, False, True), (777, 512, 128, True, True)])
+def test_linear_shortk_matches_fp32_matmul(M, N, K, relu, with_bias):
+    """alo_linear_shortk (weights resident in registers, bf16 MFMA, fp32 accumulation) against an fp32 matmul of the same
+    bf16 operands: only the final rounding to bf16 may differ."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.1).bfloat16()
+    b = torch.randn(N, device=DEV, generator=g).bfloat16() if with_bias else None
+    ref = x.float() @ w.float().t() + (b.float() if with_bias else 0)
+    ref = ref.relu() if relu else ref
+    got = alo_hip.linear_shortk(x, w, b, relu)
+    assert got.shape == (M, N) and got.dtype == torch.bfloat16
+    assert ((got.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 2e-5 * K ** 0.5).all()
+    assert alo_hip.linear_shortk_supported(x, w) and not alo_hip.linear_shortk_supported(x.float(), w.float())
+    # leading dims are kept, linear_auto picks the same kernel
+    got3 = alo_hip.linear_auto(x[: (M // 3) * 3].view(3, M // 3, K), w, b, relu) if M >= 3 else None
+    if got3 is not None:
+        assert torch.equal(got3.reshape(-1, N), got[: (M // 3) * 3])
+
+
+def test_linear_auto_falls_back_to_the_stock_gemm():
+    x = torch.randn(10, 1024, device=DEV).bfloat16()  # K = 1024: not a short-K problem
+    w, b = torch.randn(256, 1024, device=DEV).bfloat16() * 0.05, torch.randn(256, device=DEV).bfloat16()
+    with alo_hip.LaunchTimer() as t:
+        y = alo_hip.linear_auto(x, w, b, relu=True)
+    assert not t.summary() and (y.float() - torch.relu(x.float() @ w.float().t() + b.float())).abs().max().item() < 0.5
