@@ -47,6 +47,22 @@ def _add_norm(norm, x, residual, pos=None):
     return alo_hip.add_layernorm(x, residual, norm.weight, norm.bias, norm.eps, pos=pos)
 
 
+def _self_attention(mha, qk_in, v_in):
+    """Inference form of ``nn.MultiheadAttention(q = k = qk_in, v = v_in)`` on batch-first (B, L, E) tensors: the packed
+    input projection as two GEMMs (q and k share their input), ``scaled_dot_product_attention`` over the heads, the output
+    projection — no sequence-first transposes, projections on the short-K MFMA kernel when the shape allows."""
+    B, L, E = qk_in.shape
+    H = mha.num_heads
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    qk = alo_hip.linear_auto(qk_in, w[: 2 * E], None if b is None else b[: 2 * E])
+    v = alo_hip.linear_auto(v_in, w[2 * E:], None if b is None else b[2 * E:])
+    q, k = qk[..., :E], qk[..., E:]
+    heads = lambda t: t.reshape(B, L, H, E // H).transpose(1, 2)  # (B, H, L, E/H)
+    out = F.scaled_dot_product_attention(heads(q), heads(k), heads(v))
+    out = out.transpose(1, 2).reshape(B, L, E)
+    return alo_hip.linear_auto(out, mha.out_proj.weight, mha.out_proj.bias)
+
+
 def _ffn(linear1, activation, linear2, x):
     """``linear2(act(linear1(x)))``; for ReLU the activation rides in the first GEMM's epilogue (alo_linear_shortk when
     d_model is 64 / 128 / 256 and the tensors are bf16, else hipBLASLt's RELU_BIAS via ``torch._addmm_activation``) instead
@@ -176,8 +192,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def decoder_layer_forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                               tgt_key_padding_mask=None, src_padding_mask=None, **kwargs):
         q = k = self.with_pos_embed(tgt, query_pos)  # self-attention among the queries (sequence-first API)
-        tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
-                              key_padding_mask=tgt_key_padding_mask)[0].transpose(0, 1)
+        if _fused_ok(self, kwargs, tgt, query_pos) and tgt_key_padding_mask is None and self.self_attn._qkv_same_embed_dim:
+            tgt2 = _self_attention(self.self_attn, q, tgt)
+        else:
+            tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
+                                  key_padding_mask=tgt_key_padding_mask)[0].transpose(0, 1)
         if _fused_ok(self, kwargs, tgt, tgt2, query_pos):  # inference: residual + LayerNorm (+ query_pos) in one pass each
             if query_pos is None:
                 tgt = query = _add_norm(self.norm2, tgt2, tgt)

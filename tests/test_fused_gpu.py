@@ -179,3 +179,18 @@ def test_linear_auto_falls_back_to_the_stock_gemm():
     with alo_hip.LaunchTimer() as t:
         y = alo_hip.linear_auto(x, w, b, relu=True)
     assert not t.summary() and (y.float() - torch.relu(x.float() @ w.float().t() + b.float())).abs().max().item() < 0.5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-2)])
+def test_decoder_self_attention_fast_path_matches_multihead_attention(dtype, tol):
+    from alonet.deformable_detr.deformable_transformer import _self_attention
+
+    torch.manual_seed(2)
+    mha = torch.nn.MultiheadAttention(256, 8, dropout=0.1).to(DEV).to(dtype).eval()
+    tgt = torch.randn(3, 300, 256, device=DEV).to(dtype)
+    pos = torch.randn(3, 300, 256, device=DEV).to(dtype)
+    with torch.no_grad():
+        q = tgt + pos
+        want = mha(q.transpose(0, 1), q.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
+        got = _self_attention(mha, q, tgt)
+    assert got.shape == want.shape and (got.float() - want.float()).abs().max().item() <= tol
