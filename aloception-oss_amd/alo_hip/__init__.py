@@ -66,6 +66,10 @@ def _declare(lib):
     lib.alo_gru_gate.argtypes = [vp] * 4 + [ip] * 3 + [c.c_long, c.c_long, vp]
     lib.alo_gru_update.restype = ip
     lib.alo_gru_update.argtypes = [vp] * 5 + [ip] * 3 + [c.c_long, vp]
+    lib.alo_pack_mfma_b.restype = ip
+    lib.alo_pack_mfma_b.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.alo_ffn256.restype = ip
+    lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
     lib.alo_linear_shortk.argtypes = [vp] * 4 + [c.c_long, ip, ip, ip, ip, vp]
     lib.alo_pos_sine_flat.restype = ip
@@ -576,3 +580,42 @@ def linear_auto(x, weight, bias=None, relu=False):
         y = torch.mm(x2, weight.t())
         y = torch.relu_(y) if relu else y
     return y.view(*x.shape[:-1], weight.shape[0])
+
+
+def ffn256_supported(x, w1, w2):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and w1.dtype == torch.bfloat16
+            and w2.dtype == torch.bfloat16 and w1.dim() == 2 and w1.shape[1] == 256 and w1.shape[0] % 256 == 0
+            and tuple(w2.shape) == (256, w1.shape[0]))
+
+
+def pack_mfma_b(weight):
+    """(N, K) bf16 weight -> MFMA B-fragment order.  The packed copy rides on the weight tensor object itself, tagged
+    with the version counter it was made from: packed once per weight update, gone with the tensor."""
+    tag = (weight._version, weight.data_ptr())
+    hit = getattr(weight, "_alo_packed", None)
+    if hit is None or hit[0] != tag:
+        w = weight.detach().contiguous()
+        packed = torch.empty_like(w)
+        with torch.cuda.device(w.device):
+            _check(lib().alo_pack_mfma_b(_ptr(w), _ptr(packed), w.shape[0], w.shape[1], ALO_BF16, _stream(w.device)))
+        hit = (tag, packed)
+        weight._alo_packed = hit
+    return hit[1]
+
+
+def ffn256(x, w1, b1, w2, b2):
+    """``relu(x @ w1.T + b1) @ w2.T + b2`` over the last dim (= 256) of a bf16 ``x`` in one kernel (hidden width % 256 == 0)."""
+    if not ffn256_supported(x, w1, w2):
+        raise RuntimeError("ffn256: needs bf16 CUDA tensors, d_model = 256 and a hidden width that is a multiple of 256")
+    x2 = x.reshape(-1, 256)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty_like(x2)
+    M, Fh = x2.shape[0], w1.shape[0]
+    if M:
+        p1, p2 = pack_mfma_b(w1), pack_mfma_b(w2)
+        with torch.cuda.device(x.device), _timed(f"ffn256/F={Fh}", 4.0 * x2.numel(), 4.0 * M * 256 * Fh):
+            _check(lib().alo_ffn256(_ptr(x2), _ptr(p1), None if b1 is None else _ptr(b1.contiguous()),
+                                    _ptr(p2), None if b2 is None else _ptr(b2.contiguous()), _ptr(y), M, Fh,
+                                    ALO_BF16, _stream(x.device)))
+    return y.view(x.shape)

@@ -67,6 +67,9 @@ def _ffn(linear1, activation, linear2, x):
     """``linear2(act(linear1(x)))``; for ReLU the activation rides in the first GEMM's epilogue (alo_linear_shortk when
     d_model is 64 / 128 / 256 and the tensors are bf16, else hipBLASLt's RELU_BIAS via ``torch._addmm_activation``) instead
     of a separate pass over the (rows, d_ffn) intermediate."""
+    if activation is F.relu and alo_hip.ffn256_supported(x, linear1.weight, linear2.weight):
+        # d_model = 256, bf16: both layers in one kernel, the hidden activation never leaves the chip
+        return alo_hip.ffn256(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias)
     if activation is F.relu and linear1.bias is not None:
         h = alo_hip.linear_auto(x, linear1.weight, linear1.bias, relu=True)
         return alo_hip.linear_auto(h, linear2.weight, linear2.bias)

@@ -178,3 +178,227 @@ extern "C" int alo_linear_shortk(const void* x, const void* weight, const void* 
 #undef ALO_GEMM_CASE
     return ALO_ERR_UNSUPPORTED;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The transformer layer's feed-forward block in one kernel:  y = relu(x W1^T + b1) W2^T + b2,  x, y (M, 256), hidden F.
+// W1 / W2 arrive PACKED in MFMA fragment order (alo_pack_mfma_b: [row tile of 32][k step of 16][lane = 32 kg + n][8]).
+//
+// Run as two library GEMMs the (M, F) hidden activation makes a round trip through HBM (2 x 364 MB at M = 177784, F = 1024)
+// and the pair takes 316 us.  Here a workgroup owns 64 rows: it keeps them in LDS, produces the hidden activation 256
+// units at a time (each wave 64 of them) straight into LDS as bf16, and immediately contracts that chunk into its
+// 64 x 256 output accumulators (each wave 64 output columns), so the hidden tensor never exists in memory.  The weights
+// (2 x 512 KB, L2 resident) stream through registers; x is read once, y written once, in whole lines.
+// ------------------------------------------------------------------------------------------------------------------
+namespace alo {
+namespace {
+
+constexpr int kFfnRows = 64;
+constexpr int kFfnStride = 256 * 2 + 16;  // LDS row stride of the 64 x 256 bf16 tiles (x, hidden chunk, output staging)
+
+struct FfnDims {
+    long M;
+    int F;      // hidden width, multiple of 256
+    int tiles;  // ceil(M / 64)
+};
+
+__global__ void __launch_bounds__(256, 2)
+ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const bf16_t* __restrict__ B1,
+              const bf16_t* __restrict__ W2, const bf16_t* __restrict__ B2, bf16_t* __restrict__ Y, const FfnDims dm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const xs = smem;                            // x tile        [64][256] bf16
+    unsigned char* const hs = smem + kFfnRows * kFfnStride;    // hidden chunk  [64][256] bf16, then the output staging
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nl = lane & 31, kg = lane >> 5;
+    const int F = dm.F;
+
+    float b2v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b2v[t] = B2 ? bf16_to_f32(B2[64 * wave + 32 * t + nl].bits) : 0.f;
+
+    // Weight fragments arrive in batches of KB k-steps (2 column tiles x KB x 16 B per lane) through two register buffers:
+    // batch i+1 is requested before batch i is consumed, across phase and round boundaries too (L2 latency ~ the MFMA time
+    // of one batch).  sched_barrier keeps the compiler from sinking the requests next to their first use.
+    constexpr int KB = 2;            // k-steps per batch
+    constexpr int NBATCH = 16 / KB;  // batches per phase
+    auto load_batch = [&](u32x4 (&buf)[2][KB], const bf16_t* frag0, size_t tile_stride, int batch) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < KB; ++j)
+                buf[t][j] = *reinterpret_cast<const u32x4*>(frag0 + t * tile_stride + (size_t)(KB * batch + j) * 512);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_batch = [&](f32x16 (&acc)[2][2], const unsigned char* a_lds, const u32x4 (&buf)[2][KB], int batch) {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int s = KB * batch + j;
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(a_lds + nl * kFfnStride + (16 * s + 8 * kg) * 2);
+            const u32x4 a1 = *reinterpret_cast<const u32x4*>(a_lds + (32 + nl) * kFfnStride + (16 * s + 8 * kg) * 2);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(buf[0][j]), acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(buf[1][j]), acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(buf[0][j]), acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(buf[1][j]), acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int fs = F / 16;  // k steps per output-column tile of the packed W2
+    // packed fragment (row tile, k step) = 64 lanes x 16 B contiguous: a load instruction reads 8 whole lines
+    auto w1_frag = [&](int r0) { return W1 + ((size_t)((r0 + 64 * wave) / 32) * 16 * 64 + lane) * 8; };  // tile stride 16 * 512
+    auto w2_frag = [&](int r0) { return W2 + (((size_t)(2 * wave) * fs + r0 / 16) * 64 + lane) * 8; };     // tile stride fs * 512
+
+    for (int tile = blockIdx.x; tile < dm.tiles; tile += gridDim.x) {
+        // ---- x tile -> LDS (64 rows x 512 B, 8 pieces of 16 B per thread, rows contiguous across lanes); rows past the end are
+        // read from the last row (never stored) so that all eight requests go out back to back -----------------------------
+        {
+            u32x4 xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = tid + 256 * j;
+                long row = (long)tile * kFfnRows + (p >> 5);
+                row = row < dm.M ? row : dm.M - 1;
+                xv[j] = *reinterpret_cast<const u32x4*>(X + row * 256 + (p & 31) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = tid + 256 * j;
+                *reinterpret_cast<u32x4*>(xs + (p >> 5) * kFfnStride + (p & 31) * 16) = xv[j];
+            }
+        }
+        u32x4 bufa[2][KB], bufb[2][KB];
+        load_batch(bufa, w1_frag(0), (size_t)16 * 512, 0);
+        __syncthreads();
+
+        f32x16 acc2[2][2];  // [row tile][column tile] of this wave's 64 output columns
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[a][t][i] = 0.f;
+
+        for (int r0 = 0; r0 < F; r0 += 256) {
+            // ---- phase 1: this wave's 64 hidden units of the chunk: h = relu(x W1[r0 + 64 wave + ...]^T + b1) ----------------
+            f32x16 acc1[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc1[a][t][i] = 0.f;
+            const bf16_t* w1p = w1_frag(r0);
+            const bf16_t* w2p = w2_frag(r0);
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; bt += 2) {
+                load_batch(bufb, w1p, (size_t)16 * 512, bt + 1);
+                mma_batch(acc1, xs, bufa, bt);
+                if (bt + 2 < NBATCH) load_batch(bufa, w1p, (size_t)16 * 512, bt + 2);
+                else load_batch(bufa, w2p, (size_t)fs * 512, 0);
+                mma_batch(acc1, xs, bufb, bt + 1);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float bb = B1 ? bf16_to_f32(B1[r0 + 64 * wave + 32 * t + nl].bits) : 0.f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        *reinterpret_cast<uint16_t*>(hs + row * kFfnStride + (64 * wave + 32 * t + nl) * 2) =
+                            f32_to_bf16(fmaxf(acc1[a][t][r] + bb, 0.f));
+                    }
+            }
+            __syncthreads();  // the whole 64 x 256 hidden chunk is in LDS
+
+            // ---- phase 2: out[:, 64 wave ..] += h_chunk (64 x 256) W2[64 wave + ..][r0 .. r0 + 256)^T ------------------------
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; bt += 2) {
+                load_batch(bufb, w2p, (size_t)fs * 512, bt + 1);
+                mma_batch(acc2, hs, bufa, bt);
+                if (bt + 2 < NBATCH) load_batch(bufa, w2p, (size_t)fs * 512, bt + 2);
+                else if (r0 + 256 < F) load_batch(bufa, w1_frag(r0 + 256), (size_t)16 * 512, 0);
+                mma_batch(acc2, hs, bufb, bt + 1);
+            }
+            __syncthreads();  // everyone is done reading the chunk before it is overwritten
+        }
+
+        // ---- epilogue: + b2 -> bf16 -> staging (the hidden-chunk buffer) -> whole-line stores ---------------------------------
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    *reinterpret_cast<uint16_t*>(hs + row * kFfnStride + (64 * wave + 32 * t + nl) * 2) =
+                        f32_to_bf16(acc2[a][t][r] + b2v[t]);
+                }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = tid + 256 * j;
+            const long row = (long)tile * kFfnRows + (p >> 5);
+            if (row < dm.M)
+                *reinterpret_cast<u32x4*>(Y + row * 256 + (p & 31) * 8) =
+                    *reinterpret_cast<const u32x4*>(hs + (p >> 5) * kFfnStride + (p & 31) * 16);
+        }
+        __syncthreads();  // staging and x tile are rewritten by the next tile
+    }
+}
+
+}  // namespace
+}  // namespace alo
+
+namespace alo {
+namespace {
+// W (N, K) row-major -> fragments [N / 32][K / 16][64 lanes][8]: lane (kg, n) of fragment (t, s) holds W[32 t + n][16 s + 8 kg ..+8)
+__global__ void __launch_bounds__(256)
+pack_mfma_b_kernel(const bf16_t* __restrict__ W, bf16_t* __restrict__ P, int N, int K) {
+    const long total = (long)N * K / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i % 64);
+        const long frag = i / 64;
+        const int s = (int)(frag % (K / 16)), t = (int)(frag / (K / 16));
+        const int n = 32 * t + (lane & 31), k = 16 * s + 8 * (lane >> 5);
+        *reinterpret_cast<u32x4*>(P + i * 8) = *reinterpret_cast<const u32x4*>(W + (size_t)n * K + k);
+    }
+}
+}  // namespace
+}  // namespace alo
+
+extern "C" int alo_pack_mfma_b(const void* w, void* packed, int N, int K, int dtype, void* stream) {
+    ALO_REQUIRE(w && packed, ALO_ERR_INVALID_ARGUMENT, "alo_pack_mfma_b: null pointer argument");
+    ALO_REQUIRE(N > 0 && K > 0 && N % 32 == 0 && K % 16 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_pack_mfma_b: N must be a multiple of 32 and K a multiple of 16 (N=%d K=%d)", N, K);
+    ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_pack_mfma_b: bf16 only (dtype %d)", dtype);
+    long total = (long)N * K / 8;
+    unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    void* args[] = {&w, &packed, &N, &K};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(pack_mfma_b_kernel), dim3(blocks), dim3(256), args, 0,
+                                   static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_pack_mfma_b: %s", hipGetErrorString(e));
+    return check_launch("alo_pack_mfma_b");
+}
+
+extern "C" int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* y, long M,
+                          int F, int dtype, void* stream) {
+    ALO_REQUIRE(x && w1 && w2 && y, ALO_ERR_INVALID_ARGUMENT, "alo_ffn256: null pointer argument");
+    ALO_REQUIRE(M > 0 && F > 0 && F % 256 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_ffn256: M must be positive and the hidden width a positive multiple of 256 (M=%ld F=%d)", M, F);
+    ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_ffn256: bf16 only (dtype %d)", dtype);
+    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)y) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_ffn256: pointers must be 16-byte aligned");
+    FfnDims dm;
+    dm.M = M; dm.F = F; dm.tiles = (int)((M + kFfnRows - 1) / kFfnRows);
+    const size_t lds = 2 * kFfnRows * kFfnStride;
+    int gx = dm.tiles < 512 ? dm.tiles : 512;
+    void* args[] = {&x, &w1, &b1, &w2, &b2, &y, &dm};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(ffn256_kernel), dim3(gx), dim3(256), args, lds,
+                                   static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_ffn256: %s", hipGetErrorString(e));
+    return check_launch("alo_ffn256");
+}

@@ -214,6 +214,17 @@ int alo_linear_shortk(const void* x, const void* weight, const void* bias, void*
                       int dtype, void* stream);
 
 /*
+ * alo_ffn256: y (M, 256) = relu(x (M, 256) @ w1 (F, 256)^T + b1) @ w2 (256, F)^T + b2, bf16 with fp32 accumulation,
+ * F % 256 == 0: `linear2(relu(linear1(x)))` of the transformer layers (deformable_transformer.py:336-338,470-478) in one
+ * kernel — the (M, F) hidden activation lives 64 rows at a time in LDS and never reaches memory.  b1 / b2 may be NULL.
+ * w1 and w2 are PACKED weights: alo_pack_mfma_b(w (N, K) row-major) -> [N / 32][K / 16][64][8], the lane order of the MFMA
+ * B operand, so that the weight stream is read in whole lines (pack once per weight update).
+ */
+int alo_pack_mfma_b(const void* w, void* packed, int N, int K, int dtype, void* stream);
+int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* y, long M, int F,
+               int dtype, void* stream);
+
+/*
  * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened
  * (B, S, 2F) layout the encoder consumes, level embedding added: what PositionEmbeddingSine.forward + the
  * `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` / cat of DeformableTransformer.forward compute with ~15 PyTorch

@@ -194,3 +194,28 @@ def test_decoder_self_attention_fast_path_matches_multihead_attention(dtype, tol
         want = mha(q.transpose(0, 1), q.transpose(0, 1), tgt.transpose(0, 1))[0].transpose(0, 1)
         got = _self_attention(mha, q, tgt)
     assert got.shape == want.shape and (got.float() - want.float()).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("M,Fh,with_bias", [(177784, 1024, True), (2400, 1024, True), (65, 512, False), (1, 256, True), (6401, 2048, True)])
+def test_ffn256_matches_two_step_reference(M, Fh, with_bias):
+    """alo_ffn256 (hidden activation kept in LDS, packed weights) against fp32 matmuls of the same bf16 operands with the
+    hidden activation rounded to bf16 in between, exactly as the two-GEMM path stores it."""
+    g = torch.Generator(device=DEV).manual_seed(M + Fh)
+    x = torch.randn(M, 256, device=DEV, generator=g).bfloat16()
+    w1 = (torch.randn(Fh, 256, device=DEV, generator=g) * 0.06).bfloat16()
+    w2 = (torch.randn(256, Fh, device=DEV, generator=g) * 0.03).bfloat16()
+    b1 = torch.randn(Fh, device=DEV, generator=g).bfloat16() if with_bias else None
+    b2 = torch.randn(256, device=DEV, generator=g).bfloat16() if with_bias else None
+    h = (x.float() @ w1.float().t() + (b1.float() if with_bias else 0)).relu().bfloat16().float()
+    ref = h @ w2.float().t() + (b2.float() if with_bias else 0)
+    got = alo_hip.ffn256(x, w1, b1, w2, b2)
+    assert got.shape == x.shape and got.dtype == torch.bfloat16
+    # one bf16 rounding of the result + the hidden activations that round the other way by one ulp (fp32 summation order)
+    assert ((got.float() - ref).abs() <= ref.abs() * 2.0 ** -8 + 4e-3).all()
+    # the packed copy follows in-place weight updates
+    with torch.no_grad():
+        w1.mul_(0.5)
+    again = alo_hip.ffn256(x, w1, b1, w2, b2)
+    h2 = (x.float() @ w1.float().t() + (b1.float() if with_bias else 0)).relu().bfloat16().float()
+    ref2 = h2 @ w2.float().t() + (b2.float() if with_bias else 0)
+    assert ((again.float() - ref2).abs() <= ref2.abs() * 2.0 ** -8 + 4e-3).all()
