@@ -71,7 +71,7 @@ def _declare(lib):
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
-    lib.alo_linear_shortk.argtypes = [vp] * 4 + [c.c_long, ip, ip, ip, ip, vp]
+    lib.alo_linear_shortk.argtypes = [vp] * 5 + [c.c_long, ip, ip, ip, ip, vp]
     lib.alo_pos_sine_flat.restype = ip
     lib.alo_pos_sine_flat.argtypes = [vp] * 7 + [ip] * 6 + [c.c_float, c.c_float, ip, vp]
     lib.alo_add_layernorm.restype = ip
@@ -551,8 +551,9 @@ def linear_shortk_supported(x, weight):
             and weight.dim() == 2 and weight.shape[1] == x.shape[-1] and weight.shape[0] % 64 == 0)
 
 
-def linear_shortk(x, weight, bias=None, relu=False):
-    """``act(x @ weight.T + bias)`` over the last dim (64 / 128 / 256) of a bf16 ``x``; weight (N, K), N % 64 == 0."""
+def linear_shortk(x, weight, bias=None, relu=False, residual=None):
+    """``act(x @ weight.T + bias [+ residual])`` over the last dim (64 / 128 / 256) of a bf16 ``x``; weight (N, K), N % 64 == 0;
+    ``residual`` has the shape of the result and is added before the activation."""
     if not linear_shortk_supported(x, weight):
         raise RuntimeError("linear_shortk: needs bf16 CUDA tensors, K in (64, 128, 256) and N % 64 == 0")
     N, K = weight.shape
@@ -561,10 +562,16 @@ def linear_shortk(x, weight, bias=None, relu=False):
         x2 = x2.contiguous()
     y = torch.empty((x2.shape[0], N), dtype=x.dtype, device=x.device)
     M = x2.shape[0]
+    if residual is not None:
+        residual = residual.reshape(-1, N)
+        if residual.shape[0] != M or residual.dtype != x.dtype or not residual.is_contiguous():
+            raise RuntimeError("linear_shortk: residual must be a contiguous (M, N) tensor of x's dtype")
     if M:
-        with torch.cuda.device(x.device), _timed(f"linear_shortk/N={N},K={K}", 2.0 * (x2.numel() + y.numel()), 2.0 * M * N * K):
+        nbytes = 2.0 * (x2.numel() + y.numel() * (2 if residual is not None else 1))
+        with torch.cuda.device(x.device), _timed(f"linear_shortk/N={N},K={K}", nbytes, 2.0 * M * N * K):
             _check(lib().alo_linear_shortk(_ptr(x2), _ptr(weight.contiguous()), None if bias is None else _ptr(bias.contiguous()),
-                                           _ptr(y), M, N, K, 1 if relu else 0, ALO_BF16, _stream(x.device)))
+                                           None if residual is None else _ptr(residual), _ptr(y), M, N, K, 1 if relu else 0,
+                                           ALO_BF16, _stream(x.device)))
     return y.view(*x.shape[:-1], N)
 
 

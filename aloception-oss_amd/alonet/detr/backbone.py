@@ -77,6 +77,13 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
             if conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and w.shape[0] % 4 == 0:
                 # a 1x1 convolution over NHWC rows IS a matrix product: hipBLASLt runs it 1.5-6x faster than MIOpen's
                 # implicit-GEMM kernels at these shapes and takes bias + ReLU in its epilogue
+                if residual is not None and tuple(conv.stride) == (1, 1) and alo_hip.linear_shortk_supported(
+                        x.permute(0, 2, 3, 1), w.reshape(w.shape[0], -1)) and residual.is_contiguous(memory_format=torch.channels_last):
+                    # few input channels: bias + identity + ReLU ride in the epilogue of the streaming GEMM
+                    n, _, h, w_ = x.shape
+                    out = alo_hip.linear_shortk(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), w.reshape(w.shape[0], -1), b, relu,
+                                                residual=residual.permute(0, 2, 3, 1).reshape(-1, w.shape[0]))
+                    return out.view(n, h, w_, -1).permute(0, 3, 1, 2)
                 out = conv1x1_as_gemm(x, w, b if residual is None else None, conv.stride, relu=relu and residual is None)
                 return out if residual is None else alo_hip.bias_act_(out, b, residual, relu)
             if relu or residual is not None:

@@ -33,10 +33,10 @@ struct GemmDims {
     int tiles;  // ceil(M / 32)
 };
 
-template <int kK, bool RELU>
+template <int kK, bool RELU, bool HAS_RES>
 __global__ void __launch_bounds__(256)
 linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
-                   bf16_t* __restrict__ Y, const GemmDims dm) {
+                     const bf16_t* __restrict__ R, bf16_t* __restrict__ Y, const GemmDims dm) {
     constexpr int kRowBytes = kK * 2 + 16;  // LDS row stride of the X tile: +16 B keeps the 16-byte fragment reads conflict-free
     constexpr int kSteps = kK / 16;         // MFMA k-steps per tile
     constexpr int kPieces = kK / 8;         // 16-byte pieces per row
@@ -115,7 +115,7 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * kg;
                     float v = acc[t][r] + bias_v[t];
-                    if (RELU) v = fmaxf(v, 0.f);
+                    if (RELU && !HAS_RES) v = fmaxf(v, 0.f);
                     *reinterpret_cast<uint16_t*>(obuf + row * kOutStride + (32 * t + nl) * 2) = f32_to_bf16(v);
                 }
             }
@@ -127,8 +127,23 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
             for (int pass = 0; pass < 4; ++pass) {
                 const int row = pass * 8 + (lane >> 3);
                 const long grow = (long)tile * kRows + row;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * kOutStride + (lane & 7) * 16);
-                if (grow < dm.M) *reinterpret_cast<u32x4*>(Y + grow * dm.N + col0 + (lane & 7) * 8) = v;
+                u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * kOutStride + (lane & 7) * 16);
+                if (grow < dm.M) {
+                    if constexpr (HAS_RES) {  // + identity (same coordinates as y), then the activation
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(R + grow * dm.N + col0 + (lane & 7) * 8);
+                        const unsigned a4[4] = {v.x, v.y, v.z, v.w}, r4[4] = {rv.x, rv.y, rv.z, rv.w};
+                        unsigned o4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float lo = __uint_as_float(a4[i] << 16) + __uint_as_float(r4[i] << 16);
+                            float hi = __uint_as_float(a4[i] & 0xffff0000u) + __uint_as_float(r4[i] & 0xffff0000u);
+                            if (RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                            o4[i] = f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                        }
+                        v = u32x4{o4[0], o4[1], o4[2], o4[3]};
+                    }
+                    *reinterpret_cast<u32x4*>(Y + grow * dm.N + col0 + (lane & 7) * 8) = v;
+                }
             }
         }
         if (!more) break;
@@ -144,8 +159,9 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
 using namespace alo;
 
 namespace {
-template <int K, bool RELU>
-int launch_shortk(const void* x, const void* weight, const void* bias, void* y, long M, int N, hipStream_t stream) {
+template <int K, bool RELU, bool HAS_RES>
+int launch_shortk(const void* x, const void* weight, const void* bias, const void* residual, void* y, long M, int N,
+                  hipStream_t stream) {
     GemmDims dm;
     dm.M = M; dm.N = N; dm.tiles = (int)((M + kRows - 1) / kRows);
     const size_t lds = 2 * kRows * (K * 2 + 16) + 4 * kRows * kOutStride;
@@ -153,27 +169,31 @@ int launch_shortk(const void* x, const void* weight, const void* bias, void* y, 
     int gx = 512 / cols;  // persistent: about two workgroups per CU in total
     if (gx > dm.tiles) gx = dm.tiles;
     if (gx < 1) gx = 1;
-    void* args[] = {&x, &weight, &bias, &y, &dm};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU>), dim3(gx, cols), dim3(256), args,
+    void* args[] = {&x, &weight, &bias, &residual, &y, &dm};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES>), dim3(gx, cols), dim3(256), args,
                                    lds, stream);
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_linear_shortk: %s", hipGetErrorString(e));
     return check_launch("alo_linear_shortk");
 }
 }  // namespace
 
-extern "C" int alo_linear_shortk(const void* x, const void* weight, const void* bias, void* y, long M, int N, int K, int relu,
-                                 int dtype, void* stream) {
+extern "C" int alo_linear_shortk(const void* x, const void* weight, const void* bias, const void* residual, void* y, long M,
+                                 int N, int K, int relu, int dtype, void* stream) {
     ALO_REQUIRE(x && weight && y, ALO_ERR_INVALID_ARGUMENT, "alo_linear_shortk: null pointer argument");
     ALO_REQUIRE(M > 0 && N > 0 && N % 64 == 0, ALO_ERR_INVALID_ARGUMENT,
                 "alo_linear_shortk: M must be positive and N a positive multiple of 64 (M=%ld N=%d)", M, N);
     ALO_REQUIRE(K == 64 || K == 128 || K == 256, ALO_ERR_UNSUPPORTED, "alo_linear_shortk: K must be 64, 128 or 256, got %d", K);
     ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_linear_shortk: bf16 only (dtype %d)", dtype);
-    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
                 "alo_linear_shortk: pointers must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define ALO_GEMM_CASE(KK)                                                                       \
-    if (K == KK) return relu ? launch_shortk<KK, true>(x, weight, bias, y, M, N, st)           \
-                             : launch_shortk<KK, false>(x, weight, bias, y, M, N, st);
+#define ALO_GEMM_CASE(KK)                                                                                       \
+    if (K == KK) {                                                                                               \
+        if (residual) return relu ? launch_shortk<KK, true, true>(x, weight, bias, residual, y, M, N, st)       \
+                                  : launch_shortk<KK, false, true>(x, weight, bias, residual, y, M, N, st);     \
+        return relu ? launch_shortk<KK, true, false>(x, weight, bias, residual, y, M, N, st)                    \
+                    : launch_shortk<KK, false, false>(x, weight, bias, residual, y, M, N, st);                  \
+    }
     ALO_GEMM_CASE(64) ALO_GEMM_CASE(128) ALO_GEMM_CASE(256)
 #undef ALO_GEMM_CASE
     return ALO_ERR_UNSUPPORTED;

@@ -203,15 +203,15 @@ int alo_bias_act(const void* x, const void* bias, const void* residual, void* y,
                  int dtype, void* stream);
 
 /*
- * alo_linear_shortk: y (M, N) = act(x (M, K) @ weight (N, K)^T + bias), K in {64, 128, 256}, N % 64 == 0, bf16 with fp32
- * accumulation, act = ReLU when relu != 0.  The short-K nn.Linear layers next to the op — value_proj, sampling_offsets,
+ * alo_linear_shortk: y (M, N) = act(x (M, K) @ weight (N, K)^T + bias [+ residual (M, N)]), K in {64, 128, 256}, N % 64 == 0,
+ * bf16 with fp32 accumulation, act = ReLU when relu != 0 (residual: the bottleneck's identity, added before the activation).  The short-K nn.Linear layers next to the op — value_proj, sampling_offsets,
  * attention_weights, output_proj of MSDeformAttn (ms_deform_attn.py:56-59), the FFN's first layer — and the backbone's 1x1
  * convolutions with K input channels over NHWC rows: memory-bound products; the weights stay in registers, x streams
  * through once per 256 output columns, y is written in whole lines (v_mfma_f32_32x32x16_bf16).  bias (N,) bf16 or NULL.
  * 16-byte aligned pointers.
  */
-int alo_linear_shortk(const void* x, const void* weight, const void* bias, void* y, long M, int N, int K, int relu,
-                      int dtype, void* stream);
+int alo_linear_shortk(const void* x, const void* weight, const void* bias, const void* residual, void* y, long M, int N,
+                      int K, int relu, int dtype, void* stream);
 
 /*
  * alo_ffn256: y (M, 256) = relu(x (M, 256) @ w1 (F, 256)^T + b1) @ w2 (256, F)^T + b2, bf16 with fp32 accumulation,

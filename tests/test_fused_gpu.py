@@ -173,6 +173,21 @@ def test_linear_shortk_matches_fp32_matmul(M, N, K, relu, with_bias):
         assert torch.equal(got3.reshape(-1, N), got[: (M // 3) * 3])
 
 
+def test_linear_shortk_residual_epilogue():
+    """y = relu(x W^T + b + identity): the bottleneck's last 1x1 convolution with its identity in the GEMM epilogue."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(5000, 128, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(512, 128, device=DEV, generator=g) * 0.1).bfloat16()
+    b = torch.randn(512, device=DEV, generator=g).bfloat16()
+    res = torch.randn(5000, 512, device=DEV, generator=g).bfloat16()
+    pre = (x.float() @ w.float().t() + b.float()).bfloat16().float()  # the convolution's own output is rounded first
+    for relu in (True, False):
+        ref = pre + res.float()
+        ref = ref.relu() if relu else ref
+        got = alo_hip.linear_shortk(x, w, b, relu, residual=res)
+        assert ((got.float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 0.02).all()  # pre may round the other way by one ulp
+
+
 def test_linear_auto_falls_back_to_the_stock_gemm():
     x = torch.randn(10, 1024, device=DEV).bfloat16()  # K = 1024: not a short-K problem
     w, b = torch.randn(256, 1024, device=DEV).bfloat16() * 0.05, torch.randn(256, device=DEV).bfloat16()
