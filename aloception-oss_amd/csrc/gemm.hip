@@ -249,11 +249,16 @@ ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const
         __builtin_amdgcn_sched_barrier(0);
     };
     auto mma_batch = [&](f32x16 (&acc)[2][2], const unsigned char* a_lds, const u32x4 (&buf)[2][KB], int batch) {
+        u32x4 af[2][KB];  // A fragments of the whole batch first: their LDS latency overlaps instead of preceding each MFMA group
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const int s = KB * batch + j;
-            const u32x4 a0 = *reinterpret_cast<const u32x4*>(a_lds + nl * kFfnStride + (16 * s + 8 * kg) * 2);
-            const u32x4 a1 = *reinterpret_cast<const u32x4*>(a_lds + (32 + nl) * kFfnStride + (16 * s + 8 * kg) * 2);
+            af[0][j] = *reinterpret_cast<const u32x4*>(a_lds + nl * kFfnStride + (16 * s + 8 * kg) * 2);
+            af[1][j] = *reinterpret_cast<const u32x4*>(a_lds + (32 + nl) * kFfnStride + (16 * s + 8 * kg) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const u32x4 a0 = af[0][j], a1 = af[1][j];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(buf[0][j]), acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(buf[1][j]), acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(buf[0][j]), acc[1][0], 0, 0, 0);
