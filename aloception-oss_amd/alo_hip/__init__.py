@@ -68,6 +68,8 @@ def _declare(lib):
     lib.alo_gru_update.argtypes = [vp] * 5 + [ip] * 3 + [c.c_long, vp]
     lib.alo_pack_mfma_b.restype = ip
     lib.alo_pack_mfma_b.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.alo_value_proj_head_major.restype = ip
+    lib.alo_value_proj_head_major.argtypes = [vp] * 5 + [ip] * 5 + [vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -626,3 +628,26 @@ def ffn256(x, w1, b1, w2, b2):
                                     _ptr(p2), None if b2 is None else _ptr(b2.contiguous()), _ptr(y), M, Fh,
                                     ALO_BF16, _stream(x.device)))
     return y.view(x.shape)
+
+
+def value_proj_head_major_supported(x, weight, heads):
+    return (linear_shortk_supported(x, weight) and heads % 2 == 0 and weight.shape[0] == heads * 32 and x.dim() == 3)
+
+
+def value_proj_head_major(x, weight, bias, padding_mask, heads):
+    """``value_proj`` + ``masked_fill(padding_mask, 0)`` + head-major layout in one kernel: x (N, S, K) bf16 ->
+    (N, heads, S, 32) for ``msda_forward_fused_hm``."""
+    if not value_proj_head_major_supported(x, weight, heads):
+        raise RuntimeError("value_proj_head_major: needs bf16 (N, S, K) input, K in (64, 128, 256), head dimension 32")
+    N, S, K = x.shape
+    x = x if x.is_contiguous() else x.contiguous()
+    if padding_mask is not None:
+        if padding_mask.dtype != torch.bool or tuple(padding_mask.shape) != (N, S):
+            raise RuntimeError("padding_mask must be a (N, S) bool tensor")
+        padding_mask = padding_mask.contiguous()
+    out = torch.empty((N, heads, S, 32), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device), _timed(f"value_proj_hm/S={S}", 2.0 * (x.numel() + out.numel()), 2.0 * N * S * heads * 32 * K):
+        _check(lib().alo_value_proj_head_major(_ptr(x), _ptr(weight.contiguous()), None if bias is None else _ptr(bias.contiguous()),
+                                               None if padding_mask is None else _ptr(padding_mask), _ptr(out), N, S, heads, K,
+                                               ALO_BF16, _stream(x.device)))
+    return out

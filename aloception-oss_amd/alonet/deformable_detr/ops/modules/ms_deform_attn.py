@@ -102,9 +102,18 @@ class MSDeformAttn(nn.Module):
         fused = "is_tracing" not in kwargs and not needs_grad and self.fused_prologue and query.is_cuda
         # inference: the four K = d_model linears go through the streaming MFMA kernel when it fits (bf16, d_model = 256)
         proj = (lambda lin, t: alo_hip.linear_auto(t, lin.weight, lin.bias)) if fused else (lambda lin, t: lin(t))
-        value = proj(self.value_proj, input_flatten)
         offsets = proj(self.sampling_offsets, query).view(N, Lq, M, L, P, 2)
         logits = proj(self.attention_weights, query).view(N, Lq, M, L * P)
+        D = self.d_model // M
+        if (fused and D == 32 and L == 4 and P == 4 and self.value_proj.bias is not None
+                and alo_hip.value_proj_head_major_supported(input_flatten, self.value_proj.weight, M)):
+            # inference, DETR-family shape: value_proj, the padding mask and the head-major layout are ONE kernel
+            value = alo_hip.value_proj_head_major(input_flatten, self.value_proj.weight, self.value_proj.bias,
+                                                  input_padding_mask, M)
+            output = alo_hip.msda_forward_fused_hm(value, input_spatial_shapes, input_level_start_index,
+                                                   offsets.contiguous(), logits.contiguous(), reference_points)
+            return proj(self.output_proj, output)
+        value = proj(self.value_proj, input_flatten)
 
         if fused and alo_hip.head_major_supported(value.view(N, S, M, self.d_model // M), L, P):
             # inference, DETR-family shape: padding is zeroed while the projection's output is re-laid head-major (one pass

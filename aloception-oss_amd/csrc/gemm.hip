@@ -30,10 +30,15 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
 struct GemmDims {
     long M;
     int N;
-    int tiles;  // ceil(M / 32)
+    int tiles;  // ceil(M / kRows)
+    int S;      // head-major output only: rows per batch item
 };
 
-template <int kK, bool RELU, bool HAS_RES>
+// HM = true (value_proj of MSDeformAttn): y is written HEAD-major, (batch, N / 32 heads, S, 32), and rows whose padding-mask
+// byte is set are written as zeros — `value.masked_fill(mask, 0)` and the re-layout the head-major attention kernel wants,
+// for free in the epilogue (a wave's 64 columns are two heads; 16 rows of a head are 1 KB contiguous).  R then carries the
+// (M,) uint8 mask (or NULL) and dm.S the rows per batch item.
+template <int kK, bool RELU, bool HAS_RES, bool HM>
 __global__ void __launch_bounds__(256, 2)
 linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias,
                      const bf16_t* __restrict__ R, bf16_t* __restrict__ Y, const GemmDims dm) {
@@ -125,6 +130,26 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (HM) {
+                // per head (32 columns = 64 B per row): 4 lanes x 16 B per row, 16 consecutive rows = 1 KB per store instruction
+                const unsigned char* mask = reinterpret_cast<const unsigned char*>(R);
+                const int heads = dm.N / 32;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int pass = 0; pass < kRows / 16; ++pass) {
+                        const int row = pass * 16 + (lane >> 2);
+                        const long grow = (long)tile * kRows + row;
+                        if (grow < dm.M) {
+                            u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * kOutStride + hh * 64 + (lane & 3) * 16);
+                            if (mask != nullptr && mask[grow]) v = u32x4{0u, 0u, 0u, 0u};
+                            const long nb = grow / dm.S, sp = grow - nb * dm.S;
+                            const int head = col0 / 32 + hh;
+                            *reinterpret_cast<u32x4*>(Y + ((nb * heads + head) * dm.S + sp) * 32 + (lane & 3) * 8) = v;
+                        }
+                    }
+                }
+            } else
             // rows leave as whole 128-byte lines: 8 lanes x 16 B per row, 8 rows per store instruction
 #pragma unroll
             for (int pass = 0; pass < kRows / 8; ++pass) {
@@ -161,11 +186,11 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
 using namespace alo;
 
 namespace {
-template <int K, bool RELU, bool HAS_RES>
+template <int K, bool RELU, bool HAS_RES, bool HM = false>
 int launch_shortk(const void* x, const void* weight, const void* bias, const void* residual, void* y, long M, int N,
-                  hipStream_t stream) {
+                  hipStream_t stream, int S = 0) {
     GemmDims dm;
-    dm.M = M; dm.N = N; dm.tiles = (int)((M + kRows - 1) / kRows);
+    dm.M = M; dm.N = N; dm.tiles = (int)((M + kRows - 1) / kRows); dm.S = S;
     const size_t lds = kRows * (K * 2 + 16) + 4 * kRows * kOutStride;
     const int cols = (N + 255) / 256;
     int gx = 512 / cols;  // persistent: about two workgroups per CU in total
@@ -174,11 +199,11 @@ int launch_shortk(const void* x, const void* weight, const void* bias, const voi
     void* args[] = {&x, &weight, &bias, &residual, &y, &dm};
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES, HM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES>), dim3(gx, cols), dim3(256), args,
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES, HM>), dim3(gx, cols), dim3(256), args,
                                    lds, stream);
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_linear_shortk: %s", hipGetErrorString(e));
     return check_launch("alo_linear_shortk");
@@ -434,4 +459,22 @@ extern "C" int alo_ffn256(const void* x, const void* w1, const void* b1, const v
                                    static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_ffn256: %s", hipGetErrorString(e));
     return check_launch("alo_ffn256");
+}
+
+extern "C" int alo_value_proj_head_major(const void* x, const void* weight, const void* bias, const void* padding_mask,
+                                         void* value_hm, int batch, int S, int heads, int K, int dtype, void* stream) {
+    ALO_REQUIRE(x && weight && value_hm, ALO_ERR_INVALID_ARGUMENT, "alo_value_proj_head_major: null pointer argument");
+    ALO_REQUIRE(batch > 0 && S > 0 && heads > 0 && heads % 2 == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_value_proj_head_major: batch, S must be positive and the head count even (batch=%d S=%d heads=%d)", batch, S,
+                heads);
+    ALO_REQUIRE(K == 64 || K == 128 || K == 256, ALO_ERR_UNSUPPORTED, "alo_value_proj_head_major: K must be 64, 128 or 256, got %d", K);
+    ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_value_proj_head_major: bf16 only (dtype %d)", dtype);
+    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)value_hm) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_value_proj_head_major: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long M = (long)batch * S;
+    const int N = heads * 32;
+    if (K == 64) return launch_shortk<64, false, false, true>(x, weight, bias, padding_mask, value_hm, M, N, st, S);
+    if (K == 128) return launch_shortk<128, false, false, true>(x, weight, bias, padding_mask, value_hm, M, N, st, S);
+    return launch_shortk<256, false, false, true>(x, weight, bias, padding_mask, value_hm, M, N, st, S);
 }

@@ -214,6 +214,15 @@ int alo_linear_shortk(const void* x, const void* weight, const void* bias, const
                       int K, int relu, int dtype, void* stream);
 
 /*
+ * alo_value_proj_head_major: MSDeformAttn's value path in one kernel (ms_deform_attn.py:111-114): value_proj (a short-K
+ * linear layer, as alo_linear_shortk), `masked_fill(input_padding_mask, 0)` and the head-major layout of
+ * alo_value_head_major, all in the GEMM's epilogue.  x (batch * S, K) bf16, weight (heads * 32, K), bias (heads * 32,) or
+ * NULL, padding_mask (batch * S,) uint8 or NULL -> value_hm (batch, heads, S, 32).  Head dimension 32, even head count.
+ */
+int alo_value_proj_head_major(const void* x, const void* weight, const void* bias, const void* padding_mask, void* value_hm,
+                              int batch, int S, int heads, int K, int dtype, void* stream);
+
+/*
  * alo_ffn256: y (M, 256) = relu(x (M, 256) @ w1 (F, 256)^T + b1) @ w2 (256, F)^T + b2, bf16 with fp32 accumulation,
  * F % 256 == 0: `linear2(relu(linear1(x)))` of the transformer layers (deformable_transformer.py:336-338,470-478) in one
  * kernel — the (M, F) hidden activation lives 64 rows at a time in LDS and never reaches memory.  b1 / b2 may be NULL.

@@ -234,3 +234,18 @@ def test_ffn256_matches_two_step_reference(M, Fh, with_bias):
     h2 = (x.float() @ w1.float().t() + (b1.float() if with_bias else 0)).relu().bfloat16().float()
     ref2 = h2 @ w2.float().t() + (b2.float() if with_bias else 0)
     assert ((again.float() - ref2).abs() <= ref2.abs() * 2.0 ** -8 + 4e-3).all()
+
+
+@pytest.mark.parametrize("N,S,heads,K,with_mask", [(2, 22223, 8, 256, True), (3, 301, 4, 128, True), (1, 64, 2, 64, False)])
+def test_value_proj_head_major_equals_linear_then_relayout(N, S, heads, K, with_mask):
+    """value_proj + padding mask + head-major layout in the GEMM epilogue == alo_linear_shortk followed by alo_value_head_major."""
+    g = torch.Generator(device=DEV).manual_seed(N + S + K)
+    x = torch.randn(N, S, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(heads * 32, K, device=DEV, generator=g) * 0.1).bfloat16()
+    b = torch.randn(heads * 32, device=DEV, generator=g).bfloat16()
+    mask = (torch.rand(N, S, device=DEV, generator=g) < 0.25) if with_mask else None
+    got = alo_hip.value_proj_head_major(x, w, b, mask, heads)
+    two_step = alo_hip.value_head_major(alo_hip.linear_shortk(x, w, b).view(N, S, heads, 32), mask)
+    assert got.shape == (N, heads, S, 32) and torch.equal(got, two_step)
+    if with_mask:
+        assert float(got.permute(0, 2, 1, 3)[mask].abs().max()) == 0.0
