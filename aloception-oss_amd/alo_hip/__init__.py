@@ -70,8 +70,6 @@ def _declare(lib):
     lib.alo_pack_mfma_b.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.alo_value_proj_head_major.restype = ip
     lib.alo_value_proj_head_major.argtypes = [vp] * 5 + [ip] * 5 + [vp]
-    lib.alo_ffn256_add_ln.restype = ip
-    lib.alo_ffn256_add_ln.argtypes = [vp] * 7 + [c.c_float, vp, vp, vp, c.c_long, ip, ip, vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -653,31 +651,3 @@ def value_proj_head_major(x, weight, bias, padding_mask, heads):
                                                None if padding_mask is None else _ptr(padding_mask), _ptr(out), N, S, heads, K,
                                                ALO_BF16, _stream(x.device)))
     return out
-
-
-def ffn256_add_ln(x, w1, b1, w2, b2, ln_weight, ln_bias, eps=1e-5, pos=None):
-    """``LayerNorm(x + relu(x @ w1.T + b1) @ w2.T + b2)`` in one kernel; with ``pos`` also returns the result ``+ pos``.
-    -> out | (out, out_plus_pos)"""
-    if not ffn256_supported(x, w1, w2):
-        raise RuntimeError("ffn256_add_ln: needs bf16 CUDA tensors, d_model = 256 and a hidden width that is a multiple of 256")
-    x2 = x.reshape(-1, 256)
-    if not x2.is_contiguous():
-        x2 = x2.contiguous()
-    M, Fh = x2.shape[0], w1.shape[0]
-    if pos is not None:
-        pos = pos.reshape(-1, 256)
-        if pos.shape[0] != M or pos.dtype != x.dtype:
-            raise RuntimeError("ffn256_add_ln: pos must have the shape and dtype of x")
-        pos = pos.contiguous()
-    y = torch.empty_like(x2)
-    y_pos = None if pos is None else torch.empty_like(x2)
-    g, b = ln_weight.to(x.dtype).contiguous(), ln_bias.to(x.dtype).contiguous()
-    p1, p2 = pack_mfma_b(w1), pack_mfma_b(w2)
-    nbytes = 2.0 * x2.numel() * (2 + 2 * (pos is not None))
-    with torch.cuda.device(x.device), _timed(f"ffn256_add_ln/F={Fh}", nbytes, 4.0 * M * 256 * Fh):
-        _check(lib().alo_ffn256_add_ln(_ptr(x2), _ptr(p1), None if b1 is None else _ptr(b1.contiguous()), _ptr(p2),
-                                       None if b2 is None else _ptr(b2.contiguous()), _ptr(g), _ptr(b), float(eps),
-                                       None if pos is None else _ptr(pos), _ptr(y), None if pos is None else _ptr(y_pos),
-                                       M, Fh, ALO_BF16, _stream(x.device)))
-    y = y.view(x.shape)
-    return y if pos is None else (y, y_pos.view(x.shape))

@@ -63,16 +63,6 @@ def _self_attention(mha, qk_in, v_in):
     return alo_hip.linear_auto(out, mha.out_proj.weight, mha.out_proj.bias)
 
 
-def _ffn_add_norm(linear1, activation, linear2, norm, x, pos=None):
-    """``norm(x + linear2(act(linear1(x))))`` (+ the result ``+ pos``): one kernel when d_model = 256, bf16, ReLU; otherwise
-    the feed-forward block followed by the one-pass residual + LayerNorm."""
-    if (activation is F.relu and alo_hip.ffn256_supported(x, linear1.weight, linear2.weight) and x.numel() > 0
-            and norm.weight.numel() == 256):
-        return alo_hip.ffn256_add_ln(x, linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm.weight, norm.bias,
-                                     norm.eps, pos=pos)
-    return _add_norm(norm, _ffn(linear1, activation, linear2, x), x, pos=pos)
-
-
 def _ffn(linear1, activation, linear2, x):
     """``linear2(act(linear1(x)))``; for ReLU the activation rides in the first GEMM's epilogue (alo_linear_shortk when
     d_model is 64 / 128 / 256 and the tensors are bf16, else hipBLASLt's RELU_BIAS via ``torch._addmm_activation``) instead
@@ -130,9 +120,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         one HIP pass each, and the second one also emits the next layer's query.  -> (src', src' + pos | None)"""
         src2 = self.self_attn(query, reference_points, src, spatial_shapes, level_start_index, padding_mask, **kwargs)
         src = _add_norm(self.norm1, src2, src)
+        src2 = _ffn(self.linear1, self.activation, self.linear2, src)
         if next_query and pos is not None:
-            return _ffn_add_norm(self.linear1, self.activation, self.linear2, self.norm2, src, pos=pos)
-        return _ffn_add_norm(self.linear1, self.activation, self.linear2, self.norm2, src), None
+            return _add_norm(self.norm2, src2, src, pos=pos)
+        return _add_norm(self.norm2, src2, src), None
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -217,7 +208,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
             tgt2 = self.cross_attn(query, reference_points, src, src_spatial_shapes, level_start_index,
                                    src_padding_mask, **kwargs)
             tgt = _add_norm(self.norm1, tgt2, tgt)
-            return _ffn_add_norm(self.linear1, self.activation, self.linear2, self.norm3, tgt)
+            return _add_norm(self.norm3, _ffn(self.linear1, self.activation, self.linear2, tgt), tgt)
         tgt = self.norm2(tgt + self.dropout2(tgt2))
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
                                level_start_index, src_padding_mask, **kwargs)

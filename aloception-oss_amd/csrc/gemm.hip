@@ -254,37 +254,9 @@ struct FfnDims {
     int tiles;  // ceil(M / 64)
 };
 
-struct LnArgs {
-    const bf16_t* gamma;  // (256,)
-    const bf16_t* beta;   // (256,)
-    const bf16_t* pos;    // (M, 256) or NULL
-    bf16_t* y_pos;        // (M, 256) or NULL: LayerNorm output + pos
-    float eps;
-};
-
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ void unpack4(const u32x2& p, float (&v)[4]) {
-    v[0] = __uint_as_float(p.x << 16); v[1] = __uint_as_float(p.x & 0xffff0000u);
-    v[2] = __uint_as_float(p.y << 16); v[3] = __uint_as_float(p.y & 0xffff0000u);
-}
-__device__ __forceinline__ u32x2 pack4(const float (&v)[4]) {
-    u32x2 o;
-    o.x = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    o.y = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-    return o;
-}
-
-// LN = true: y = LayerNorm(x + ffn(x)) * gamma + beta (and y_pos = y + pos): the layer's residual + norm in the epilogue — the
-// residual IS the x tile already sitting in LDS, so the separate add + LayerNorm pass over (M, 256) disappears entirely.
-template <bool LN, bool HAS_POS>
 __global__ void __launch_bounds__(256, 2)
 ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const bf16_t* __restrict__ B1,
-              const bf16_t* __restrict__ W2, const bf16_t* __restrict__ B2, bf16_t* __restrict__ Y, const FfnDims dm,
-              const LnArgs ln) {
+              const bf16_t* __restrict__ W2, const bf16_t* __restrict__ B2, bf16_t* __restrict__ Y, const FfnDims dm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const xs = smem;                            // x tile        [64][256] bf16
     unsigned char* const hs = smem + kFfnRows * kFfnStride;    // hidden chunk  [64][256] bf16, then the output staging
@@ -419,60 +391,13 @@ ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const
                         f32_to_bf16(acc2[a][t][r] + b2v[t]);
                 }
         __syncthreads();
-        if constexpr (LN) {
-            // one wave = 16 rows, one lane = 4 consecutive columns: residual from the x tile, two wave reductions per row
-            float g4[4], b4[4];
-            unpack4(*reinterpret_cast<const u32x2*>(ln.gamma + 4 * lane), g4);
-            unpack4(*reinterpret_cast<const u32x2*>(ln.beta + 4 * lane), b4);
-            u32x2 pv[16];
-            if constexpr (HAS_POS) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    long grow = (long)tile * kFfnRows + 16 * wave + r;
-                    grow = grow < dm.M ? grow : dm.M - 1;
-                    pv[r] = *reinterpret_cast<const u32x2*>(ln.pos + grow * 256 + 4 * lane);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 16 * wave + r;
-                const long grow = (long)tile * kFfnRows + row;
-                float f[4], x4[4];
-                unpack4(*reinterpret_cast<const u32x2*>(hs + row * kFfnStride + 8 * lane), f);
-                unpack4(*reinterpret_cast<const u32x2*>(xs + row * kFfnStride + 8 * lane), x4);
-                float v[4], sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { v[i] = f[i] + x4[i]; sum += v[i]; }
-                const float mean = wave_sum64(sum) * (1.0f / 256.0f);
-                float q = 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; q += d * d; }
-                const float rstd = rsqrtf(wave_sum64(q) * (1.0f / 256.0f) + ln.eps);
-                float o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (v[i] - mean) * rstd * g4[i] + b4[i];
-                if (grow < dm.M) {
-                    const u32x2 ob = pack4(o);
-                    *reinterpret_cast<u32x2*>(Y + grow * 256 + 4 * lane) = ob;
-                    if constexpr (HAS_POS) {
-                        float orr[4], p4[4];
-                        unpack4(ob, orr);   // the sum is taken on the rounded output, as `out + pos` would be
-                        unpack4(pv[r], p4);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) orr[i] += p4[i];
-                        *reinterpret_cast<u32x2*>(ln.y_pos + grow * 256 + 4 * lane) = pack4(orr);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int p = tid + 256 * j;
-                const long row = (long)tile * kFfnRows + (p >> 5);
-                if (row < dm.M)
-                    *reinterpret_cast<u32x4*>(Y + row * 256 + (p & 31) * 8) =
-                        *reinterpret_cast<const u32x4*>(hs + (p >> 5) * kFfnStride + (p & 31) * 16);
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int p = tid + 256 * j;
+            const long row = (long)tile * kFfnRows + (p >> 5);
+            if (row < dm.M)
+                *reinterpret_cast<u32x4*>(Y + row * 256 + (p & 31) * 8) =
+                    *reinterpret_cast<const u32x4*>(hs + (p >> 5) * kFfnStride + (p & 31) * 16);
         }
         __syncthreads();  // staging and x tile are rewritten by the next tile
     }
@@ -512,50 +437,28 @@ extern "C" int alo_pack_mfma_b(const void* w, void* packed, int N, int K, int dt
     return check_launch("alo_pack_mfma_b");
 }
 
-namespace {
-int ffn256_launch(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* y, long M, int F,
-                  int dtype, const LnArgs& ln, bool with_ln, void* stream, const char* what) {
-    ALO_REQUIRE(x && w1 && w2 && y, ALO_ERR_INVALID_ARGUMENT, "%s: null pointer argument", what);
+extern "C" int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* y, long M,
+                          int F, int dtype, void* stream) {
+    ALO_REQUIRE(x && w1 && w2 && y, ALO_ERR_INVALID_ARGUMENT, "alo_ffn256: null pointer argument");
     ALO_REQUIRE(M > 0 && F > 0 && F % 256 == 0, ALO_ERR_INVALID_ARGUMENT,
-                "%s: M must be positive and the hidden width a positive multiple of 256 (M=%ld F=%d)", what, M, F);
-    ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "%s: bf16 only (dtype %d)", what, dtype);
-    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)y | (uintptr_t)ln.pos | (uintptr_t)ln.y_pos |
-                  (uintptr_t)ln.gamma | (uintptr_t)ln.beta) & 15) == 0,
-                ALO_ERR_INVALID_ARGUMENT, "%s: pointers must be 16-byte aligned", what);
+                "alo_ffn256: M must be positive and the hidden width a positive multiple of 256 (M=%ld F=%d)", M, F);
+    ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_ffn256: bf16 only (dtype %d)", dtype);
+    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)y) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_ffn256: pointers must be 16-byte aligned");
     FfnDims dm;
     dm.M = M; dm.F = F; dm.tiles = (int)((M + kFfnRows - 1) / kFfnRows);
     const size_t lds = 2 * kFfnRows * kFfnStride;
     int gx = dm.tiles < 512 ? dm.tiles : 512;
-    void* args[] = {&x, &w1, &b1, &w2, &b2, &y, &dm, const_cast<LnArgs*>(&ln)};
-    const void* kern = !with_ln ? reinterpret_cast<const void*>(ffn256_kernel<false, false>)
-                                : (ln.pos ? reinterpret_cast<const void*>(ffn256_kernel<true, true>)
-                                          : reinterpret_cast<const void*>(ffn256_kernel<true, false>));
-    static bool attr_set[3] = {false, false, false};
-    const int which = !with_ln ? 0 : (ln.pos ? 2 : 1);
-    if (!attr_set[which]) {
-        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[which] = true;
+    void* args[] = {&x, &w1, &b1, &w2, &b2, &y, &dm};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
     }
-    hipError_t e = hipLaunchKernel(kern, dim3(gx), dim3(256), args, lds, static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
-    return check_launch(what);
-}
-}  // namespace
-
-extern "C" int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* y, long M,
-                          int F, int dtype, void* stream) {
-    LnArgs ln{nullptr, nullptr, nullptr, nullptr, 0.f};
-    return ffn256_launch(x, w1, b1, w2, b2, y, M, F, dtype, ln, false, stream, "alo_ffn256");
-}
-
-extern "C" int alo_ffn256_add_ln(const void* x, const void* w1, const void* b1, const void* w2, const void* b2,
-                                 const void* gamma, const void* beta, float eps, const void* pos, void* y, void* y_pos, long M,
-                                 int F, int dtype, void* stream) {
-    ALO_REQUIRE(gamma && beta, ALO_ERR_INVALID_ARGUMENT, "alo_ffn256_add_ln: gamma / beta are null");
-    ALO_REQUIRE((pos == nullptr) == (y_pos == nullptr), ALO_ERR_INVALID_ARGUMENT, "alo_ffn256_add_ln: pos and y_pos go together");
-    LnArgs ln{static_cast<const bf16_t*>(gamma), static_cast<const bf16_t*>(beta), static_cast<const bf16_t*>(pos),
-              static_cast<bf16_t*>(y_pos), eps};
-    return ffn256_launch(x, w1, b1, w2, b2, y, M, F, dtype, ln, true, stream, "alo_ffn256_add_ln");
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(ffn256_kernel), dim3(gx), dim3(256), args, lds,
+                                   static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_ffn256: %s", hipGetErrorString(e));
+    return check_launch("alo_ffn256");
 }
 
 extern "C" int alo_value_proj_head_major(const void* x, const void* weight, const void* bias, const void* padding_mask,

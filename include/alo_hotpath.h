@@ -230,13 +230,6 @@ int alo_value_proj_head_major(const void* x, const void* weight, const void* bia
  * B operand, so that the weight stream is read in whole lines (pack once per weight update).
  */
 int alo_pack_mfma_b(const void* w, void* packed, int N, int K, int dtype, void* stream);
-/* alo_ffn256 with the layer's residual + LayerNorm in its epilogue: y = LayerNorm_256(x + ffn(x)) * gamma + beta and, when
- * pos is given, y_pos = y + pos (`src = self.norm2(src + self.dropout3(src2))` + the next layer's with_pos_embed,
- * deformable_transformer.py:336-352): the residual is the x tile the kernel already holds, so the separate
- * add + LayerNorm pass disappears.  gamma, beta (256,) bf16; pos / y_pos (M, 256) both or neither. */
-int alo_ffn256_add_ln(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, const void* gamma,
-                      const void* beta, float eps, const void* pos, void* y, void* y_pos, long M, int F, int dtype,
-                      void* stream);
 int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* y, long M, int F,
                int dtype, void* stream);
 

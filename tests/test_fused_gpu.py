@@ -249,23 +249,3 @@ def test_value_proj_head_major_equals_linear_then_relayout(N, S, heads, K, with_
     assert got.shape == (N, heads, S, 32) and torch.equal(got, two_step)
     if with_mask:
         assert float(got.permute(0, 2, 1, 3)[mask].abs().max()) == 0.0
-
-
-@pytest.mark.parametrize("M,with_pos", [(177784, True), (2400, False), (97, True)])
-def test_ffn256_add_ln_matches_ffn_then_add_layernorm(M, with_pos):
-    """Residual + LayerNorm (+ pos) in the feed-forward kernel's epilogue == alo_ffn256 followed by alo_add_layernorm."""
-    g = torch.Generator(device=DEV).manual_seed(M)
-    x = torch.randn(M, 256, device=DEV, generator=g).bfloat16()
-    w1 = (torch.randn(1024, 256, device=DEV, generator=g) * 0.06).bfloat16()
-    w2 = (torch.randn(256, 1024, device=DEV, generator=g) * 0.03).bfloat16()
-    b1 = torch.randn(1024, device=DEV, generator=g).bfloat16()
-    b2 = torch.randn(256, device=DEV, generator=g).bfloat16()
-    gamma = (torch.rand(256, device=DEV, generator=g) + 0.5).bfloat16()
-    beta = torch.randn(256, device=DEV, generator=g).bfloat16()
-    pos = torch.randn(M, 256, device=DEV, generator=g).bfloat16() if with_pos else None
-    two = alo_hip.add_layernorm(alo_hip.ffn256(x, w1, b1, w2, b2), x, gamma, beta, 1e-5, pos=pos)
-    one = alo_hip.ffn256_add_ln(x, w1, b1, w2, b2, gamma, beta, 1e-5, pos=pos)
-    if with_pos:
-        assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1])
-    else:
-        assert torch.equal(one, two)
