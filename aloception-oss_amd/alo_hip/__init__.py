@@ -70,6 +70,8 @@ def _declare(lib):
     lib.alo_pack_mfma_b.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.alo_value_proj_head_major.restype = ip
     lib.alo_value_proj_head_major.argtypes = [vp] * 5 + [ip] * 5 + [vp]
+    lib.alo_conv3x3_nhwc.restype = ip
+    lib.alo_conv3x3_nhwc.argtypes = [vp] * 4 + [ip] * 7 + [vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -628,6 +630,41 @@ def ffn256(x, w1, b1, w2, b2):
                                     _ptr(p2), None if b2 is None else _ptr(b2.contiguous()), _ptr(y), M, Fh,
                                     ALO_BF16, _stream(x.device)))
     return y.view(x.shape)
+
+
+def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1):
+    """3x3 / stride 1 / padding 1 convolution of a channels-last bf16 CUDA activation with Cin % 128 == 0, Cout % 64 == 0."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and weight.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] % 128 == 0
+            and weight.shape[0] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and not torch.is_grad_enabled())
+
+
+def conv3x3(x, weight, bias=None, relu=False):
+    """``act(F.conv2d(x, weight, bias, 1, 1))`` for a channels-last bf16 ``x`` (N, Cin, H, W): implicit GEMM on MFMA with the
+    bias and the ReLU in its epilogue.  Returns a channels-last (N, Cout, H, W) tensor."""
+    if not conv3x3_supported(x, weight):
+        raise RuntimeError("conv3x3: needs a channels-last bf16 CUDA activation, a (Cout, Cin, 3, 3) weight, Cin % 128 == 0, "
+                           "Cout % 64 == 0, no autograd")
+    n, cin, h, w_ = x.shape
+    cout = weight.shape[0]
+    tag = (weight._version, weight.data_ptr())
+    hit = getattr(weight, "_alo_packed", None)
+    if hit is None or hit[0] != tag:
+        # (Cout, ky, kx, Cin) row-major = the channels-last memory of the weight; pack it as a (Cout, 9 Cin) matrix
+        wm = weight.detach().permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+        packed = torch.empty_like(wm)
+        with torch.cuda.device(x.device):
+            _check(lib().alo_pack_mfma_b(_ptr(wm), _ptr(packed), cout, 9 * cin, ALO_BF16, _stream(x.device)))
+        hit = (tag, packed)
+        weight._alo_packed = hit
+    y = torch.empty((n, cout, h, w_), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    bias_c = None if bias is None else bias.contiguous()
+    with torch.cuda.device(x.device), _timed(f"conv3x3/C={cin}", 2.0 * (x.numel() + y.numel()), 2.0 * 9 * cin * y.numel()):
+        _check(lib().alo_conv3x3_nhwc(_ptr(x), _ptr(hit[1]), None if bias_c is None else _ptr(bias_c), _ptr(y), n, h, w_, cin,
+                                      cout, 1 if relu else 0, ALO_BF16, _stream(x.device)))
+    return y
 
 
 def value_proj_head_major_supported(x, weight, heads):

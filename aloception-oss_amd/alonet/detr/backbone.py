@@ -86,6 +86,9 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
                     return out.view(n, h, w_, -1).permute(0, 3, 1, 2)
                 out = conv1x1_as_gemm(x, w, b if residual is None else None, conv.stride, relu=relu and residual is None)
                 return out if residual is None else alo_hip.bias_act_(out, b, residual, relu)
+            if residual is None and alo_hip.conv3x3_supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+                # the bottleneck's 3x3: implicit GEMM on MFMA, bias + ReLU in its epilogue (2-3.5x MIOpen at these shapes)
+                return alo_hip.conv3x3(x, w, b, relu)
             if relu or residual is not None:
                 # bias (+ identity) + ReLU are ONE in-place pass over the convolution output instead of MIOpen's separate
                 # bias kernel followed by add / relu kernels

@@ -234,6 +234,15 @@ int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, co
                int dtype, void* stream);
 
 /*
+ * alo_conv3x3_nhwc: y (N, H, W, Cout) = act(conv3x3(x (N, H, W, Cin), stride 1, padding 1) + bias), bf16 with fp32 accumulation:
+ * Bottleneck.conv2 + the folded FrozenBatchNorm2d + ReLU of the ResNet backbone (alonet/detr/backbone.py:19-47,84-92;
+ * torchvision Bottleneck), an implicit GEMM on MFMA.  w_packed = alo_pack_mfma_b of the (Cout, 9 * Cin) matrix
+ * w[o][(ky * 3 + kx) * Cin + c] (= the channels-last memory order of a (Cout, Cin, 3, 3) weight).  Cin % 128 == 0, Cout % 64 == 0.
+ */
+int alo_conv3x3_nhwc(const void* x, const void* w_packed, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
+                     int relu, int dtype, void* stream);
+
+/*
  * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened
  * (B, S, 2F) layout the encoder consumes, level embedding added: what PositionEmbeddingSine.forward + the
  * `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` / cat of DeformableTransformer.forward compute with ~15 PyTorch

@@ -249,3 +249,40 @@ def test_value_proj_head_major_equals_linear_then_relayout(N, S, heads, K, with_
     assert got.shape == (N, heads, S, 32) and torch.equal(got, two_step)
     if with_mask:
         assert float(got.permute(0, 2, 1, 3)[mask].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 128, 25, 42), (1, 256, 7, 9), (3, 512, 5, 70), (1, 128, 1, 1), (2, 128, 64, 3)])
+@pytest.mark.parametrize("relu,with_bias", [(True, True), (False, False)])
+def test_conv3x3_matches_fp32_convolution(shape, relu, with_bias):
+    """alo_conv3x3_nhwc against F.conv2d in fp32 on the same bf16 inputs: fp32 accumulation, one bf16 rounding of the result."""
+    n, c, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + c + h)
+    x = torch.randn(n, c, h, w, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    cout = c // 2 if c >= 256 else c
+    wt = (torch.randn(cout, c, 3, 3, device="cuda", generator=g) / (9 * c) ** 0.5).to(torch.bfloat16)
+    wt = wt.contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, device="cuda", generator=g).to(torch.bfloat16) if with_bias else None
+    with torch.no_grad():
+        ref = F.conv2d(x.float(), wt.float(), None if b is None else b.float(), 1, 1)
+        if relu:
+            ref = F.relu(ref)
+        got = alo_hip.conv3x3(x, wt, b, relu=relu)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    # |result| is O(1): half a bf16 ulp of the largest value plus fp32 summation-order noise
+    assert (got.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_conv3x3_refuses_what_it_does_not_cover():
+    x = torch.randn(1, 64, 8, 8, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(64, 64, 3, 3, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        assert not alo_hip.conv3x3_supported(x, wt)
+        with pytest.raises(RuntimeError):
+            alo_hip.conv3x3(x, wt)
+        x128 = torch.randn(1, 128, 8, 8, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w128 = torch.randn(128, 128, 3, 3, device="cuda", dtype=torch.bfloat16)
+        assert alo_hip.conv3x3_supported(x128, w128)
+        assert not alo_hip.conv3x3_supported(x128, w128, stride=(2, 2))
+        assert not alo_hip.conv3x3_supported(x128.contiguous(), w128)
