@@ -71,7 +71,9 @@ def _declare(lib):
     lib.alo_value_proj_head_major.restype = ip
     lib.alo_value_proj_head_major.argtypes = [vp] * 5 + [ip] * 5 + [vp]
     lib.alo_conv3x3_nhwc.restype = ip
-    lib.alo_conv3x3_nhwc.argtypes = [vp] * 4 + [ip] * 7 + [vp]
+    lib.alo_conv3x3_nhwc.argtypes = [vp] * 4 + [ip] * 8 + [vp]
+    lib.alo_stem_conv_pool.restype = ip
+    lib.alo_stem_conv_pool.argtypes = [vp] * 4 + [ip] * 3 + [c.c_long] * 4 + [ip, vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -633,20 +635,21 @@ def ffn256(x, w1, b1, w2, b2):
 
 
 def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1):
-    """3x3 / stride 1 / padding 1 convolution of a channels-last bf16 CUDA activation with Cin % 128 == 0, Cout % 64 == 0."""
+    """3x3 / padding 1 / stride 1 or 2 convolution of a channels-last bf16 CUDA activation, Cin % 64 == 0, Cout % 64 == 0."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and weight.dim() == 4
-            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
-            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] % 128 == 0
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) in ((1, 1), (2, 2)) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1] and x.shape[1] % 64 == 0
             and weight.shape[0] % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last)
             and not torch.is_grad_enabled())
 
 
-def conv3x3(x, weight, bias=None, relu=False):
-    """``act(F.conv2d(x, weight, bias, 1, 1))`` for a channels-last bf16 ``x`` (N, Cin, H, W): implicit GEMM on MFMA with the
-    bias and the ReLU in its epilogue.  Returns a channels-last (N, Cout, H, W) tensor."""
-    if not conv3x3_supported(x, weight):
-        raise RuntimeError("conv3x3: needs a channels-last bf16 CUDA activation, a (Cout, Cin, 3, 3) weight, Cin % 128 == 0, "
-                           "Cout % 64 == 0, no autograd")
+def conv3x3(x, weight, bias=None, relu=False, stride=1):
+    """``act(F.conv2d(x, weight, bias, stride, 1))`` for a channels-last bf16 ``x`` (N, Cin, H, W): implicit GEMM on MFMA with
+    the bias and the ReLU in its epilogue.  Returns a channels-last (N, Cout, Ho, Wo) tensor."""
+    stride = stride[0] if isinstance(stride, (tuple, list)) else stride
+    if not conv3x3_supported(x, weight, (stride, stride)):
+        raise RuntimeError("conv3x3: needs a channels-last bf16 CUDA activation, a (Cout, Cin, 3, 3) weight, Cin % 64 == 0, "
+                           "Cout % 64 == 0, stride 1 or 2, no autograd")
     n, cin, h, w_ = x.shape
     cout = weight.shape[0]
     tag = (weight._version, weight.data_ptr())
@@ -659,11 +662,47 @@ def conv3x3(x, weight, bias=None, relu=False):
             _check(lib().alo_pack_mfma_b(_ptr(wm), _ptr(packed), cout, 9 * cin, ALO_BF16, _stream(x.device)))
         hit = (tag, packed)
         weight._alo_packed = hit
-    y = torch.empty((n, cout, h, w_), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     bias_c = None if bias is None else bias.contiguous()
-    with torch.cuda.device(x.device), _timed(f"conv3x3/C={cin}", 2.0 * (x.numel() + y.numel()), 2.0 * 9 * cin * y.numel()):
+    with torch.cuda.device(x.device), _timed(f"conv3x3/C={cin}/s={stride}", 2.0 * (x.numel() + y.numel()), 2.0 * 9 * cin * y.numel()):
         _check(lib().alo_conv3x3_nhwc(_ptr(x), _ptr(hit[1]), None if bias_c is None else _ptr(bias_c), _ptr(y), n, h, w_, cin,
-                                      cout, 1 if relu else 0, ALO_BF16, _stream(x.device)))
+                                      cout, stride, 1 if relu else 0, ALO_BF16, _stream(x.device)))
+    return y
+
+
+def stem_conv_pool_supported(x, weight):
+    """bf16 CUDA (N, 3, H, W) image (any strides), (64, 3, 7, 7) bf16 weight, inference."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3
+            and tuple(weight.shape) == (64, 3, 7, 7) and not torch.is_grad_enabled())
+
+
+def stem_conv_pool(x, weight, bias=None):
+    """``max_pool2d(relu(conv2d(x, weight, bias, stride=2, padding=3)), 3, 2, 1)`` — the ResNet stem — in one kernel.
+    Returns a channels-last (N, 64, Hp, Wp) bf16 tensor."""
+    if not stem_conv_pool_supported(x, weight):
+        raise RuntimeError("stem_conv_pool: needs a bf16 CUDA (N, 3, H, W) image, a (64, 3, 7, 7) bf16 weight, no autograd")
+    n, _, h, w_ = x.shape
+    tag = (weight._version, weight.data_ptr())
+    hit = getattr(weight, "_alo_packed", None)
+    if hit is None or hit[0] != tag:
+        # (64, 7 tap rows x 24): per tap row the 7 taps x 3 channels interleaved as the image rows are, then 3 zero columns
+        wm = torch.zeros((64, 8, 24), dtype=weight.dtype, device=weight.device)
+        wm[:, :7, :21] = weight.detach().permute(0, 2, 3, 1).reshape(64, 7, 21)
+        wm = wm.reshape(64, 192)[:, :176].contiguous()
+        packed = torch.empty_like(wm)
+        with torch.cuda.device(x.device):
+            _check(lib().alo_pack_mfma_b(_ptr(wm), _ptr(packed), 64, 176, ALO_BF16, _stream(x.device)))
+        hit = (tag, packed)
+        weight._alo_packed = hit
+    hc, wc = (h - 1) // 2 + 1, (w_ - 1) // 2 + 1
+    hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
+    y = torch.empty((n, 64, hp, wp), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    bias_c = None if bias is None else bias.contiguous()
+    sn, sc, sh, sw = x.stride()
+    with torch.cuda.device(x.device), _timed("stem_conv_pool", 2.0 * (x.numel() + y.numel()), 2.0 * 147 * 64 * n * hc * wc):
+        _check(lib().alo_stem_conv_pool(_ptr(x), _ptr(hit[1]), None if bias_c is None else _ptr(bias_c), _ptr(y), n, h, w_,
+                                        sn, sc, sh, sw, ALO_BF16, _stream(x.device)))
     return y
 
 

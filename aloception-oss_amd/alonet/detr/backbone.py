@@ -50,6 +50,24 @@ def conv1x1_as_gemm(x, weight, bias, stride=(1, 1), relu=False):
     return out.view(n, h, w_, -1).permute(0, 3, 1, 2)
 
 
+def folded_conv_bn(conv, bn):
+    """``(w', b')`` with ``bn(conv(x)) == conv'(x)``: ``w' = w * scale[:, None, None, None]`` (channels-last), ``b' = shift``.
+    In eval mode the folded tensors are cached (keyed on the parameter versions); in training mode they are rebuilt every
+    call so autograd still reaches ``conv.weight``."""
+    key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.dtype, bn.weight.data_ptr(), bn.weight._version,
+           bn.running_var._version, bn.running_mean._version, bn.bias._version)
+    cached = conv.__dict__.get("_folded")
+    if conv.training or torch.is_grad_enabled() and conv.weight.requires_grad or cached is None or cached[0] != key:
+        scale, shift = bn.scale_shift()
+        w = (conv.weight.float() * scale.float().reshape(-1, 1, 1, 1)).to(conv.weight.dtype)
+        w = w.contiguous(memory_format=torch.channels_last)
+        b = shift.to(conv.weight.dtype)
+        if not conv.training and not (torch.is_grad_enabled() and conv.weight.requires_grad):
+            conv.__dict__["_folded"] = (key, w.detach(), b.detach())
+        return w, b
+    return cached[1], cached[2]
+
+
 def conv_bn(x, conv, bn, relu=False, residual=None):
     """``act(bn(conv(x)) [+ residual])`` with the frozen batch-norm folded into the convolution's weight and bias.
 
@@ -60,18 +78,7 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
     untouched.
     """
     if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
-        key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.dtype, bn.weight.data_ptr(), bn.weight._version,
-               bn.running_var._version, bn.running_mean._version, bn.bias._version)
-        cached = conv.__dict__.get("_folded")
-        if conv.training or torch.is_grad_enabled() and conv.weight.requires_grad or cached is None or cached[0] != key:
-            scale, shift = bn.scale_shift()
-            w = (conv.weight.float() * scale.float().reshape(-1, 1, 1, 1)).to(conv.weight.dtype)
-            w = w.contiguous(memory_format=torch.channels_last)
-            b = shift.to(conv.weight.dtype)
-            if not conv.training and not (torch.is_grad_enabled() and conv.weight.requires_grad):
-                conv.__dict__["_folded"] = (key, w.detach(), b.detach())
-        else:
-            _, w, b = cached
+        w, b = folded_conv_bn(conv, bn)
         if alo_hip.fusable(x, w) and x.is_contiguous(memory_format=torch.channels_last):
             # inference on the GPU, NHWC activations
             if conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and w.shape[0] % 4 == 0:
@@ -88,7 +95,7 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
                 return out if residual is None else alo_hip.bias_act_(out, b, residual, relu)
             if residual is None and alo_hip.conv3x3_supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
                 # the bottleneck's 3x3: implicit GEMM on MFMA, bias + ReLU in its epilogue (2-3.5x MIOpen at these shapes)
-                return alo_hip.conv3x3(x, w, b, relu)
+                return alo_hip.conv3x3(x, w, b, relu, conv.stride)
             if relu or residual is not None:
                 # bias (+ identity) + ReLU are ONE in-place pass over the convolution output instead of MIOpen's separate
                 # bias kernel followed by add / relu kernels
@@ -169,12 +176,25 @@ class ResNetBody(nn.Module):
         layers += [Bottleneck(self.inplanes, planes, 1, self.dilation, None, norm_layer) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    def _stem_fusable(self, x):
+        c, p = self.conv1, self.maxpool
+        return (alo_hip.stem_conv_pool_supported(x, c.weight) and isinstance(self.bn1, FrozenBatchNorm2d) and c.bias is None
+                and c.stride == (2, 2) and c.padding == (3, 3) and c.dilation == (1, 1) and c.groups == 1
+                and isinstance(p, nn.MaxPool2d) and p.kernel_size == 3 and p.stride == 2 and p.padding == 1
+                and p.dilation == 1 and not p.ceil_mode)
+
     def forward(self, x):
         out = {}
         # NHWC activations: MIOpen's bf16/fp32 implicit-GEMM kernels are NHWC-native; fed NCHW they wrap every
         # convolution in a pair of layout-transpose kernels
-        x = x.contiguous(memory_format=torch.channels_last)
-        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, relu=True))
+        if self._stem_fusable(x):
+            # conv1 + bn1 + ReLU + max-pool in one kernel, straight from the NCHW image: the half-resolution 64-channel map
+            # (the largest activation of the network) never reaches memory
+            w, b = folded_conv_bn(self.conv1, self.bn1)
+            x = alo_hip.stem_conv_pool(x, w, b)
+        else:
+            x = x.contiguous(memory_format=torch.channels_last)
+            x = self.maxpool(conv_bn(x, self.conv1, self.bn1, relu=True))
         for name in ("layer1", "layer2", "layer3", "layer4"):
             x = getattr(self, name)(x)
             if name in self.return_layers:

@@ -52,11 +52,16 @@ struct bf16_t {
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((unsigned)b) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round to nearest even, NaN stays NaN
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 converts in hardware (v_cvt_pk_bf16_f32, two values per instruction)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    const __bf16 b = static_cast<__bf16>(f);
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {  // lo in bits 0-15
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+    const bf16x2_hw r = __builtin_convertvector(f32x2_hw{lo, hi}, bf16x2_hw);
+    return __builtin_bit_cast(unsigned, r);
 }
 
 // A raw (stride-0) buffer resource over [base, base + bytes).  Loads whose byte offset falls outside return 0 and
@@ -151,10 +156,10 @@ __device__ __forceinline__ void store_vec(T* p, const CT (&v)[VEC]) {
         *reinterpret_cast<double2*>(p) = double2{(double)v[0], (double)v[1]};
     } else if constexpr (sizeof(T) == 2 && VEC == 8) {
         u32x4 o;
-        o.x = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        o.y = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-        o.z = f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-        o.w = f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]);
+        o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<u32x4*>(p) = o;
     } else {
 #pragma unroll

@@ -32,8 +32,8 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
     u32x2 o;
-    o.x = f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    o.y = f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<u32x2*>(p) = o;
 }
 

@@ -166,7 +166,7 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                             float lo = __uint_as_float(a4[i] << 16) + __uint_as_float(r4[i] << 16);
                             float hi = __uint_as_float(a4[i] & 0xffff0000u) + __uint_as_float(r4[i] & 0xffff0000u);
                             if (RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                            o4[i] = f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+                            o4[i] = pack_bf16x2(lo, hi);
                         }
                         v = u32x4{o4[0], o4[1], o4[2], o4[3]};
                     }

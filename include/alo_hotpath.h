@@ -234,13 +234,24 @@ int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, co
                int dtype, void* stream);
 
 /*
- * alo_conv3x3_nhwc: y (N, H, W, Cout) = act(conv3x3(x (N, H, W, Cin), stride 1, padding 1) + bias), bf16 with fp32 accumulation:
- * Bottleneck.conv2 + the folded FrozenBatchNorm2d + ReLU of the ResNet backbone (alonet/detr/backbone.py:19-47,84-92;
- * torchvision Bottleneck), an implicit GEMM on MFMA.  w_packed = alo_pack_mfma_b of the (Cout, 9 * Cin) matrix
- * w[o][(ky * 3 + kx) * Cin + c] (= the channels-last memory order of a (Cout, Cin, 3, 3) weight).  Cin % 128 == 0, Cout % 64 == 0.
+ * alo_conv3x3_nhwc: y (N, Ho, Wo, Cout) = act(conv3x3(x (N, H, W, Cin), stride 1 or 2, padding 1) + bias), bf16 with fp32
+ * accumulation: Bottleneck.conv2 + the folded FrozenBatchNorm2d + ReLU of the ResNet backbone (alonet/detr/backbone.py:19-47,
+ * 84-92; torchvision Bottleneck), an implicit GEMM on MFMA.  Ho = (H - 1) / stride + 1.  w_packed = alo_pack_mfma_b of the
+ * (Cout, 9 * Cin) matrix w[o][(ky * 3 + kx) * Cin + c] (= the channels-last memory order of a (Cout, Cin, 3, 3) weight).
+ * Cin % 64 == 0, Cout % 64 == 0; bias may be NULL.
  */
 int alo_conv3x3_nhwc(const void* x, const void* w_packed, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
-                     int relu, int dtype, void* stream);
+                     int stride, int relu, int dtype, void* stream);
+
+/*
+ * alo_stem_conv_pool: the ResNet stem in one kernel — y (N, Hp, Wp, 64) = maxpool3x3/s2/p1(relu(conv7x7/s2/p3(x) + bias)), bf16 with
+ * fp32 accumulation (alonet/detr/backbone.py:19-47 with torchvision's ResNet.conv1 / bn1 / relu / maxpool; the frozen batch-norm
+ * folded into weight and bias).  x is a (N, 3, H, W) bf16 image addressed through its ELEMENT strides (NCHW or channels-last);
+ * Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1.  w_packed = alo_pack_mfma_b of the (64, 176) matrix
+ * m[o][ky * 24 + kx * 3 + c] = w[o][c][ky][kx] (zero elsewhere).  The half-resolution convolution output never reaches memory.
+ */
+int alo_stem_conv_pool(const void* x, const void* w_packed, const void* bias, void* y, int N, int H, int W, long stride_n,
+                       long stride_c, long stride_h, long stride_w, int dtype, void* stream);
 
 /*
  * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened

@@ -252,22 +252,24 @@ def test_value_proj_head_major_equals_linear_then_relayout(N, S, heads, K, with_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 128, 25, 42), (1, 256, 7, 9), (3, 512, 5, 70), (1, 128, 1, 1), (2, 128, 64, 3)])
+@pytest.mark.parametrize("shape", [(2, 128, 25, 42), (1, 256, 7, 9), (3, 512, 5, 70), (1, 128, 1, 1), (2, 128, 64, 3),
+                                   (2, 64, 30, 41), (1, 64, 2, 2)])
+@pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("relu,with_bias", [(True, True), (False, False)])
-def test_conv3x3_matches_fp32_convolution(shape, relu, with_bias):
+def test_conv3x3_matches_fp32_convolution(shape, stride, relu, with_bias):
     """alo_conv3x3_nhwc against F.conv2d in fp32 on the same bf16 inputs: fp32 accumulation, one bf16 rounding of the result."""
     n, c, h, w = shape
     g = torch.Generator(device="cuda").manual_seed(n * 1000 + c + h)
     x = torch.randn(n, c, h, w, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    cout = c // 2 if c >= 256 else c
+    cout = c // 2 if c >= 256 else (2 * c if c == 64 and h > 2 else c)
     wt = (torch.randn(cout, c, 3, 3, device="cuda", generator=g) / (9 * c) ** 0.5).to(torch.bfloat16)
     wt = wt.contiguous(memory_format=torch.channels_last)
     b = torch.randn(cout, device="cuda", generator=g).to(torch.bfloat16) if with_bias else None
     with torch.no_grad():
-        ref = F.conv2d(x.float(), wt.float(), None if b is None else b.float(), 1, 1)
+        ref = F.conv2d(x.float(), wt.float(), None if b is None else b.float(), stride, 1)
         if relu:
             ref = F.relu(ref)
-        got = alo_hip.conv3x3(x, wt, b, relu=relu)
+        got = alo_hip.conv3x3(x, wt, b, relu=relu, stride=stride)
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     # |result| is O(1): half a bf16 ulp of the largest value plus fp32 summation-order noise
     assert (got.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
@@ -275,14 +277,53 @@ def test_conv3x3_matches_fp32_convolution(shape, relu, with_bias):
 
 @pytest.mark.gpu
 def test_conv3x3_refuses_what_it_does_not_cover():
-    x = torch.randn(1, 64, 8, 8, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    wt = torch.randn(64, 64, 3, 3, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(1, 32, 8, 8, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(64, 32, 3, 3, device="cuda", dtype=torch.bfloat16)
     with torch.no_grad():
         assert not alo_hip.conv3x3_supported(x, wt)
         with pytest.raises(RuntimeError):
             alo_hip.conv3x3(x, wt)
         x128 = torch.randn(1, 128, 8, 8, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
         w128 = torch.randn(128, 128, 3, 3, device="cuda", dtype=torch.bfloat16)
-        assert alo_hip.conv3x3_supported(x128, w128)
-        assert not alo_hip.conv3x3_supported(x128, w128, stride=(2, 2))
+        assert alo_hip.conv3x3_supported(x128, w128) and alo_hip.conv3x3_supported(x128, w128, stride=(2, 2))
+        assert not alo_hip.conv3x3_supported(x128, w128, stride=(3, 3))
+        assert not alo_hip.conv3x3_supported(x128, w128, dilation=(2, 2))
         assert not alo_hip.conv3x3_supported(x128.contiguous(), w128)
+    assert not alo_hip.conv3x3_supported(x128, w128)   # autograd on: the kernel has no backward
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,layout", [((2, 3, 64, 96), "nchw"), ((1, 3, 37, 53), "nhwc"), ((3, 3, 8, 8), "nchw"),
+                                          ((1, 3, 101, 30), "nchw"), ((1, 3, 5, 200), "nhwc")])
+def test_stem_conv_pool_matches_fp32_stem(shape, layout):
+    """alo_stem_conv_pool against max_pool2d(relu(conv2d(...))) in fp32 on the same bf16 inputs (one bf16 rounding, which
+    commutes with the max)."""
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(*shape, device="cuda", generator=g).to(torch.bfloat16)
+    if layout == "nhwc":
+        x = x.contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(64, 3, 7, 7, device="cuda", generator=g) / 147 ** 0.5).to(torch.bfloat16)
+    b = torch.randn(64, device="cuda", generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        ref = F.max_pool2d(F.relu(F.conv2d(x.float(), wt.float(), b.float(), 2, 3)), 3, 2, 1)
+        got = alo_hip.stem_conv_pool(x, wt, b)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_resnet_stem_fused_matches_unfused():
+    from alonet.detr.backbone import ResNetBody
+    torch.manual_seed(3)
+    net = ResNetBody("resnet50").cuda().to(torch.bfloat16).eval()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5); m.running_mean.normal_(0, 0.1); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    x = torch.randn(2, 3, 96, 130, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        assert net._stem_fusable(x)
+        fused = net(x)["0"]
+        net._stem_fusable = lambda _x: False
+        plain = net(x)["0"]
+    scale = plain.float().abs().max().item()
+    assert (fused.float() - plain.float()).abs().max().item() <= 0.03 * max(scale, 1.0)
