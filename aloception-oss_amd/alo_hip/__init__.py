@@ -74,6 +74,10 @@ def _declare(lib):
     lib.alo_conv3x3_nhwc.argtypes = [vp] * 4 + [ip] * 8 + [vp]
     lib.alo_stem_conv_pool.restype = ip
     lib.alo_stem_conv_pool.argtypes = [vp] * 4 + [ip] * 3 + [c.c_long] * 4 + [ip, vp]
+    lib.alo_groupnorm_rows_workspace_bytes.restype = c.c_size_t
+    lib.alo_groupnorm_rows_workspace_bytes.argtypes = [ip, ip, ip]
+    lib.alo_groupnorm_rows.restype = ip
+    lib.alo_groupnorm_rows.argtypes = [vp] * 5 + [ip] * 4 + [c.c_float, c.c_long, ip, vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -704,6 +708,35 @@ def stem_conv_pool(x, weight, bias=None):
         _check(lib().alo_stem_conv_pool(_ptr(x), _ptr(hit[1]), None if bias_c is None else _ptr(bias_c), _ptr(y), n, h, w_,
                                         sn, sc, sh, sw, ALO_BF16, _stream(x.device)))
     return y
+
+
+def groupnorm_rows_supported(x, weight, groups):
+    """bf16 CUDA channels-last rows (B, HW, C); C / 8 and ``groups`` divide 256; whole 8-channel slices per group."""
+    c_ = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and weight is not None and weight.dtype == torch.bfloat16
+            and c_ % 8 == 0 and 256 % (c_ // 8) == 0 and c_ % groups == 0 and (c_ // groups) % 8 == 0 and 256 % groups == 0
+            and not torch.is_grad_enabled())
+
+
+def groupnorm_rows(x, weight, bias, groups, eps=1e-5, out=None):
+    """``F.group_norm`` over channels-last rows: x (B, HW, C) contiguous -> out (B, HW, C), which may be a slice
+    ``flat[:, start:start + HW]`` of a larger (B, S, C) buffer (rows contiguous, any batch stride)."""
+    if not groupnorm_rows_supported(x, weight, groups):
+        raise RuntimeError("groupnorm_rows: needs bf16 CUDA rows (B, HW, C) with C / 8 and groups dividing 256, no autograd")
+    x = x.contiguous()
+    b_, hw, c_ = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    if tuple(out.shape) != (b_, hw, c_) or out.dtype != x.dtype or out.stride(2) != 1 or out.stride(1) != c_:
+        raise RuntimeError("groupnorm_rows: out must be (B, HW, C) of the input's dtype with contiguous rows")
+    if b_ and hw:
+        nbytes = lib().alo_groupnorm_rows_workspace_bytes(b_, hw, groups)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _timed(f"groupnorm_rows/HW={hw}", 6.0 * x.numel()):
+            _check(lib().alo_groupnorm_rows(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), _ptr(out), _ptr(ws), b_, hw,
+                                            c_, groups, float(eps), out.stride(0) if b_ > 1 else hw * c_, ALO_BF16,
+                                            _stream(x.device)))
+    return out
 
 
 def value_proj_head_major_supported(x, weight, heads):

@@ -15,6 +15,7 @@ from torch import nn
 import alo_hip
 import aloscene
 from alonet.common import load_weights
+from alonet.detr.backbone import conv1x1_as_gemm
 from alonet.detr.misc import assert_and_export_onnx
 from alonet.transformers import MLP, PositionEmbeddingSine
 
@@ -139,15 +140,30 @@ class DeformableDETR(nn.Module):
         features, pos = self.backbone(frames, skip_pos_levels=skip, **kwargs)
 
         srcs, masks = [], []
-        for lvl, (src, mask) in enumerate(features[1:]):
-            srcs.append(self.input_proj[lvl](src))
-            masks.append(mask[:, 0])
-        for lvl in range(len(srcs), self.num_feature_levels):  # extra, coarser levels
-            src = self.input_proj[lvl](features[-1][0] if lvl == len(features) - 1 else srcs[-1])
-            mask = F.interpolate(frame_masks.float(), size=src.shape[-2:]).to(torch.bool)
-            pos.append(None if lazy_pos else self.backbone[1]((src, mask)).to(src.dtype))
-            srcs.append(src)
-            masks.append(mask[:, 0])
+        flat = self._flat_sources(features) if lazy_pos else None
+        if flat is not None:
+            # inference: every level's projection is normalised straight into its slot of the encoder's flattened source
+            flat, slots = flat
+            for lvl, (start, (h, w)) in enumerate(slots):
+                x, mask = features[min(lvl + 1, len(features) - 1)]
+                rows = flat[:, start:start + h * w]
+                self._project(lvl, x, out_rows=rows)
+                srcs.append(rows.view(rows.shape[0], h, w, -1).permute(0, 3, 1, 2))
+                if lvl + 1 >= len(features):
+                    mask = F.interpolate(frame_masks.float(), size=(h, w)).to(torch.bool)
+                    pos.append(None)
+                masks.append(mask[:, 0])
+            kwargs = dict(kwargs, src_flatten=flat)
+        else:
+            for lvl, (src, mask) in enumerate(features[1:]):
+                srcs.append(self._project(lvl, src))
+                masks.append(mask[:, 0])
+            for lvl in range(len(srcs), self.num_feature_levels):  # extra, coarser levels
+                src = self._project(lvl, features[-1][0] if lvl == len(features) - 1 else srcs[-1])
+                mask = F.interpolate(frame_masks.float(), size=src.shape[-2:]).to(torch.bool)
+                pos.append(None if lazy_pos else self.backbone[1]((src, mask)).to(src.dtype))
+                srcs.append(src)
+                masks.append(mask[:, 0])
         if lazy_pos:
             kwargs = dict(kwargs, pos_encoder=self.backbone[1])
 
@@ -155,6 +171,59 @@ class DeformableDETR(nn.Module):
         if self.return_bb_outputs:
             features[-1] = (srcs[-2], masks[-2])
         return self.forward_heads(transformer_out, bb_outputs=(features, pos[:-1]))
+
+    def _project_fast(self, lvl, x):
+        """Which fast path covers ``input_proj[lvl]`` on ``x``: "gemm" (1x1), "conv3x3" or None."""
+        conv = self.input_proj[lvl][0]
+        if (alo_hip.fusable(x, conv.weight) and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+                and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == "zeros"):
+            if conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.out_channels % 4 == 0:
+                return "gemm"
+            if conv.kernel_size == (3, 3) and alo_hip.conv3x3_supported(x, conv.weight, conv.stride, conv.padding):
+                return "conv3x3"
+        return None
+
+    def _project(self, lvl, x, out_rows=None):
+        """``input_proj[lvl](x)`` (convolution + GroupNorm).  At inference on channels-last bf16 maps the 1x1 projections are
+        GEMMs over the NHWC rows and the 3x3 / stride 2 one is the implicit-GEMM kernel (MIOpen's choices for these shapes are
+        3-5x slower); with ``out_rows`` (B, h*w, C) the GroupNorm writes its channels-last rows there (alo_groupnorm_rows)."""
+        conv, norm = self.input_proj[lvl][0], self.input_proj[lvl][1]
+        kind = self._project_fast(lvl, x)
+        if kind is None:
+            assert out_rows is None
+            return self.input_proj[lvl](x)
+        if kind == "gemm":
+            y = conv1x1_as_gemm(x, conv.weight, conv.bias, conv.stride)
+        else:
+            y = alo_hip.conv3x3(x, conv.weight, conv.bias, False, conv.stride)
+        if out_rows is None:
+            return norm(y)
+        n, c, h, w = y.shape
+        alo_hip.groupnorm_rows(y.permute(0, 2, 3, 1).reshape(n, h * w, c), norm.weight, norm.bias, norm.num_groups, norm.eps,
+                               out=out_rows)
+        return out_rows
+
+    def _flat_sources(self, features):
+        """(flat (B, S, C) buffer, [(start, (h, w)) per level]) when every level can be projected + normalised straight into the
+        encoder's flattened source, else None."""
+        n_bb = len(features) - 1
+        if self.num_feature_levels > n_bb + 1:   # a second extra level would read the first one out of the flat buffer
+            return None
+        slots, start = [], 0
+        for lvl in range(self.num_feature_levels):
+            x = features[min(lvl + 1, n_bb)][0]
+            conv, norm = self.input_proj[lvl][0], self.input_proj[lvl][1]
+            if self._project_fast(lvl, x) is None or not isinstance(norm, nn.GroupNorm) or not norm.affine:
+                return None
+            h = (x.shape[2] + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] + 1
+            w = (x.shape[3] + 2 * conv.padding[1] - conv.kernel_size[1]) // conv.stride[1] + 1
+            probe = x.new_empty((1, 1, conv.out_channels))
+            if not alo_hip.groupnorm_rows_supported(probe, norm.weight, norm.num_groups):
+                return None
+            slots.append((start, (h, w)))
+            start += h * w
+        x0 = features[1][0]
+        return x0.new_empty((x0.shape[0], start, self.input_proj[0][0].out_channels)), slots
 
     def forward_position_heads(self, transformer_outputs):
         hs = transformer_outputs["hs"]

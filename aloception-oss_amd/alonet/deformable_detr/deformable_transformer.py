@@ -327,14 +327,16 @@ class DeformableTransformer(nn.Module):
         device = srcs[0].device
         src_flatten, mask_flatten, pos_flatten, shapes = [], [], [], []
         pos_encoder = kwargs.pop("pos_encoder", None)  # set by DeformableDETR when it left the encodings to this module
+        ready = kwargs.pop("src_flatten", None)        # (B, S, C): the levels of ``srcs`` are already views into it
         for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
             _, _, h, w = src.shape
             shapes.append((h, w))
-            src_flatten.append(src.flatten(2).transpose(1, 2))
+            if ready is None:
+                src_flatten.append(src.flatten(2).transpose(1, 2))
             mask_flatten.append(mask.flatten(1))
             if pos_embed is not None:
                 pos_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
-        src_flatten = torch.cat(src_flatten, 1)
+        src_flatten = torch.cat(src_flatten, 1) if ready is None else ready
         mask_flatten = torch.cat(mask_flatten, 1)
         spatial_shapes, level_start_index = _level_geometry(tuple(shapes), device)
         sizes = [h * w for h, w in shapes]

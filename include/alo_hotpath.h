@@ -254,6 +254,17 @@ int alo_stem_conv_pool(const void* x, const void* w_packed, const void* bias, vo
                        long stride_c, long stride_h, long stride_w, int dtype, void* stream);
 
 /*
+ * alo_groupnorm_rows: GroupNorm of channels-last rows x (B, HW, C) -> y (B, HW, C) with an arbitrary batch stride, so that the
+ * result lands inside the encoder's flattened (B, S, C) source at the level's offset: `input_proj[l][1]` + the flatten / transpose /
+ * cat of DeformableTransformer.forward (alonet/deformable_detr/deformable_detr.py:75-76,141-151; deformable_transformer.py:331-337).
+ * bf16 in / out, fp32 Welford statistics (biased variance, as torch.nn.GroupNorm), deterministic.  weight / bias (C,) bf16.
+ * C / 8 and groups must divide 256; C / groups % 8 == 0.  workspace: alo_groupnorm_rows_workspace_bytes(B, HW, groups) bytes.
+ */
+size_t alo_groupnorm_rows_workspace_bytes(int B, int HW, int groups);
+int alo_groupnorm_rows(const void* x, const void* weight, const void* bias, void* y, void* workspace, int B, int HW, int C,
+                       int groups, float eps, long y_batch_stride, int dtype, void* stream);
+
+/*
  * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened
  * (B, S, 2F) layout the encoder consumes, level embedding added: what PositionEmbeddingSine.forward + the
  * `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` / cat of DeformableTransformer.forward compute with ~15 PyTorch

@@ -327,3 +327,23 @@ def test_resnet_stem_fused_matches_unfused():
         plain = net(x)["0"]
     scale = plain.float().abs().max().item()
     assert (fused.float() - plain.float()).abs().max().item() <= 0.03 * max(scale, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,HW,C,groups", [(2, 1000, 256, 32), (1, 7, 256, 32), (3, 300, 128, 8), (1, 513, 64, 8), (2, 257, 256, 16)])
+def test_groupnorm_rows_matches_group_norm(B, HW, C, groups):
+    """alo_groupnorm_rows against F.group_norm in fp32 on the same bf16 rows, written into a slice of a larger flat buffer."""
+    g = torch.Generator(device="cuda").manual_seed(B * HW + C)
+    x = (torch.randn(B, HW, C, device="cuda", generator=g) * 3 + 0.7).to(torch.bfloat16)
+    wt = torch.randn(C, device="cuda", generator=g).to(torch.bfloat16)
+    b = torch.randn(C, device="cuda", generator=g).to(torch.bfloat16)
+    flat = torch.full((B, HW + 21, C), 7.0, device="cuda", dtype=torch.bfloat16)
+    with torch.no_grad():
+        ref = F.group_norm(x.float().transpose(1, 2), groups, wt.float(), b.float(), 1e-5).transpose(1, 2)
+        out = alo_hip.groupnorm_rows(x, wt, b, groups, 1e-5, out=flat[:, 8:8 + HW])
+    assert out.data_ptr() == flat[:, 8:].data_ptr()
+    assert (out.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item()) + 1e-3
+    assert (flat[:, :8] == 7.0).all() and (flat[:, 8 + HW:] == 7.0).all()   # nothing written outside the slot
+    with torch.no_grad():
+        alone = alo_hip.groupnorm_rows(x, wt, b, groups, 1e-5)
+    assert torch.equal(alone, out)
