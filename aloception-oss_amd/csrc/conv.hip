@@ -86,6 +86,11 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
     const int HWo = dm.Ho * dm.Wo;
     const int col0 = KSPLIT ? blockIdx.y * 64 : blockIdx.y * 128 + wave * 64;  // this wave's 64 output channels
     const bool has_cols = col0 < dm.Cout;                               // Cout % 64 == 0
+    float* const bias_s = reinterpret_cast<float*>(smem + G::kLds);     // the workgroup's 128 (K-split: 64) bias values, fp32
+    {
+        const int c = (KSPLIT ? blockIdx.y * 64 : blockIdx.y * 128) + tid;
+        bias_s[tid] = (bias != nullptr && c < dm.Cout && (!KSPLIT || tid < 64)) ? bf16_to_f32(bias[c].bits) : 0.f;
+    }
 
     // Persistent workgroups.  Workgroup ids go round-robin over the 8 XCDs, so XCD x (ids = x mod 8) takes the x-th eighth of
     // the tiles: neighbouring tiles — which share two of their three halo rows — meet in the same L2.
@@ -169,8 +174,8 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
                     if (!ok1) a1 = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(f.v[j][b]), acc[0][b], 0, 0, 0);
-                        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(f.v[j][b]), acc[1][b], 0, 0, 0);
+                        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(f.v[j][b]), as_bf16x8(a0), acc[0][b], 0, 0, 0);
+                        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(f.v[j][b]), as_bf16x8(a1), acc[1][b], 0, 0, 0);
                     }
                 }
             };
@@ -222,19 +227,22 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
 
         if (has_cols && !(KSPLIT && wave == 1)) {
             unsigned char* const obuf = smem + (KSPLIT ? 0 : wave) * (kPix * kOutStride);
+            // the product is computed transposed (weights = the MFMA's row operand): lane = output pixel 32 a + nl, registers
+            // 4 q .. 4 q + 3 = channels col0 + 32 b + 8 q + 4 kg .. + 3 -> bias, ReLU, bf16, one 8-byte LDS write per quad
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const float bv = bias ? bf16_to_f32(bias[col0 + 32 * b + nl].bits) : 0.f;
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 32 * b + 8 * q + 4 * kg;
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias_s + (KSPLIT ? 0 : wave) * 64 + c);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        float v = acc[a][b][r] + bv;
-                        if (dm.relu) v = fmaxf(v, 0.f);
-                        *reinterpret_cast<uint16_t*>(obuf + row * kOutStride + (32 * b + nl) * 2) = f32_to_bf16(v);
+                    for (int a = 0; a < 2; ++a) {
+                        float v0 = acc[a][b][4 * q] + bb[0], v1 = acc[a][b][4 * q + 1] + bb[1];
+                        float v2 = acc[a][b][4 * q + 2] + bb[2], v3 = acc[a][b][4 * q + 3] + bb[3];
+                        if (dm.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        *reinterpret_cast<u32x2*>(obuf + (32 * a + nl) * kOutStride + c * 2) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
                     }
-            }
+                }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -255,7 +263,7 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
 template <int STRIDE, bool KSPLIT>
 hipError_t launch_conv(const void* x, const void* w, const void* bias, void* y, const ConvDims& dm, hipStream_t stream) {
     const void* kern = reinterpret_cast<const void*>(conv3x3_kernel<STRIDE, KSPLIT>);
-    constexpr int lds = Geo<STRIDE>::kLds;
+    constexpr int lds = Geo<STRIDE>::kLds + kThreads * 4;
     void* args[] = {&x, &w, &bias, &y, const_cast<ConvDims*>(&dm)};
     const unsigned gy = KSPLIT ? dm.Cout / 64 : (dm.Cout + 127) / 128;
     const int ntiles = dm.tiles_per_image * dm.N;

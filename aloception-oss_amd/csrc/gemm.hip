@@ -57,16 +57,21 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
     const int nl = lane & 31, kg = lane >> 5;       // MFMA lane roles: row/column inside a 32-tile, 8-element k group
 
     // ---- resident B operand: W[col0 + 32 t + nl][16 s + 8 kg .. + 8) for t < 2, s < kSteps ----------------------------------
+    // W is the MFMA's ROW operand (the product is computed transposed, Y^T = W X^T), so that a lane ends up holding 2 x 16
+    // output columns of ONE row of the tile, four consecutive columns per accumulator quad: they leave as 8-byte LDS writes.
     u32x4 wreg[2][kSteps];
-    float bias_v[2] = {0.f, 0.f};
+    // bias in accumulator order, [kg][t][16]: register r of lane (nl, kg) is column 32 t + (r & 3) + 8 (r >> 2) + 4 kg; the
+    // accumulators start from it
+    float* const bias_tab = reinterpret_cast<float*>(smem + kRows * kRowBytes + 4 * (kRows * kOutStride)) + wave * 64;
     if (has_cols) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bf16_t* wr = W + (size_t)(col0 + 32 * t + nl) * kK + 8 * kg;
 #pragma unroll
             for (int s = 0; s < kSteps; ++s) wreg[t][s] = *reinterpret_cast<const u32x4*>(wr + 16 * s);
-            if (bias != nullptr) bias_v[t] = bf16_to_f32(bias[col0 + 32 * t + nl].bits);
         }
+        const int r = lane & 15, t = (lane >> 4) & 1, k2 = lane >> 5;
+        bias_tab[lane] = bias != nullptr ? bf16_to_f32(bias[col0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * k2].bits) : 0.f;
     }
 
     // ---- tile loader: kRows rows x 2K bytes in 16-byte pieces; thread -> (row, piece) keeps rows contiguous.  Rows past the
@@ -107,25 +112,28 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_tab + (kg * 2 + t) * 16 + 4 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[t][4 * q + i] = b4[i];
+                    }
 #pragma unroll
                 for (int s = 0; s < kSteps; ++s) {
-                    // A fragment: X[tile row 32 half + nl][16 s + 8 kg .. + 8)
+                    // X fragment: X[tile row 32 half + nl][16 s + 8 kg .. + 8)
                     const u32x4 a = *reinterpret_cast<const u32x4*>(xbuf + (32 * half + nl) * kRowBytes + (16 * s + 8 * kg) * 2);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(wreg[0][s]), acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(wreg[1][s]), acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wreg[0][s]), as_bf16x8(a), acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wreg[1][s]), as_bf16x8(a), acc[1], 0, 0, 0);
                 }
-                // accumulator (lane = column nl, register r = row (r & 3) + 8 (r >> 2) + 4 kg) -> + bias -> bf16 -> LDS [row][col]
+                // lane = tile row 32 half + nl; registers 4 q .. 4 q + 3 = columns 32 t + 8 q + 4 kg .. + 3 -> bf16 -> LDS [row][col]
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * half + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        float v = acc[t][r] + bias_v[t];
-                        if (RELU && !HAS_RES) v = fmaxf(v, 0.f);
-                        *reinterpret_cast<uint16_t*>(obuf + row * kOutStride + (32 * t + nl) * 2) = f32_to_bf16(v);
+                    for (int q = 0; q < 4; ++q) {
+                        float v0 = acc[t][4 * q], v1 = acc[t][4 * q + 1], v2 = acc[t][4 * q + 2], v3 = acc[t][4 * q + 3];
+                        if (RELU && !HAS_RES) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        *reinterpret_cast<u32x2*>(obuf + (32 * half + nl) * kOutStride + (32 * t + 8 * q + 4 * kg) * 2) =
+                            u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
                     }
-                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -191,7 +199,7 @@ int launch_shortk(const void* x, const void* weight, const void* bias, const voi
                   hipStream_t stream, int S = 0) {
     GemmDims dm;
     dm.M = M; dm.N = N; dm.tiles = (int)((M + kRows - 1) / kRows); dm.S = S;
-    const size_t lds = kRows * (K * 2 + 16) + 4 * kRows * kOutStride;
+    const size_t lds = kRows * (K * 2 + 16) + 4 * kRows * kOutStride + 4 * 64 * sizeof(float);
     const int cols = (N + 255) / 256;
     int gx = 512 / cols;  // persistent: about two workgroups per CU in total
     if (gx > dm.tiles) gx = dm.tiles;
@@ -264,9 +272,13 @@ ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const
     const int nl = lane & 31, kg = lane >> 5;
     const int F = dm.F;
 
-    float b2v[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) b2v[t] = B2 ? bf16_to_f32(B2[64 * wave + 32 * t + nl].bits) : 0.f;
+    // biases as fp32 in LDS (b1: F values, b2: 256); the products are computed transposed (weights = the MFMA's row operand),
+    // so a lane owns ONE row of the tile and four consecutive columns per accumulator quad: bias, activation and the bf16
+    // conversion work on quads and leave as 8-byte LDS writes
+    float* const b1s = reinterpret_cast<float*>(smem + 2 * kFfnRows * kFfnStride);
+    float* const b2s = b1s + F;
+    for (int i = tid; i < F; i += 256) b1s[i] = B1 ? bf16_to_f32(B1[i].bits) : 0.f;
+    b2s[tid] = B2 ? bf16_to_f32(B2[tid].bits) : 0.f;
 
     // Weight fragments arrive in batches of KB k-steps (2 column tiles x KB x 16 B per lane) through two register buffers:
     // batch i+1 is requested before batch i is consumed, across phase and round boundaries too (L2 latency ~ the MFMA time
@@ -292,10 +304,10 @@ ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const u32x4 a0 = af[0][j], a1 = af[1][j];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(buf[0][j]), acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a0), as_bf16x8(buf[1][j]), acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(buf[0][j]), acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1), as_bf16x8(buf[1][j]), acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(buf[0][j]), as_bf16x8(a0), acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(buf[1][j]), as_bf16x8(a0), acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(buf[0][j]), as_bf16x8(a1), acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(buf[1][j]), as_bf16x8(a1), acc[1][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -354,17 +366,18 @@ ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const
                 mma_batch(acc1, xs, bufb, bt + 1);
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float bb = B1 ? bf16_to_f32(B1[r0 + 64 * wave + 32 * t + nl].bits) : 0.f;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int q = 0; q < 4; ++q) {
+                    const int col = 64 * wave + 32 * t + 8 * q + 4 * kg;  // registers 4 q .. 4 q + 3 = hidden units col .. col + 3
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + r0 + col);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        *reinterpret_cast<uint16_t*>(hs + row * kFfnStride + (64 * wave + 32 * t + nl) * 2) =
-                            f32_to_bf16(fmaxf(acc1[a][t][r] + bb, 0.f));
+                    for (int a = 0; a < 2; ++a) {
+                        const float v0 = fmaxf(acc1[a][t][4 * q] + bb[0], 0.f), v1 = fmaxf(acc1[a][t][4 * q + 1] + bb[1], 0.f);
+                        const float v2 = fmaxf(acc1[a][t][4 * q + 2] + bb[2], 0.f), v3 = fmaxf(acc1[a][t][4 * q + 3] + bb[3], 0.f);
+                        *reinterpret_cast<u32x2*>(hs + (32 * a + nl) * kFfnStride + col * 2) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
                     }
-            }
+                }
             __syncthreads();  // the whole 64 x 256 hidden chunk is in LDS
 
             // ---- phase 2: out[:, 64 wave ..] += h_chunk (64 x 256) W2[64 wave + ..][r0 .. r0 + 256)^T ------------------------
@@ -383,13 +396,15 @@ ffn256_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W1, const
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int q = 0; q < 4; ++q) {
+                const int col = 64 * wave + 32 * t + 8 * q + 4 * kg;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b2s + col);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    *reinterpret_cast<uint16_t*>(hs + row * kFfnStride + (64 * wave + 32 * t + nl) * 2) =
-                        f32_to_bf16(acc2[a][t][r] + b2v[t]);
-                }
+                for (int a = 0; a < 2; ++a)
+                    *reinterpret_cast<u32x2*>(hs + (32 * a + nl) * kFfnStride + col * 2) =
+                        u32x2{pack_bf16x2(acc2[a][t][4 * q] + bb[0], acc2[a][t][4 * q + 1] + bb[1]),
+                              pack_bf16x2(acc2[a][t][4 * q + 2] + bb[2], acc2[a][t][4 * q + 3] + bb[3])};
+            }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -447,7 +462,7 @@ extern "C" int alo_ffn256(const void* x, const void* w1, const void* b1, const v
                 "alo_ffn256: pointers must be 16-byte aligned");
     FfnDims dm;
     dm.M = M; dm.F = F; dm.tiles = (int)((M + kFfnRows - 1) / kFfnRows);
-    const size_t lds = 2 * kFfnRows * kFfnStride;
+    const size_t lds = 2 * kFfnRows * kFfnStride + ((size_t)F + 256) * sizeof(float);
     int gx = dm.tiles < 512 ? dm.tiles : 512;
     void* args[] = {&x, &w1, &b1, &w2, &b2, &y, &dm};
     static bool attr_set = false;
