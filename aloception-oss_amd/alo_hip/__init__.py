@@ -71,7 +71,9 @@ def _declare(lib):
     lib.alo_value_proj_head_major.restype = ip
     lib.alo_value_proj_head_major.argtypes = [vp] * 5 + [ip] * 5 + [vp]
     lib.alo_conv3x3_nhwc.restype = ip
-    lib.alo_conv3x3_nhwc.argtypes = [vp] * 4 + [ip] * 8 + [vp]
+    lib.alo_conv3x3_nhwc.argtypes = [vp] * 5 + [ip] * 8 + [vp]
+    lib.alo_conv3x3_workspace_bytes.restype = c.c_size_t
+    lib.alo_conv3x3_workspace_bytes.argtypes = [ip] * 6
     lib.alo_stem_conv_pool.restype = ip
     lib.alo_stem_conv_pool.argtypes = [vp] * 4 + [ip] * 3 + [c.c_long] * 4 + [ip, vp]
     lib.alo_groupnorm_rows_workspace_bytes.restype = c.c_size_t
@@ -669,9 +671,12 @@ def conv3x3(x, weight, bias=None, relu=False, stride=1):
     ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
     y = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     bias_c = None if bias is None else bias.contiguous()
+    ws_bytes = lib().alo_conv3x3_workspace_bytes(n, h, w_, cin, cout, stride)   # split-K partial sums (few-tile shapes only)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with torch.cuda.device(x.device), _timed(f"conv3x3/C={cin}/s={stride}", 2.0 * (x.numel() + y.numel()), 2.0 * 9 * cin * y.numel()):
-        _check(lib().alo_conv3x3_nhwc(_ptr(x), _ptr(hit[1]), None if bias_c is None else _ptr(bias_c), _ptr(y), n, h, w_, cin,
-                                      cout, stride, 1 if relu else 0, ALO_BF16, _stream(x.device)))
+        _check(lib().alo_conv3x3_nhwc(_ptr(x), _ptr(hit[1]), None if bias_c is None else _ptr(bias_c), _ptr(y),
+                                      None if ws is None else _ptr(ws), n, h, w_, cin, cout, stride, 1 if relu else 0, ALO_BF16,
+                                      _stream(x.device)))
     return y
 
 

@@ -49,6 +49,7 @@ struct ConvDims {
     int N, H, W, Ho, Wo, Cin, Cout;
     int tiles_per_image;
     int relu;
+    int zsplit, cin_per_z;   // split-K over gridDim.z: workgroup z reduces input channels [z * cin_per_z, + cin_per_z)
 };
 
 struct WFrag { u32x4 v[2][2]; };    // [k-step of the batch][column tile]
@@ -77,7 +78,7 @@ __device__ __forceinline__ int slot_pixel(int slot, int p0, const ConvDims& dm) 
 template <int STRIDE, bool KSPLIT>
 __global__ void __launch_bounds__(kThreads, 2)
 conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, const bf16_t* __restrict__ bias,
-               bf16_t* __restrict__ Y, const ConvDims dm) {
+               bf16_t* __restrict__ Y, float* __restrict__ partial, const ConvDims dm) {
     using G = Geo<STRIDE>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const halo = smem;
@@ -122,7 +123,8 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
                 stage[it] = *reinterpret_cast<const u32x4*>(ximg + (size_t)slot_pixel<STRIDE>(slot, first, dm) * dm.Cin + piece * 8);
         }
     };
-    load_halo(tile, 0);
+    const int cbeg = blockIdx.z * dm.cin_per_z, cend = cbeg + dm.cin_per_z;
+    load_halo(tile, cbeg);
 
     for (; tile < tile_end; tile += lanes_per_xcd) {
         const int img = tile / dm.tiles_per_image;
@@ -151,7 +153,7 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-        for (int c0 = 0; c0 < dm.Cin; c0 += G::kChunk) {
+        for (int c0 = cbeg; c0 < cend; c0 += G::kChunk) {
             // weights of batch kb of this chunk: tap kb / kBpt, k-steps 2 (kb % kBpt) and + 1 of the chunk
             auto load_w = [&](WFrag& f, int kb) {
                 const bf16_t* p = wfrag + (size_t)((kb / G::kBpt) * ksteps_per_tap + c0 / 16 + 2 * (kb % G::kBpt)) * 512;
@@ -189,8 +191,8 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
                 if (i < G::kPieces) *reinterpret_cast<u32x4*>(halo + slot * G::kPixStride + piece * 16) = stage[it];
             }
             __syncthreads();
-            if (c0 + G::kChunk < dm.Cin) load_halo(tile, c0 + G::kChunk);
-            else if (tile + lanes_per_xcd < tile_end) load_halo(tile + lanes_per_xcd, 0);
+            if (c0 + G::kChunk < cend) load_halo(tile, c0 + G::kChunk);
+            else if (tile + lanes_per_xcd < tile_end) load_halo(tile + lanes_per_xcd, cbeg);
 
             if (has_cols) {
 #pragma unroll 1
@@ -225,7 +227,25 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
             }
         }
 
-        if (has_cols && !(KSPLIT && wave == 1)) {
+        if (!KSPLIT && dm.zsplit > 1) {
+            // split-K: the raw fp32 partial sums of this channel range go to partial[z][pixel][channel]; conv_splitk_finalize_kernel
+            // adds the ranges up in a fixed order (deterministic), then bias / ReLU / bf16
+            if (has_cols) {
+                float* pz = partial + ((size_t)blockIdx.z * dm.N + img) * HWo * dm.Cout + col0;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int q = p0 + 32 * a + nl;
+                    if (q < HWo) {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int qd = 0; qd < 4; ++qd)
+                                *reinterpret_cast<f32x4*>(pz + (size_t)q * dm.Cout + 32 * b + 8 * qd + 4 * kg) =
+                                    f32x4{acc[a][b][4 * qd], acc[a][b][4 * qd + 1], acc[a][b][4 * qd + 2], acc[a][b][4 * qd + 3]};
+                    }
+                }
+            }
+        } else if (has_cols && !(KSPLIT && wave == 1)) {
             unsigned char* const obuf = smem + (KSPLIT ? 0 : wave) * (kPix * kOutStride);
             // the product is computed transposed (weights = the MFMA's row operand): lane = output pixel 32 a + nl, registers
             // 4 q .. 4 q + 3 = channels col0 + 32 b + 8 q + 4 kg .. + 3 -> bias, ReLU, bf16, one 8-byte LDS write per quad
@@ -260,16 +280,49 @@ conv3x3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp, cons
     }
 }
 
+// y[p][c] = act(sum_z partial[z][p][c] + bias[c]) -> bf16; one thread per 8 channels
+__global__ void __launch_bounds__(256)
+conv_splitk_finalize_kernel(const float* __restrict__ partial, const bf16_t* __restrict__ bias, bf16_t* __restrict__ Y, long rows,
+                            int Cout, int Z, int relu) {
+    const long n8 = rows * (Cout / 8);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const int c = (int)(e % Cout);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bias ? bf16_to_f32(bias[c + j].bits) : 0.f;
+        for (int z = 0; z < Z; ++z) {
+            const float* p = partial + (size_t)z * rows * Cout + e;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+        }
+        if (relu)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        *reinterpret_cast<u32x4*>(Y + e) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    }
+}
+
+// split-K factor: only when the tiles alone leave most of the chip idle (the 2048 -> 256 input projection: 80 workgroups)
+int conv_zsplit(int ntiles, int Cin, int Cout) {
+    if (Cout == 64) return 1;
+    const int base = ntiles * ((Cout + 127) / 128);
+    int z = 1;
+    while (base * z * 2 <= 1024 && Cin % (z * 2 * 64) == 0 && Cin / (z * 2) >= 128) z *= 2;
+    return z;
+}
+
 template <int STRIDE, bool KSPLIT>
-hipError_t launch_conv(const void* x, const void* w, const void* bias, void* y, const ConvDims& dm, hipStream_t stream) {
+hipError_t launch_conv(const void* x, const void* w, const void* bias, void* y, void* partial, const ConvDims& dm, hipStream_t stream) {
     const void* kern = reinterpret_cast<const void*>(conv3x3_kernel<STRIDE, KSPLIT>);
     constexpr int lds = Geo<STRIDE>::kLds + kThreads * 4;
-    void* args[] = {&x, &w, &bias, &y, const_cast<ConvDims*>(&dm)};
+    void* args[] = {&x, &w, &bias, &y, &partial, const_cast<ConvDims*>(&dm)};
     const unsigned gy = KSPLIT ? dm.Cout / 64 : (dm.Cout + 127) / 128;
     const int ntiles = dm.tiles_per_image * dm.N;
     int per_xcd = (ntiles + 7) / 8;
     if (per_xcd > 128) per_xcd = 128;   // 32 CUs per XCD x up to 4 resident workgroups
-    return hipLaunchKernel(kern, dim3((unsigned)(8 * per_xcd), gy), dim3(kThreads), args, lds, stream);
+    return hipLaunchKernel(kern, dim3((unsigned)(8 * per_xcd), gy, (unsigned)dm.zsplit), dim3(kThreads), args, lds, stream);
 }
 
 }  // namespace
@@ -277,15 +330,22 @@ hipError_t launch_conv(const void* x, const void* w, const void* bias, void* y, 
 
 using namespace alo;
 
-extern "C" int alo_conv3x3_nhwc(const void* x, const void* w_packed, const void* bias, void* y, int N, int H, int W, int Cin,
-                                int Cout, int stride, int relu, int dtype, void* stream) {
+extern "C" size_t alo_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return 0;
+    const long hwo = (long)((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+    const int z = conv_zsplit((int)((hwo + kPix - 1) / kPix) * N, Cin, Cout);
+    return z > 1 ? (size_t)z * N * hwo * Cout * sizeof(float) : 0;
+}
+
+extern "C" int alo_conv3x3_nhwc(const void* x, const void* w_packed, const void* bias, void* y, void* workspace, int N, int H,
+                                int W, int Cin, int Cout, int stride, int relu, int dtype, void* stream) {
     ALO_REQUIRE(x && w_packed && y, ALO_ERR_INVALID_ARGUMENT, "alo_conv3x3_nhwc: null pointer argument");
     ALO_REQUIRE(N > 0 && H > 0 && W > 0, ALO_ERR_INVALID_ARGUMENT, "alo_conv3x3_nhwc: N, H, W must be positive");
     ALO_REQUIRE(stride == 1 || stride == 2, ALO_ERR_UNSUPPORTED, "alo_conv3x3_nhwc: stride must be 1 or 2 (got %d)", stride);
     ALO_REQUIRE(Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0, ALO_ERR_UNSUPPORTED,
                 "alo_conv3x3_nhwc: Cin and Cout must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
     ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_conv3x3_nhwc: bf16 only (dtype %d)", dtype);
-    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y | (uintptr_t)workspace) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
                 "alo_conv3x3_nhwc: pointers must be 16-byte aligned");
     ALO_REQUIRE((long)H * W < (1L << 24) && (long)N * H * W * (long)(Cin > Cout ? Cin : Cout) < (1L << 40), ALO_ERR_UNSUPPORTED,
                 "alo_conv3x3_nhwc: image too large");
@@ -294,10 +354,22 @@ extern "C" int alo_conv3x3_nhwc(const void* x, const void* w_packed, const void*
     dm.Ho = (H - 1) / stride + 1;
     dm.Wo = (W - 1) / stride + 1;
     dm.tiles_per_image = (dm.Ho * dm.Wo + kPix - 1) / kPix;
+    dm.zsplit = workspace ? conv_zsplit(dm.tiles_per_image * N, Cin, Cout) : 1;   // no workspace: no split-K
+    dm.cin_per_z = Cin / dm.zsplit;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool ksplit = Cout == 64;
-    hipError_t e = stride == 1 ? (ksplit ? launch_conv<1, true>(x, w_packed, bias, y, dm, s) : launch_conv<1, false>(x, w_packed, bias, y, dm, s))
-                               : (ksplit ? launch_conv<2, true>(x, w_packed, bias, y, dm, s) : launch_conv<2, false>(x, w_packed, bias, y, dm, s));
+    hipError_t e = stride == 1 ? (ksplit ? launch_conv<1, true>(x, w_packed, bias, y, workspace, dm, s) : launch_conv<1, false>(x, w_packed, bias, y, workspace, dm, s))
+                               : (ksplit ? launch_conv<2, true>(x, w_packed, bias, y, workspace, dm, s) : launch_conv<2, false>(x, w_packed, bias, y, workspace, dm, s));
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_conv3x3_nhwc: %s", hipGetErrorString(e));
+    if (dm.zsplit > 1) {
+        const long rows = (long)N * dm.Ho * dm.Wo;
+        const float* part = static_cast<const float*>(workspace);
+        int z = dm.zsplit;
+        long blocks = (rows * (Cout / 8) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        void* args[] = {&part, &bias, &y, const_cast<long*>(&rows), &Cout, &z, &relu};
+        e = hipLaunchKernel(reinterpret_cast<const void*>(conv_splitk_finalize_kernel), dim3((unsigned)blocks), dim3(256), args, 0, s);
+        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_conv3x3_nhwc (finalize): %s", hipGetErrorString(e));
+    }
     return check_launch("alo_conv3x3_nhwc");
 }

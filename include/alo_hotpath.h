@@ -238,10 +238,13 @@ int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, co
  * accumulation: Bottleneck.conv2 + the folded FrozenBatchNorm2d + ReLU of the ResNet backbone (alonet/detr/backbone.py:19-47,
  * 84-92; torchvision Bottleneck), an implicit GEMM on MFMA.  Ho = (H - 1) / stride + 1.  w_packed = alo_pack_mfma_b of the
  * (Cout, 9 * Cin) matrix w[o][(ky * 3 + kx) * Cin + c] (= the channels-last memory order of a (Cout, Cin, 3, 3) weight).
- * Cin % 64 == 0, Cout % 64 == 0; bias may be NULL.
+ * Cin % 64 == 0, Cout % 64 == 0; bias may be NULL.  When the output has too few tiles to fill the chip (the 2048 -> 256 input
+ * projection, alonet/deformable_detr/deformable_detr.py:75-84) the reduction is split over the input channels: workspace is then
+ * alo_conv3x3_workspace_bytes(...) bytes (0 = not needed; NULL = never split) of fp32 partial sums, added up in a fixed order.
  */
-int alo_conv3x3_nhwc(const void* x, const void* w_packed, const void* bias, void* y, int N, int H, int W, int Cin, int Cout,
-                     int stride, int relu, int dtype, void* stream);
+size_t alo_conv3x3_workspace_bytes(int N, int H, int W, int Cin, int Cout, int stride);
+int alo_conv3x3_nhwc(const void* x, const void* w_packed, const void* bias, void* y, void* workspace, int N, int H, int W, int Cin,
+                     int Cout, int stride, int relu, int dtype, void* stream);
 
 /*
  * alo_stem_conv_pool: the ResNet stem in one kernel — y (N, Hp, Wp, 64) = maxpool3x3/s2/p1(relu(conv7x7/s2/p3(x) + bias)), bf16 with

@@ -253,7 +253,7 @@ def test_value_proj_head_major_equals_linear_then_relayout(N, S, heads, K, with_
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 128, 25, 42), (1, 256, 7, 9), (3, 512, 5, 70), (1, 128, 1, 1), (2, 128, 64, 3),
-                                   (2, 64, 30, 41), (1, 64, 2, 2)])
+                                   (2, 64, 30, 41), (1, 64, 2, 2), (2, 1024, 13, 11)])   # the last one takes the split-K route
 @pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("relu,with_bias", [(True, True), (False, False)])
 def test_conv3x3_matches_fp32_convolution(shape, stride, relu, with_bias):
