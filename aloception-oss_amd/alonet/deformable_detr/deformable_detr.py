@@ -225,23 +225,34 @@ class DeformableDETR(nn.Module):
         x0 = features[1][0]
         return x0.new_empty((x0.shape[0], start, self.input_proj[0][0].out_channels)), slots
 
+    @staticmethod
+    def _shared(heads):
+        """True when every decoder level uses the SAME head module (no box refinement): the levels can go through it at once."""
+        return all(m is heads[0] for m in heads)
+
     def forward_position_heads(self, transformer_outputs):
         hs = transformer_outputs["hs"]
         init_ref, inter_refs = transformer_outputs["init_reference_out"], transformer_outputs["inter_references_out"]
-        coords = []
-        for lvl in range(hs.shape[0]):
-            reference = inverse_sigmoid(init_ref if lvl == 0 else inter_refs[lvl - 1])
-            tmp = self.bbox_embed[lvl](hs[lvl])
+
+        def boxes(tmp, reference):
             if reference.shape[-1] == 4:
                 tmp = tmp + reference
             else:
                 assert reference.shape[-1] == 2
                 tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], -1)
-            coords.append(tmp.sigmoid())
-        return coords
+            return tmp.sigmoid()
+
+        if self._shared(self.bbox_embed) and hs.dim() == 4 and inter_refs.dim() == 4 and hs.shape[0] > 1:
+            # one pass over all levels instead of ~14 small kernels per level (level l refines reference l - 1)
+            refs = torch.cat([init_ref.unsqueeze(0).to(inter_refs.dtype), inter_refs[:hs.shape[0] - 1]], 0)
+            return list(boxes(self.bbox_embed[0](hs), inverse_sigmoid(refs)).unbind(0))
+        return [boxes(self.bbox_embed[lvl](hs[lvl]), inverse_sigmoid(init_ref if lvl == 0 else inter_refs[lvl - 1]))
+                for lvl in range(hs.shape[0])]
 
     def forward_class_heads(self, transformer_outputs):
         hs = transformer_outputs["hs"]
+        if self._shared(self.class_embed) and hs.dim() == 4:
+            return self.class_embed[0](hs)
         return torch.stack([self.class_embed[lvl](hs[lvl]) for lvl in range(hs.shape[0])])
 
     def forward_heads(self, transformer_outputs, bb_outputs=None, **kwargs):
