@@ -80,6 +80,8 @@ def _declare(lib):
     lib.alo_groupnorm_rows_workspace_bytes.argtypes = [ip, ip, ip]
     lib.alo_groupnorm_rows.restype = ip
     lib.alo_groupnorm_rows.argtypes = [vp] * 5 + [ip] * 4 + [c.c_float, c.c_long, ip, vp]
+    lib.alo_linear_packed.restype = ip
+    lib.alo_linear_packed.argtypes = [vp] * 5 + [c.c_long, ip, ip, ip, ip, vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -587,16 +589,59 @@ def linear_shortk(x, weight, bias=None, relu=False, residual=None):
     return y.view(*x.shape[:-1], N)
 
 
-def linear_auto(x, weight, bias=None, relu=False):
-    """Inference-time ``act(F.linear(x, weight, bias))``: the streaming MFMA kernel when the shape allows it (bf16, K in
-    {64, 128, 256}, N % 64 == 0), otherwise the stock GEMM with the bias / ReLU epilogue."""
-    if linear_shortk_supported(x, weight) and (bias is None or bias.dtype == x.dtype):
-        return linear_shortk(x, weight, bias, relu)
+def linear_packed_supported(x, weight):
+    """bf16 CUDA, K % 256 == 0 (K >= 512: below that linear_shortk keeps the weights in registers), N % 128 == 0, inference."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
+            and x.shape[-1] == weight.shape[1] and weight.shape[1] % 256 == 0 and weight.shape[1] >= 512
+            and weight.shape[0] % 128 == 0 and not torch.is_grad_enabled())
+
+
+def linear_packed(x, weight, bias=None, relu=False, residual=None):
+    """``act(F.linear(x, weight, bias) [+ residual])`` with the weight streamed in MFMA fragment order (packed once per weight
+    version, cached on the tensor)."""
+    if not linear_packed_supported(x, weight):
+        raise RuntimeError("linear_packed: needs bf16 CUDA tensors, K % 256 == 0, K >= 512, N % 128 == 0, no autograd")
     x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M, K = x2.shape
+    N = weight.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        residual = residual.reshape(M, N)
+        if residual.dtype != x.dtype or not residual.is_contiguous():
+            raise RuntimeError("linear_packed: residual must be a contiguous (M, N) tensor of the input's dtype")
+    if M:
+        packed = pack_mfma_b(weight)
+        bias_c = None if bias is None else bias.to(x.dtype).contiguous()
+        with torch.cuda.device(x.device), _timed(f"linear_packed/K={K}/N={N}", 2.0 * (M * K + M * N * (2 if residual is not None else 1)),
+                                                 2.0 * M * N * K):
+            _check(lib().alo_linear_packed(_ptr(x2), _ptr(packed), None if bias_c is None else _ptr(bias_c),
+                                           None if residual is None else _ptr(residual), _ptr(y), M, N, K, 1 if relu else 0,
+                                           ALO_BF16, _stream(x.device)))
+    return y.view(*x.shape[:-1], N)
+
+
+def linear_auto(x, weight, bias=None, relu=False, residual=None):
+    """Inference-time ``act(F.linear(x, weight, bias) [+ residual])``: the streaming MFMA kernels when the shape allows it
+    (bf16; K in {64, 128, 256} with N % 64 == 0, or K % 256 == 0 with N % 128 == 0), otherwise the stock GEMM with the bias /
+    ReLU epilogue."""
+    if linear_shortk_supported(x, weight) and (bias is None or bias.dtype == x.dtype):
+        return linear_shortk(x, weight, bias, relu, residual=residual)
+    if linear_packed_supported(x, weight) and (bias is None or bias.dtype == x.dtype) and (
+            residual is not None or weight.shape[0] >= 1024 or tuple(weight.shape) == (128, 512)):
+        # measured on MI355X at the backbone's shapes: the streaming kernel wins with many output columns, with the identity
+        # fused in, and at (N, K) = (128, 512); hipBLASLt wins the rest
+        return linear_packed(x, weight, bias, relu, residual=residual)
+    x2 = x.reshape(-1, x.shape[-1])
+    fused_act = relu and residual is None
     if bias is not None:
-        y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False) if relu else torch.addmm(bias, x2, weight.t())
+        y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False) if fused_act else torch.addmm(bias, x2, weight.t())
     else:
         y = torch.mm(x2, weight.t())
+        y = torch.relu_(y) if fused_act else y
+    if residual is not None:
+        y = y + residual.reshape(y.shape)
         y = torch.relu_(y) if relu else y
     return y.view(*x.shape[:-1], weight.shape[0])
 

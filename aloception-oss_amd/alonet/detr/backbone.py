@@ -37,16 +37,29 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.reshape(1, -1, 1, 1).to(x.dtype) + shift.reshape(1, -1, 1, 1).to(x.dtype)
 
 
-def conv1x1_as_gemm(x, weight, bias, stride=(1, 1), relu=False):
-    """1x1 convolution of a channels-last ``x`` (N,Cin,H,W) as ``rows @ W^T`` on hipBLASLt -> channels-last (N,Cout,H',W').
-    ``bias`` and ReLU ride in the GEMM epilogue (``torch._addmm_activation``); a strided convolution first gathers the
-    kept pixels (a quarter of the map)."""
+def _weight_2d(weight):
+    """(Cout, Cin, 1, 1) -> (Cout, Cin), the SAME view object every call: the packed copy the streaming kernels make rides on it."""
+    w2 = weight.__dict__.get("_alo_2d") if hasattr(weight, "__dict__") else None
+    if w2 is None or w2._version != weight._version or w2.data_ptr() != weight.data_ptr():
+        w2 = weight.reshape(weight.shape[0], -1)
+        try:
+            weight._alo_2d = w2
+        except AttributeError:
+            pass
+    return w2
+
+
+def conv1x1_as_gemm(x, weight, bias, stride=(1, 1), relu=False, residual=None):
+    """1x1 convolution of a channels-last ``x`` (N,Cin,H,W) as ``rows @ W^T`` -> channels-last (N,Cout,H',W'): the streaming
+    MFMA kernels (bias, identity and ReLU in their epilogue) when the shape allows it, otherwise hipBLASLt with the bias / ReLU
+    epilogue (``torch._addmm_activation``).  A strided convolution first gathers the kept pixels (a quarter of the map).
+    ``residual``: channels-last (N,Cout,H',W'), added before the activation."""
     if tuple(stride) != (1, 1):
         x = x[:, :, ::stride[0], ::stride[1]]
     n, cin, h, w_ = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(-1, cin)  # a view for stride 1 (NHWC rows are contiguous), one gather otherwise
-    # few input channels (64 / 128 / 256, bf16): the streaming MFMA kernel; otherwise hipBLASLt with the epilogue
-    out = alo_hip.linear_auto(rows, weight.reshape(weight.shape[0], cin), bias, relu)
+    res_rows = None if residual is None else residual.permute(0, 2, 3, 1).reshape(-1, weight.shape[0])
+    out = alo_hip.linear_auto(rows, _weight_2d(weight), bias, relu, residual=res_rows)
     return out.view(n, h, w_, -1).permute(0, 3, 1, 2)
 
 
@@ -84,15 +97,15 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
             if conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and w.shape[0] % 4 == 0:
                 # a 1x1 convolution over NHWC rows IS a matrix product: hipBLASLt runs it 1.5-6x faster than MIOpen's
                 # implicit-GEMM kernels at these shapes and takes bias + ReLU in its epilogue
-                if residual is not None and tuple(conv.stride) == (1, 1) and alo_hip.linear_shortk_supported(
-                        x.permute(0, 2, 3, 1), w.reshape(w.shape[0], -1)) and residual.is_contiguous(memory_format=torch.channels_last):
-                    # few input channels: bias + identity + ReLU ride in the epilogue of the streaming GEMM
-                    n, _, h, w_ = x.shape
-                    out = alo_hip.linear_shortk(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), w.reshape(w.shape[0], -1), b, relu,
-                                                residual=residual.permute(0, 2, 3, 1).reshape(-1, w.shape[0]))
-                    return out.view(n, h, w_, -1).permute(0, 3, 1, 2)
-                out = conv1x1_as_gemm(x, w, b if residual is None else None, conv.stride, relu=relu and residual is None)
-                return out if residual is None else alo_hip.bias_act_(out, b, residual, relu)
+                rows_probe = x.permute(0, 2, 3, 1)
+                w2 = _weight_2d(w)
+                if residual is None or (tuple(conv.stride) == (1, 1) and residual.is_contiguous(memory_format=torch.channels_last)
+                                        and (alo_hip.linear_shortk_supported(rows_probe, w2)
+                                             or alo_hip.linear_packed_supported(rows_probe, w2))):
+                    # bias + identity + ReLU ride in the epilogue of the streaming GEMM
+                    return conv1x1_as_gemm(x, w, b, conv.stride, relu=relu, residual=residual)
+                out = conv1x1_as_gemm(x, w, None, conv.stride)
+                return alo_hip.bias_act_(out, b, residual, relu)
             if residual is None and alo_hip.conv3x3_supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
                 # the bottleneck's 3x3: implicit GEMM on MFMA, bias + ReLU in its epilogue (2-3.5x MIOpen at these shapes)
                 return alo_hip.conv3x3(x, w, b, relu, conv.stride)

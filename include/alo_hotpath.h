@@ -234,6 +234,14 @@ int alo_ffn256(const void* x, const void* w1, const void* b1, const void* w2, co
                int dtype, void* stream);
 
 /*
+ * alo_linear_packed: y (M, N) = act(x (M, K) @ w (N, K)^T + bias [+ residual]) for the long-K 1x1 convolutions of the backbone and the
+ * 1x1 input projections over NHWC rows (alonet/detr/backbone.py:19-47, deformable_detr.py:75-84): bf16, fp32 accumulation,
+ * K % 256 == 0, N % 128 == 0.  w_packed = alo_pack_mfma_b(w).  residual (M, N) or NULL is added before the activation.
+ */
+int alo_linear_packed(const void* x, const void* w_packed, const void* bias, const void* residual, void* y, long M, int N, int K,
+                      int relu, int dtype, void* stream);
+
+/*
  * alo_conv3x3_nhwc: y (N, Ho, Wo, Cout) = act(conv3x3(x (N, H, W, Cin), stride 1 or 2, padding 1) + bias), bf16 with fp32
  * accumulation: Bottleneck.conv2 + the folded FrozenBatchNorm2d + ReLU of the ResNet backbone (alonet/detr/backbone.py:19-47,
  * 84-92; torchvision Bottleneck), an implicit GEMM on MFMA.  Ho = (H - 1) / stride + 1.  w_packed = alo_pack_mfma_b of the

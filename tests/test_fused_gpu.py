@@ -347,3 +347,24 @@ def test_groupnorm_rows_matches_group_norm(B, HW, C, groups):
     with torch.no_grad():
         alone = alo_hip.groupnorm_rows(x, wt, b, groups, 1e-5)
     assert torch.equal(alone, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(1000, 512, 128), (77, 1024, 256), (130, 2048, 512), (64, 512, 2048), (1, 768, 384)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_linear_packed_matches_fp32_linear(M, K, N, relu, res):
+    """alo_linear_packed against F.linear in fp32 on the same bf16 inputs (the identity is added to the bf16-rounded product,
+    as the unfused conv -> add -> relu sequence does)."""
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16) if res else None
+    with torch.no_grad():
+        ref = F.linear(x.float(), w.float(), b.float())
+        if res:
+            ref = ref.to(torch.bfloat16).float() + r.float()
+        if relu:
+            ref = F.relu(ref)
+        got = alo_hip.linear_packed(x, w, b, relu, residual=r)
+    assert (got.float() - ref).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
