@@ -330,8 +330,17 @@ def test_head_major_path_is_bit_identical_and_masks_padding(N, M, D, Lq, ref_dim
     assert torch.equal(alo_hip.value_head_major(value, None), value.permute(0, 2, 1, 3))
     got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
     want = alo_hip.msda_forward_fused(value.masked_fill(mask[..., None, None], 0), shapes, start, offsets, logits, ref)
-    if os.environ.get("ALO_MSDA_MFMA") == "0":  # tuning knob: the pixel-major call then runs the generic (VALU) kernel
+    paired = D == 32 and os.environ.get("ALO_MSDA_PAIRED", "0") == "1"
+    if os.environ.get("ALO_MSDA_MFMA") == "0" or paired:
+        # tuning knob: the pixel-major call then runs the generic (VALU) kernel; D = 32: the x-paired kernel adds the left and the
+        # right tap columns separately (same exact products, another order of the fp32 additions): one bf16 ulp at most
         assert ((got.float() - want.float()).abs() <= want.float().abs() * 2.0 ** -7 + 1e-6).all()
+        # ... and against the float64 definition itself
+        loc, attn = _prologue_in_torch(offsets.float(), logits.float(), ref, shapes, 4)
+        exact = O.msda_forward(value.masked_fill(mask[..., None, None], 0).double().cpu().numpy(), shapes.cpu().numpy(),
+                               start.cpu().numpy(), loc.double().cpu().numpy(), attn.double().cpu().numpy())
+        err = np.abs(got.double().cpu().numpy() - exact)
+        assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)   # half a bf16 ulp + the fp32 prologue (hardware exp / rcp)
     else:
         assert torch.equal(got, want)
 
