@@ -82,6 +82,10 @@ def _declare(lib):
     lib.alo_groupnorm_rows.argtypes = [vp] * 5 + [ip] * 4 + [c.c_float, c.c_long, ip, vp]
     lib.alo_linear_packed.restype = ip
     lib.alo_linear_packed.argtypes = [vp] * 5 + [c.c_long, ip, ip, ip, ip, vp]
+    lib.alo_mask_pyramid.restype = ip
+    lib.alo_mask_pyramid.argtypes = [vp, ip, vp, vp, ip, ip, ip, ip, c.POINTER(c.c_int), c.c_uint, vp]
+    lib.alo_encoder_reference_points.restype = ip
+    lib.alo_encoder_reference_points.argtypes = [vp, vp, ip, ip, c.POINTER(c.c_int), vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -786,6 +790,54 @@ def groupnorm_rows(x, weight, bias, groups, eps=1e-5, out=None):
             _check(lib().alo_groupnorm_rows(_ptr(x), _ptr(weight.contiguous()), _ptr(bias.contiguous()), _ptr(out), _ptr(ws), b_, hw,
                                             c_, groups, float(eps), out.stride(0) if b_ > 1 else hw * c_, ALO_BF16,
                                             _stream(x.device)))
+    return out
+
+
+def _host_shapes(shapes):
+    flat = [int(v) for hw in shapes for v in hw]
+    return (ctypes.c_int * len(flat))(*flat), len(flat) // 2
+
+
+def mask_pyramid(frame_mask, shapes, nearest_levels=()):
+    """Padding mask of every level + valid ratios from the frame mask, in two small kernels.
+
+    frame_mask: (B, H, W) or (B, 1, H, W), float32 or bool / uint8, non-zero on padding.  shapes: [(h_l, w_l)].  Level l is
+    resized like ``F.interpolate(mask.float(), (h_l, w_l), mode="bilinear", align_corners=False) != 0``, or with
+    ``mode="nearest"`` for l in ``nearest_levels``.  Returns (mask_flat (B, S) bool, valid_ratios (B, L, 2) float32 as (w, h))."""
+    if frame_mask.dim() == 4:
+        frame_mask = frame_mask[:, 0]
+    if not frame_mask.is_cuda or frame_mask.dim() != 3:
+        raise RuntimeError("mask_pyramid: needs a CUDA (B, H, W) or (B, 1, H, W) mask")
+    if frame_mask.dtype not in (torch.float32, torch.bool, torch.uint8):
+        frame_mask = frame_mask != 0
+    frame_mask = frame_mask.contiguous()
+    b_, h, w_ = frame_mask.shape
+    arr, L = _host_shapes(shapes)
+    S = sum(int(a) * int(b) for a, b in shapes)
+    mask_flat = torch.empty((b_, S), dtype=torch.uint8, device=frame_mask.device)
+    ratios = torch.empty((b_, L, 2), dtype=torch.float32, device=frame_mask.device)
+    bits = 0
+    for l in nearest_levels:
+        bits |= 1 << int(l)
+    with torch.cuda.device(frame_mask.device), _timed("mask_pyramid", float(frame_mask.numel() + mask_flat.numel())):
+        _check(lib().alo_mask_pyramid(_ptr(frame_mask), 1 if frame_mask.dtype == torch.float32 else 0, _ptr(mask_flat), _ptr(ratios),
+                                      b_, h, w_, L, arr, bits, _stream(frame_mask.device)))
+    return mask_flat.view(torch.bool), ratios
+
+
+def encoder_reference_points(valid_ratios, shapes):
+    """(B, S, L, 2) float32 reference points of the encoder (pixel centres over the valid extent) in one kernel."""
+    if not valid_ratios.is_cuda or valid_ratios.dtype != torch.float32 or valid_ratios.dim() != 3 or valid_ratios.shape[2] != 2:
+        raise RuntimeError("encoder_reference_points: needs CUDA float32 valid ratios of shape (B, L, 2)")
+    valid_ratios = valid_ratios.contiguous()
+    arr, L = _host_shapes(shapes)
+    if L != valid_ratios.shape[1]:
+        raise RuntimeError("encoder_reference_points: one (h, w) per level of valid_ratios")
+    S = sum(int(a) * int(b) for a, b in shapes)
+    out = torch.empty((valid_ratios.shape[0], S, L, 2), dtype=torch.float32, device=valid_ratios.device)
+    with torch.cuda.device(valid_ratios.device), _timed("encoder_reference_points", 4.0 * out.numel()):
+        _check(lib().alo_encoder_reference_points(_ptr(valid_ratios), _ptr(out), valid_ratios.shape[0], L, arr,
+                                                  _stream(valid_ratios.device)))
     return out
 
 

@@ -15,7 +15,7 @@ from torch import nn
 import alo_hip
 import aloscene
 from alonet.common import load_weights
-from alonet.detr.backbone import conv1x1_as_gemm
+from alonet.detr.backbone import _resize_mask, conv1x1_as_gemm
 from alonet.detr.misc import assert_and_export_onnx
 from alonet.transformers import MLP, PositionEmbeddingSine
 
@@ -137,23 +137,29 @@ class DeformableDETR(nn.Module):
                     and isinstance(self.backbone[1], PositionEmbeddingSine) and self.backbone[1].num_pos_feats % 4 == 0
                     and alo_hip.fusable(frames.as_tensor(), self.transformer.level_embed))
         skip = tuple(range(len(self.backbone.num_channels))) if lazy_pos else (() if self.return_bb_outputs else (0,))
-        features, pos = self.backbone(frames, skip_pos_levels=skip, **kwargs)
+        # inference: the per-level padding masks come from one kernel below, not from one F.interpolate per backbone stage
+        features, pos = self.backbone(frames, skip_pos_levels=skip, **(dict(kwargs, skip_masks=True) if lazy_pos else kwargs))
 
         srcs, masks = [], []
         flat = self._flat_sources(features) if lazy_pos else None
+        if lazy_pos and flat is None:   # rare shapes: the stock mask resize after all
+            features = [(x, _resize_mask(frame_masks.float(), x.shape[-2:]).to(torch.bool)) for x, _ in features]
         if flat is not None:
-            # inference: every level's projection is normalised straight into its slot of the encoder's flattened source
+            # every level's projection is normalised straight into its slot of the encoder's flattened source; masks of all
+            # levels (bilinear resize for the backbone stages, nearest for the extra level, as the stock path) + valid ratios: one call
             flat, slots = flat
+            n_bb = len(features) - 1
+            shapes = [hw for _, hw in slots]
+            mask_flat, valid_ratios = alo_hip.mask_pyramid(frame_masks, shapes, nearest_levels=range(n_bb, len(slots)))
             for lvl, (start, (h, w)) in enumerate(slots):
-                x, mask = features[min(lvl + 1, len(features) - 1)]
+                x = features[min(lvl + 1, n_bb)][0]
                 rows = flat[:, start:start + h * w]
                 self._project(lvl, x, out_rows=rows)
                 srcs.append(rows.view(rows.shape[0], h, w, -1).permute(0, 3, 1, 2))
-                if lvl + 1 >= len(features):
-                    mask = F.interpolate(frame_masks.float(), size=(h, w)).to(torch.bool)
+                if lvl >= n_bb:
                     pos.append(None)
-                masks.append(mask[:, 0])
-            kwargs = dict(kwargs, src_flatten=flat)
+                masks.append(mask_flat[:, start:start + h * w].view(-1, h, w))
+            kwargs = dict(kwargs, src_flatten=flat, mask_flatten=mask_flat, valid_ratios=valid_ratios)
         else:
             for lvl, (src, mask) in enumerate(features[1:]):
                 srcs.append(self._project(lvl, src))

@@ -137,6 +137,9 @@ class DeformableTransformerEncoder(nn.Module):
         """Every pixel centre of every level, normalised by the valid (un-padded) extent: (B, S, L, 2)."""
         per_level = []
         host_shapes = getattr(spatial_shapes, "_alo_shapes", None)  # python copy set by DeformableTransformer: no device sync
+        if (host_shapes is not None and valid_ratios.is_cuda and valid_ratios.dtype == torch.float32
+                and not (torch.is_grad_enabled() and valid_ratios.requires_grad) and "is_tracing" not in kwargs):
+            return alo_hip.encoder_reference_points(valid_ratios, host_shapes)   # one kernel instead of ~10 per level
         for lvl in range(spatial_shapes.shape[0]):
             h, w = host_shapes[lvl] if host_shapes is not None else (int(spatial_shapes[lvl, 0]), int(spatial_shapes[lvl, 1]))
             ys = torch.arange(h, dtype=torch.float32, device=device) + 0.5
@@ -328,16 +331,19 @@ class DeformableTransformer(nn.Module):
         src_flatten, mask_flatten, pos_flatten, shapes = [], [], [], []
         pos_encoder = kwargs.pop("pos_encoder", None)  # set by DeformableDETR when it left the encodings to this module
         ready = kwargs.pop("src_flatten", None)        # (B, S, C): the levels of ``srcs`` are already views into it
+        ready_mask = kwargs.pop("mask_flatten", None)  # (B, S) bool and (B, L, 2) float32 from alo_mask_pyramid
+        ready_ratios = kwargs.pop("valid_ratios", None)
         for lvl, (src, mask, pos_embed) in enumerate(zip(srcs, masks, pos_embeds)):
             _, _, h, w = src.shape
             shapes.append((h, w))
             if ready is None:
                 src_flatten.append(src.flatten(2).transpose(1, 2))
-            mask_flatten.append(mask.flatten(1))
+            if ready_mask is None:
+                mask_flatten.append(mask.flatten(1))
             if pos_embed is not None:
                 pos_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
         src_flatten = torch.cat(src_flatten, 1) if ready is None else ready
-        mask_flatten = torch.cat(mask_flatten, 1)
+        mask_flatten = torch.cat(mask_flatten, 1) if ready_mask is None else ready_mask
         spatial_shapes, level_start_index = _level_geometry(tuple(shapes), device)
         sizes = [h * w for h, w in shapes]
         if pos_flatten:
@@ -347,7 +353,7 @@ class DeformableTransformer(nn.Module):
             pos_flatten = alo_hip.pos_sine_flat(mask_flatten, spatial_shapes, level_start_index, pos_encoder.dim_t(device),
                                                 self.level_embed, pos_encoder.normalize, pos_encoder.center,
                                                 pos_encoder.scale, src_flatten.dtype)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1) if ready_ratios is None else ready_ratios
 
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, pos_flatten, mask_flatten,
                               **kwargs)

@@ -234,9 +234,13 @@ class BackboneBase(nn.Module):
         self.body = backbone
         self.num_channels = num_channels
 
-    def forward(self, frames, **kwargs):
-        frame_masks = frames.mask.as_tensor()
+    def forward(self, frames, skip_masks=False, **kwargs):
+        """``skip_masks``: the caller derives the per-level padding masks itself (alo_mask_pyramid); ``None`` is returned
+        in their place."""
         xs = self.body(frames.as_tensor())
+        if skip_masks:
+            return {name: (x, None) for name, x in xs.items()}
+        frame_masks = frames.mask.as_tensor()
         out = {}
         for name, x in xs.items():
             out[name] = (x, _resize_mask(frame_masks.float(), x.shape[-2:]).to(torch.bool))

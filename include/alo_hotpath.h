@@ -276,6 +276,22 @@ int alo_groupnorm_rows(const void* x, const void* weight, const void* bias, void
                        int groups, float eps, long y_batch_stride, int dtype, void* stream);
 
 /*
+ * alo_mask_pyramid: the padding mask of every level, flattened, and the valid ratios, from the (B, H, W) frame mask:
+ *   mask_flat[b][start_l + y * w_l + x] = F.interpolate(mask.float(), (h_l, w_l), mode_l)[b, 0, y, x] != 0   (uint8 0 / 1)
+ *   valid_ratios[b][l] = (un-padded pixels in the first row / w_l, in the first column / h_l)                    (fp32)
+ * mode_l = "nearest" where bit l of nearest_levels is set, else "bilinear", align_corners = False, in ATen's arithmetic.  Replaces
+ * alonet/detr/backbone.py:127-128 (mask resize per stage), deformable_detr.py:147, deformable_transformer.py:318-323,334-338,350.
+ * frame_mask: fp32 (mask_is_float = 1) or uint8 / bool, non-zero = padding.  level_shapes_host: 2 * L ints (h_0, w_0, ...) in HOST memory.
+ *
+ * alo_encoder_reference_points: (B, S, L, 2) fp32 — the centre of every pixel of every level normalised by the valid extent of its own
+ * level and re-scaled by each level's valid ratio (DeformableTransformerEncoder.get_reference_points, deformable_transformer.py:136-149).
+ */
+int alo_mask_pyramid(const void* frame_mask, int mask_is_float, unsigned char* mask_flat, float* valid_ratios, int B, int H, int W,
+                     int L, const int* level_shapes_host, unsigned nearest_levels, void* stream);
+int alo_encoder_reference_points(const float* valid_ratios, float* reference_points, int B, int L, const int* level_shapes_host,
+                                 void* stream);
+
+/*
  * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened
  * (B, S, 2F) layout the encoder consumes, level embedding added: what PositionEmbeddingSine.forward + the
  * `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` / cat of DeformableTransformer.forward compute with ~15 PyTorch

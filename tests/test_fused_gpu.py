@@ -368,3 +368,60 @@ def test_linear_packed_matches_fp32_linear(M, K, N, relu, res):
             ref = F.relu(ref)
         got = alo_hip.linear_packed(x, w, b, relu, residual=r)
     assert (got.float() - ref).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
+
+
+def _stock_masks(frame_mask, shapes, n_bilinear):
+    """What the reference computes per level (detr/backbone.py:127-128, deformable_detr.py:147, deformable_transformer.py:318-323)."""
+    masks, ratios = [], []
+    for lvl, (h, w) in enumerate(shapes):
+        if lvl < n_bilinear:
+            m = F.interpolate(frame_mask.float(), size=(h, w), mode="bilinear", align_corners=False).to(torch.bool)[:, 0]
+        else:
+            m = F.interpolate(frame_mask.float(), size=(h, w)).to(torch.bool)[:, 0]
+        masks.append(m.flatten(1))
+        valid_h = torch.sum((~m).float()[:, :, 0], 1, keepdim=True)
+        valid_w = torch.sum((~m).float()[:, 0, :], 1, keepdim=True)
+        ratios.append(torch.cat([valid_w / w, valid_h / h], 1))
+    return torch.cat(masks, 1), torch.stack(ratios, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(800, 1333), (641, 487), (96, 130), (33, 65), (512, 512)])
+@pytest.mark.parametrize("as_float", [True, False])
+def test_mask_pyramid_matches_interpolate(H, W, as_float):
+    """alo_mask_pyramid == F.interpolate(...).to(bool) + get_valid_ratio, bit for bit, for rectangular paddings of every size and
+    for random masks."""
+    def down(v, k):
+        for _ in range(k):
+            v = (v - 1) // 2 + 1
+        return v
+    shapes = [(down(H, k), down(W, k)) for k in (3, 4, 5, 6)]
+    g = torch.Generator(device="cuda").manual_seed(H * 7 + W)
+    B = 6
+    mask = torch.zeros(B, 1, H, W, device="cuda")
+    for b in range(B - 1):   # bottom / right padding of various extents, as batched frames have
+        ph = int(torch.randint(0, H // 2, (1,), generator=g, device="cuda"))
+        pw = int(torch.randint(0, W // 2, (1,), generator=g, device="cuda"))
+        if ph:
+            mask[b, :, H - ph:, :] = 1
+        if pw:
+            mask[b, :, :, W - pw:] = 1
+    mask[B - 1] = (torch.rand(1, H, W, device="cuda", generator=g) < 0.3).float()
+    arg = mask if as_float else mask.bool()
+    want_m, want_r = _stock_masks(mask, shapes, 3)
+    got_m, got_r = alo_hip.mask_pyramid(arg, shapes, nearest_levels=[3])
+    assert got_m.dtype == torch.bool and torch.equal(got_m, want_m)
+    assert torch.equal(got_r, want_r)
+
+
+@pytest.mark.gpu
+def test_encoder_reference_points_match_the_torch_construction():
+    from alonet.deformable_detr.deformable_transformer import DeformableTransformerEncoder, _level_geometry
+    shapes = ((100, 167), (50, 84), (25, 42), (13, 21))
+    spatial_shapes, _ = _level_geometry(shapes, torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ratios = torch.rand(8, 4, 2, device="cuda", generator=g) * 0.6 + 0.4
+    got = DeformableTransformerEncoder.get_reference_points(spatial_shapes, ratios, device=ratios.device)
+    want = DeformableTransformerEncoder.get_reference_points(spatial_shapes, ratios, device=ratios.device, is_tracing=True)
+    assert got.shape == want.shape == (8, sum(h * w for h, w in shapes), 4, 2)
+    assert torch.equal(got, want)
