@@ -295,6 +295,13 @@ class DeformableDETR(nn.Module):
         activation_fn = activation_fn or self.activation_fn
         if outs_scores is None or outs_labels is None:
             outs_labels, outs_scores = self.get_outs_labels(m_outputs, activation_fn=activation_fn)
+        if torch.is_tensor(outs_scores) and torch.is_tensor(outs_labels):  # one comparison for the batch, not one per image
+            if activation_fn == "softmax":
+                keep = outs_labels != self.background_class
+                keep = keep if threshold is None else keep & (outs_scores > threshold)
+            else:
+                keep = outs_scores > (0.2 if threshold is None else threshold)
+            return list(keep.unbind(0))
         filters = []
         for scores, labels in zip(outs_scores, outs_labels):
             if activation_fn == "softmax":

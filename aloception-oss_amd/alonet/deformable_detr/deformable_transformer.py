@@ -197,7 +197,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def decoder_layer_forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                               tgt_key_padding_mask=None, src_padding_mask=None, **kwargs):
-        q = k = self.with_pos_embed(tgt, query_pos)  # self-attention among the queries (sequence-first API)
+        carried = tgt.__dict__.get("_alo_with_pos")  # (query_pos, tgt + query_pos) left by the previous layer's last LayerNorm kernel
+        if carried is not None and carried[0] is query_pos:
+            q = k = carried[1]
+        else:
+            q = k = self.with_pos_embed(tgt, query_pos)  # self-attention among the queries (sequence-first API)
         if _fused_ok(self, kwargs, tgt, query_pos) and tgt_key_padding_mask is None and self.self_attn._qkv_same_embed_dim:
             tgt2 = _self_attention(self.self_attn, q, tgt)
         else:
@@ -211,7 +215,12 @@ class DeformableTransformerDecoderLayer(nn.Module):
             tgt2 = self.cross_attn(query, reference_points, src, src_spatial_shapes, level_start_index,
                                    src_padding_mask, **kwargs)
             tgt = _add_norm(self.norm1, tgt2, tgt)
-            return _add_norm(self.norm3, _ffn(self.linear1, self.activation, self.linear2, tgt), tgt)
+            if query_pos is None or not query_pos.is_contiguous():
+                return _add_norm(self.norm3, _ffn(self.linear1, self.activation, self.linear2, tgt), tgt)
+            # the layer's output and (output + query_pos), the next layer's self-attention input, from the same pass
+            out, out_pos = _add_norm(self.norm3, _ffn(self.linear1, self.activation, self.linear2, tgt), tgt, pos=query_pos)
+            out._alo_with_pos = (query_pos, out_pos)
+            return out
         tgt = self.norm2(tgt + self.dropout2(tgt2))
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
                                level_start_index, src_padding_mask, **kwargs)
@@ -241,13 +250,15 @@ class DeformableTransformerDecoder(nn.Module):
                         query_pos=None, src_padding_mask=None, tgt_key_padding_mask=None, **kwargs):
         output = tgt
         intermediate, intermediate_refs = [], []
+        ref_input = None
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
-                ratios = torch.cat([src_valid_ratios, src_valid_ratios], -1)
-                ref_input = reference_points[:, :, None] * ratios[:, None]
-            else:
-                assert reference_points.shape[-1] == 2
-                ref_input = reference_points[:, :, None] * src_valid_ratios[:, None]
+            if ref_input is None or self.bbox_embed is not None:  # without box refinement the reference points never change
+                if reference_points.shape[-1] == 4:
+                    ratios = torch.cat([src_valid_ratios, src_valid_ratios], -1)
+                    ref_input = reference_points[:, :, None] * ratios[:, None]
+                else:
+                    assert reference_points.shape[-1] == 2
+                    ref_input = reference_points[:, :, None] * src_valid_ratios[:, None]
             output = layer(tgt=output, query_pos=query_pos, reference_points=ref_input, src=src,
                            src_spatial_shapes=src_spatial_shapes, level_start_index=src_level_start_index,
                            src_padding_mask=src_padding_mask, tgt_key_padding_mask=tgt_key_padding_mask, **kwargs)
@@ -362,6 +373,10 @@ class DeformableTransformer(nn.Module):
         query_pos, tgt = torch.split(query_embed, c, dim=1)
         query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
         tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
+        if _fused_ok(self, kwargs, memory, query_embed):
+            # the one-pass kernels of the decoder layers want dense operands: materialise the two broadcasts once per forward
+            # instead of once per layer
+            query_pos, tgt = query_pos.contiguous(), tgt.contiguous()
         reference_points = self.reference_points(query_pos).sigmoid()
 
         out = {}

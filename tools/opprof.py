@@ -57,3 +57,11 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
         step()
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=40, max_shapes_column_width=70))
+if "--ops" in sys.argv:  # compact list: aten ops that launch kernels, by count per step
+    rows = [(e.key, e.count, e.self_device_time_total, str(e.input_shapes)[:80]) for e in prof.key_averages(group_by_input_shape=True)
+            if e.key.startswith("aten::") and e.self_device_time_total > 0]
+    rows.sort(key=lambda r: -r[1])
+    n = 3
+    print("aten ops with device time: %d launches/step, %.3f ms/step" % (sum(r[1] for r in rows) / n, sum(r[2] for r in rows) / n / 1e3))
+    for k, c, t, sh in rows[:60]:
+        print("%-28s x%-5.1f %7.1f us/step  %s" % (k, c / n, t / n, sh))
