@@ -57,6 +57,8 @@ def _declare(lib):
     lib.alo_corr_lookup.restype = ip
     lib.alo_corr_lookup.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
     lib.alo_msda_forward_fused_hm.restype = ip
+    lib.alo_msda_forward_fused_hm_rows.restype = ip
+    lib.alo_msda_forward_fused_hm_rows.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [vp]
     lib.alo_msda_forward_fused_hm.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_value_head_major.restype = ip
     lib.alo_value_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
@@ -334,15 +336,34 @@ def value_head_major(value, padding_mask=None):
     return out
 
 
+def _query_rows(t, inner):
+    """Row stride (elements) of a (N, Lq, ...) tensor whose per-query block of ``inner`` elements is dense and whose queries are
+    evenly spaced — a dense tensor or a column slice of a wider (N, Lq, C) buffer; None otherwise."""
+    if t.dim() < 3 or t.shape[0] == 0 or t.shape[1] == 0:
+        return None
+    expect = 1
+    for size, stride in zip(reversed(t.shape[2:]), reversed(t.stride()[2:])):
+        if size != 1 and stride != expect:
+            return None
+        expect *= size
+    if expect != inner:
+        return None
+    rs = t.stride(1) if t.shape[1] > 1 else inner
+    if rs < inner or (t.shape[0] > 1 and t.stride(0) != rs * t.shape[1]):
+        return None
+    return rs
+
+
 def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points):
-    """``msda_forward_fused`` on a head-major value (N, M, S, D) (see ``value_head_major``): same result, bit for bit."""
+    """``msda_forward_fused`` on a head-major value (N, M, S, D) (see ``value_head_major``): same result, bit for bit.
+    ``sampling_offsets`` (N, Lq, M, L, P, 2) and ``attn_logits`` (N, Lq, M, L*P) may be column slices of one wider (N, Lq, C)
+    buffer (a merged projection): only their per-query blocks have to be dense."""
     if not value_hm.is_cuda:
         raise RuntimeError("Not implemented on the CPU")
     N, M, S, D = value_hm.shape
     _, Lq, _, L, P, _ = sampling_offsets.shape
     reference_points = reference_points.float().contiguous()
-    _require_cuda_contiguous([("value", value_hm), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
-                              ("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)])
+    _require_cuda_contiguous([("value", value_hm), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index)])
     if sampling_offsets.dtype != value_hm.dtype or attn_logits.dtype != value_hm.dtype:
         raise RuntimeError("sampling_offsets and attn_logits must have the dtype of value")
     if spatial_shapes.dtype != torch.int32 or level_start_index.dtype != torch.int32:
@@ -350,14 +371,18 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     ref_dim = reference_points.shape[-1]
     if tuple(reference_points.shape) != (N, Lq, L, ref_dim) or attn_logits.numel() != N * Lq * M * L * P:
         raise RuntimeError("reference_points must be (N,Lq,L,2|4) and attn_logits (N,Lq,M,L*P)")
+    off_rs, log_rs = _query_rows(sampling_offsets, M * L * P * 2), _query_rows(attn_logits, M * L * P)
+    if off_rs is None or log_rs is None or off_rs % 8 or log_rs % 8 or not sampling_offsets.is_cuda or not attn_logits.is_cuda:
+        sampling_offsets, attn_logits = sampling_offsets.contiguous(), attn_logits.contiguous()
+        off_rs, log_rs = M * L * P * 2, M * L * P
     out = torch.empty((N, Lq, M * D), dtype=value_hm.dtype, device=value_hm.device)
     e = value_hm.element_size()
     nbytes = e * (N * S * M * D + N * Lq * M * D + N * Lq * M * L * P * 3) + 4 * reference_points.numel()
     def launch():
-        _check(lib().alo_msda_forward_fused_hm(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
-                                               _ptr(sampling_offsets), _ptr(attn_logits), _ptr(reference_points),
-                                               _ptr(out), N, S, M, D, L, Lq, P, ref_dim, _DTYPE_CODE[value_hm.dtype],
-                                               _stream(value_hm.device)))
+        _check(lib().alo_msda_forward_fused_hm_rows(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
+                                                    _ptr(sampling_offsets), _ptr(attn_logits), off_rs, log_rs,
+                                                    _ptr(reference_points), _ptr(out), N, S, M, D, L, Lq, P, ref_dim,
+                                                    _DTYPE_CODE[value_hm.dtype], _stream(value_hm.device)))
 
     with torch.cuda.device(value_hm.device), _timed(f"msda_fwd_fused/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
         launch()

@@ -73,6 +73,18 @@ class MSDeformAttn(nn.Module):
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.0)
 
+    def _merged_query_projection(self):
+        """[sampling_offsets; attention_weights] as one (3*M*L*P, C) weight + bias, rebuilt when either parameter changes."""
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.data_ptr(), aw.weight.data_ptr(),
+               so.weight.dtype, so.weight.device)
+        hit = self.__dict__.get("_alo_merged")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, torch.cat([so.weight, aw.weight], 0).contiguous(), torch.cat([so.bias, aw.bias], 0).contiguous())
+            self.__dict__["_alo_merged"] = hit
+        return hit[1], hit[2]
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None, **kwargs):
         """
@@ -102,16 +114,25 @@ class MSDeformAttn(nn.Module):
         fused = "is_tracing" not in kwargs and not needs_grad and self.fused_prologue and query.is_cuda
         # inference: the four K = d_model linears go through the streaming MFMA kernel when it fits (bf16, d_model = 256)
         proj = (lambda lin, t: alo_hip.linear_auto(t, lin.weight, lin.bias)) if fused else (lambda lin, t: lin(t))
-        offsets = proj(self.sampling_offsets, query).view(N, Lq, M, L, P, 2)
-        logits = proj(self.attention_weights, query).view(N, Lq, M, L * P)
         D = self.d_model // M
-        if (fused and D == 32 and L == 4 and P == 4 and self.value_proj.bias is not None
-                and alo_hip.value_proj_head_major_supported(input_flatten, self.value_proj.weight, M)):
+        hm = (fused and D == 32 and L == 4 and P == 4 and self.value_proj.bias is not None
+              and alo_hip.value_proj_head_major_supported(input_flatten, self.value_proj.weight, M))
+        if hm and self.sampling_offsets.bias is not None and self.attention_weights.bias is not None:
+            # both projections of the query in ONE GEMM (query read once); the attention kernel takes its offsets and logits as
+            # column slices of the merged result
+            w_cat, b_cat = self._merged_query_projection()
+            both = alo_hip.linear_auto(query, w_cat, b_cat)
+            offsets = both[..., :M * L * P * 2].view(N, Lq, M, L, P, 2)
+            logits = both[..., M * L * P * 2:].view(N, Lq, M, L * P)
+        else:
+            offsets = proj(self.sampling_offsets, query).view(N, Lq, M, L, P, 2)
+            logits = proj(self.attention_weights, query).view(N, Lq, M, L * P)
+        if hm:
             # inference, DETR-family shape: value_proj, the padding mask and the head-major layout are ONE kernel
             value = alo_hip.value_proj_head_major(input_flatten, self.value_proj.weight, self.value_proj.bias,
                                                   input_padding_mask, M)
-            output = alo_hip.msda_forward_fused_hm(value, input_spatial_shapes, input_level_start_index,
-                                                   offsets.contiguous(), logits.contiguous(), reference_points)
+            output = alo_hip.msda_forward_fused_hm(value, input_spatial_shapes, input_level_start_index, offsets, logits,
+                                                   reference_points)
             return proj(self.output_proj, output)
         value = proj(self.value_proj, input_flatten)
 

@@ -49,6 +49,7 @@ struct Dims {
     unsigned nblocks;
     int ref_dim;           // fused prologue only: last dim of reference_points (2 or 4)
     int p_shift, m_shift;  // log2(P), log2(M) when they are powers of two, else -1 (integer division fallback)
+    int loc_row_elems, attn_row_elems;  // fused wave kernels: elements between consecutive queries of the offsets / logits buffers
 };
 
 // Image-space position, validity and the four corners of one sampling point (cuh:285-291, :38-78).
@@ -472,9 +473,11 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
         {
             float x[4], y[4], a[4];
             if constexpr (FUSED) {
-                const u32x4 lr = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(loc_) + 2 * g0);
-                const u32x2 ar = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(attn_) + g0);
+                // offsets / logits rows may be slices of one wider buffer (a merged projection): row strides are arguments
                 const int q = dm.m_shift >= 0 ? (pair >> dm.m_shift) : pair / dm.M;
+                const long qrow = (long)b * Lq + q;
+                const u32x4 lr = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(loc_) + qrow * dm.loc_row_elems + 32 * m + 8 * lane);
+                const u32x2 ar = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(attn_) + qrow * dm.attn_row_elems + 16 * m + 4 * lane);
                 const float* rp = ref + (((long)b * Lq + q) * dm.L + lane) * dm.ref_dim;
                 float r0, r1, r2 = 0.f, r3 = 0.f;
                 if (dm.ref_dim == 2) {
@@ -663,9 +666,9 @@ msda_fwd_hm_paired_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 
         // ---- stage 1: two sampling points -> the left-column and the right-column descriptor of sample pair l8 --------------
         {
-            const long g0 = (batch_pair0 + pair) * 16 + 4 * level + 2 * half;
-            const u32x2 lr = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(loc_) + 2 * g0);
-            const unsigned ar = *reinterpret_cast<const unsigned*>(static_cast<const bf16_t*>(attn_) + g0);
+            const long qrow = (long)b * Lq + qc;
+            const u32x2 lr = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(loc_) + qrow * dm.loc_row_elems + 32 * m + 8 * level + 4 * half);
+            const unsigned ar = *reinterpret_cast<const unsigned*>(static_cast<const bf16_t*>(attn_) + qrow * dm.attn_row_elems + 16 * m + 4 * level + 2 * half);
             const float* rp = ref + (((long)b * Lq + qc) * dm.L + level) * dm.ref_dim;
             float r0, r1, r2 = 0.f, r3 = 0.f;
             if (dm.ref_dim == 2) {
@@ -970,6 +973,8 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G, long tar
     d.S = S; d.M = M; d.D = D; d.L = L; d.P = P;
     d.pairs_per_batch = Lq * M;
     d.ref_dim = 0;
+    d.loc_row_elems = M * L * P * 2;
+    d.attn_row_elems = M * L * P;
     d.p_shift = (P & (P - 1)) == 0 ? __builtin_ctz((unsigned)P) : -1;
     d.m_shift = (M & (M - 1)) == 0 ? __builtin_ctz((unsigned)M) : -1;
     const int pairs = kThreads / G;
@@ -1049,7 +1054,8 @@ using namespace alo;
 namespace {
 int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
                  const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
-                 int P, int value_dtype, int loc_dtype, void* stream_, bool head_major = false) {
+                 int P, int value_dtype, int loc_dtype, void* stream_, bool head_major = false, long loc_row_elems = 0,
+                 long attn_row_elems = 0) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
                           loc_dtype, &elem))
@@ -1071,6 +1077,9 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
                     "alo_msda_forward_fused_hm: needs bf16, L = P = 4, D %% 8 == 0, D <= 32 and 16-byte aligned pointers");
         dm = make_dims(N, S, M, D, L, Lq, P, 16, 16384);
         dm.ref_dim = ref_dim;
+        if (loc_row_elems > 0) dm.loc_row_elems = (int)loc_row_elems;
+        if (attn_row_elems > 0) dm.attn_row_elems = (int)attn_row_elems;
+        const int loc_rs = dm.loc_row_elems, attn_rs = dm.attn_row_elems;
         // runs are (16 consecutive queries, head) tiles; heads of one query block stay on neighbouring waves
         const long runs = (long)((Lq + 15) / 16) * M;
         dm.runs_per_batch = (int)runs;
@@ -1080,6 +1089,8 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
             // x-paired gathers: a wave serves 8 consecutive queries of one head (see msda_fwd_hm_paired_kernel)
             dm = make_dims(N, S, M, D, L, Lq, P, 32, 16384);
             dm.ref_dim = ref_dim;
+            dm.loc_row_elems = loc_rs;
+            dm.attn_row_elems = attn_rs;
             const long runs8 = (long)((Lq + 7) / 8) * M;
             dm.runs_per_batch = (int)runs8;
             dm.blocks_per_batch = (int)((runs8 + dm.iters_per_block - 1) / dm.iters_per_block);
@@ -1138,6 +1149,23 @@ extern "C" int alo_msda_forward_fused_hm(const void* value_hm, const int32_t* sp
                 "alo_msda_forward_fused_hm: last dim of reference_points must be 2 or 4, got %d", ref_dim);
     return forward_impl(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
                         ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true);
+}
+
+extern "C" int alo_msda_forward_fused_hm_rows(const void* value_hm, const int32_t* spatial_shapes,
+                                              const int32_t* level_start_index, const void* sampling_offsets,
+                                              const void* attn_logits, long offsets_row_elems, long logits_row_elems,
+                                              const void* reference_points, void* out, int N, int S, int M, int D, int L,
+                                              int Lq, int P, int ref_dim, int value_dtype, void* stream_) {
+    ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_rows: reference_points is null");
+    ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_forward_fused_hm_rows: last dim of reference_points must be 2 or 4, got %d", ref_dim);
+    ALO_REQUIRE(offsets_row_elems >= (long)M * L * P * 2 && logits_row_elems >= (long)M * L * P && offsets_row_elems % 8 == 0 &&
+                    logits_row_elems % 8 == 0 && offsets_row_elems < (1L << 30) && logits_row_elems < (1L << 30),
+                ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_forward_fused_hm_rows: row strides must cover a query's M*L*P*2 offsets / M*L*P logits and keep 16-byte alignment");
+    return forward_impl(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
+                        ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true, offsets_row_elems,
+                        logits_row_elems);
 }
 
 extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,

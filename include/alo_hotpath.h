@@ -112,6 +112,15 @@ int alo_msda_forward_fused_hm(const void* value_hm, const int32_t* spatial_shape
                               const void* sampling_offsets, const void* attn_logits, const void* reference_points,
                               void* out, int N, int S, int M, int D, int L, int Lq, int P, int ref_dim,
                               int value_dtype, void* stream);
+/*
+ * Same, with the RAW offsets and logits of a query allowed to sit in rows of a wider buffer: `sampling_offsets` points at the query-0
+ * offsets, consecutive queries are offsets_row_elems elements apart (>= M*L*P*2), likewise `attn_logits` / logits_row_elems (>= M*L*P).
+ * Lets `sampling_offsets` and `attention_weights` (ms_deform_attn.py:119-121) be ONE GEMM with 3*M*L*P output columns.
+ */
+int alo_msda_forward_fused_hm_rows(const void* value_hm, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                   const void* sampling_offsets, const void* attn_logits, long offsets_row_elems,
+                                   long logits_row_elems, const void* reference_points, void* out, int N, int S, int M, int D,
+                                   int L, int Lq, int P, int ref_dim, int value_dtype, void* stream);
 
 /*
  * value (N, S, M, D) -> out (N, M, S, D), rows of padded pixels zeroed (padding_mask (N, S) uint8/bool, nullable):

@@ -354,3 +354,24 @@ def test_head_major_rejects_other_shapes():
     with pytest.raises(RuntimeError, match="L = P = 4"):
         alo_hip.msda_forward_fused_hm(v, shapes, start, off, lg, torch.rand(1, 3, 2, 2, device=DEV))
     assert not alo_hip.head_major_supported(torch.zeros(1, 4, 2, 32, device=DEV), 4, 4)  # fp32
+
+
+@pytest.mark.parametrize("N,Lq", [(2, 77), (1, 300)])
+def test_head_major_takes_offsets_and_logits_as_slices_of_a_merged_projection(N, Lq):
+    """alo_msda_forward_fused_hm_rows: raw offsets and logits as column slices of one (N, Lq, 3*M*L*P) buffer give the bits of the
+    dense call."""
+    M, D, L, P = 8, 32, 4, 4
+    shapes_l = [(16, 21), (8, 11), (4, 6), (2, 3)]
+    gen = torch.Generator(device=DEV).manual_seed(11 + Lq)
+    shapes = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
+    start = dev(level_start(shapes_l))
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    vhm = torch.randn(N, M, S, D, generator=gen, device=DEV).bfloat16()
+    both = (torch.randn(N, Lq, M * L * P * 3, generator=gen, device=DEV) * 2.0).bfloat16()
+    ref = torch.rand(N, Lq, L, 2, generator=gen, device=DEV)
+    offsets = both[..., :M * L * P * 2].view(N, Lq, M, L, P, 2)
+    logits = both[..., M * L * P * 2:].view(N, Lq, M, L * P)
+    assert not offsets.is_contiguous() and not logits.is_contiguous()
+    got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    want = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets.contiguous(), logits.contiguous(), ref)
+    assert torch.equal(got, want)
