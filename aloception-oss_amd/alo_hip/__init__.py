@@ -88,6 +88,8 @@ def _declare(lib):
     lib.alo_mask_pyramid.argtypes = [vp, ip, vp, vp, ip, ip, ip, ip, c.POINTER(c.c_int), c.c_uint, vp]
     lib.alo_encoder_reference_points.restype = ip
     lib.alo_encoder_reference_points.argtypes = [vp, vp, ip, ip, c.POINTER(c.c_int), vp]
+    lib.alo_conv1x1_nhwc.restype = ip
+    lib.alo_conv1x1_nhwc.argtypes = [vp, vp, ip, vp, vp, vp] + [ip] * 8 + [vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -649,6 +651,37 @@ def linear_packed(x, weight, bias=None, relu=False, residual=None):
                                            None if residual is None else _ptr(residual), _ptr(y), M, N, K, 1 if relu else 0,
                                            ALO_BF16, _stream(x.device)))
     return y.view(*x.shape[:-1], N)
+
+
+def conv1x1_strided_supported(x, weight2d):
+    """Strided 1x1 convolution of a channels-last bf16 map addressed inside the GEMM's tile loader: the shapes linear_auto
+    would send to one of the streaming kernels."""
+    if not (x.dim() == 4 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    if os.environ.get("ALO_CONV1X1_GATHER") == "0":   # A/B knob: gather the kept pixels with a copy kernel first
+        return False
+    rows = x.permute(0, 2, 3, 1)
+    if linear_shortk_supported(rows, weight2d):
+        return True
+    return linear_packed_supported(rows, weight2d) and (weight2d.shape[0] >= 1024 or tuple(weight2d.shape) == (128, 512))
+
+
+def conv1x1_strided(x, weight2d, bias, stride, relu=False):
+    """``act(F.conv2d(x, weight2d[:, :, None, None], bias, stride))`` for a channels-last bf16 ``x``; returns channels-last."""
+    if not conv1x1_strided_supported(x, weight2d):
+        raise RuntimeError("conv1x1_strided: unsupported dtype / layout / shape")
+    n, cin, h, w_ = x.shape
+    cout = weight2d.shape[0]
+    ho, wo = (h - 1) // stride + 1, (w_ - 1) // stride + 1
+    y = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    packed = not linear_shortk_supported(x.permute(0, 2, 3, 1), weight2d)
+    wt = pack_mfma_b(weight2d) if packed else weight2d.contiguous()
+    bias_c = None if bias is None else bias.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device), _timed(f"conv1x1_strided/K={cin}/N={cout}", 2.0 * (y.numel() // cout * cin + y.numel()),
+                                             2.0 * y.numel() * cin):
+        _check(lib().alo_conv1x1_nhwc(_ptr(x), _ptr(wt), 1 if packed else 0, None if bias_c is None else _ptr(bias_c), None, _ptr(y),
+                                      n, h, w_, cin, cout, stride, 1 if relu else 0, ALO_BF16, _stream(x.device)))
+    return y
 
 
 def linear_auto(x, weight, bias=None, relu=False, residual=None):

@@ -55,6 +55,10 @@ def conv1x1_as_gemm(x, weight, bias, stride=(1, 1), relu=False, residual=None):
     epilogue (``torch._addmm_activation``).  A strided convolution first gathers the kept pixels (a quarter of the map).
     ``residual``: channels-last (N,Cout,H',W'), added before the activation."""
     if tuple(stride) != (1, 1):
+        if (stride[0] == stride[1] and residual is None and not torch.is_grad_enabled()
+                and alo_hip.conv1x1_strided_supported(x, _weight_2d(weight))):
+            # the streaming GEMM addresses the kept pixels itself: no gathered copy of a quarter of the map
+            return alo_hip.conv1x1_strided(x, _weight_2d(weight), bias, stride[0], relu)
         x = x[:, :, ::stride[0], ::stride[1]]
     n, cin, h, w_ = x.shape
     rows = x.permute(0, 2, 3, 1).reshape(-1, cin)  # a view for stride 1 (NHWC rows are contiguous), one gather otherwise

@@ -32,7 +32,19 @@ struct GemmDims {
     int N;
     int tiles;  // ceil(M / kRows)
     int S;      // head-major output only: rows per batch item
+    // strided 1x1 convolution: row r of X' = pixel (n, gs * yo, gs * xo) of the NHWC map X; gs <= 1: X' = X
+    int gs, gWo, gHoWo, gW, gHW;
 };
+
+// row of the GEMM -> row of the NHWC input it reads (identity unless the 1x1 convolution is strided)
+template <typename D>
+__device__ __forceinline__ long gather_row(const D& dm, long row) {
+    if (dm.gs <= 1) return row;
+    const long n = row / dm.gHoWo;
+    const int rem = (int)(row - n * dm.gHoWo);
+    const int yo = rem / dm.gWo, xo = rem - yo * dm.gWo;
+    return n * dm.gHW + (long)(yo * dm.gs) * dm.gW + xo * dm.gs;
+}
 
 // HM = true (value_proj of MSDeformAttn): y is written HEAD-major, (batch, N / 32 heads, S, 32), and rows whose padding-mask
 // byte is set are written as zeros — `value.masked_fill(mask, 0)` and the re-layout the head-major attention kernel wants,
@@ -81,7 +93,7 @@ linear_shortk_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
         for (int j = 0; j < kLoads; ++j) {
             const int p = tid + 256 * j;  // piece index: row = p / kPieces, 16-byte column = p % kPieces
             long row = (long)tile * kRows + p / kPieces;
-            row = row < dm.M ? row : dm.M - 1;
+            row = gather_row(dm, row < dm.M ? row : dm.M - 1);
             r[j] = *reinterpret_cast<const u32x4*>(X + row * kK + (p % kPieces) * 8);
         }
     };
@@ -196,9 +208,12 @@ using namespace alo;
 namespace {
 template <int K, bool RELU, bool HAS_RES, bool HM = false>
 int launch_shortk(const void* x, const void* weight, const void* bias, const void* residual, void* y, long M, int N,
-                  hipStream_t stream, int S = 0) {
+                  hipStream_t stream, int S = 0, const int* gather = nullptr) {
     GemmDims dm;
     dm.M = M; dm.N = N; dm.tiles = (int)((M + kRows - 1) / kRows); dm.S = S;
+    dm.gs = gather ? gather[0] : 1;
+    dm.gWo = gather ? gather[2] : 1; dm.gHoWo = gather ? gather[1] * gather[2] : 1;
+    dm.gW = gather ? gather[4] : 1; dm.gHW = gather ? gather[3] * gather[4] : 1;
     const size_t lds = kRows * (K * 2 + 16) + 4 * kRows * kOutStride + 4 * 64 * sizeof(float);
     const int cols = (N + 255) / 256;
     int gx = 512 / cols;  // persistent: about two workgroups per CU in total
@@ -238,6 +253,23 @@ extern "C" int alo_linear_shortk(const void* x, const void* weight, const void* 
     ALO_GEMM_CASE(64) ALO_GEMM_CASE(128) ALO_GEMM_CASE(256)
 #undef ALO_GEMM_CASE
     return ALO_ERR_UNSUPPORTED;
+}
+
+// 1x1 convolution with a spatial stride over an NHWC map, resident-weight flavour: the kept pixels are addressed by the tile
+// loader itself (no gathered copy of the input).  Declared in alo_hotpath.h as part of alo_conv1x1_nhwc (gemm_packed.hip).
+extern "C" int alo_internal_shortk_gather(const void* x, const void* weight, const void* bias, const void* residual, void* y,
+                                          long M, int N, int K, int relu, const int* gather, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define ALO_GEMM_CASE(KK)                                                                                                  \
+    if (K == KK) {                                                                                                          \
+        if (residual) return relu ? launch_shortk<KK, true, true>(x, weight, bias, residual, y, M, N, st, 0, gather)       \
+                                  : launch_shortk<KK, false, true>(x, weight, bias, residual, y, M, N, st, 0, gather);     \
+        return relu ? launch_shortk<KK, true, false>(x, weight, bias, residual, y, M, N, st, 0, gather)                    \
+                    : launch_shortk<KK, false, false>(x, weight, bias, residual, y, M, N, st, 0, gather);                  \
+    }
+    ALO_GEMM_CASE(64) ALO_GEMM_CASE(128) ALO_GEMM_CASE(256)
+#undef ALO_GEMM_CASE
+    return fail(ALO_ERR_UNSUPPORTED, "alo_conv1x1_nhwc: the resident-weight kernel needs Cin in (64, 128, 256), got %d", K);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -24,7 +24,17 @@ constexpr int kOutStride = 64 * 2 + 16;   // LDS row stride of a wave's 64 x 64 
 struct PackedDims {
     long M;
     int N, K;
+    // strided 1x1 convolution: row r of X' = pixel (n, gs * yo, gs * xo) of the NHWC map X; gs <= 1: X' = X
+    int gs, gWo, gHoWo, gW, gHW;
 };
+
+__device__ __forceinline__ long gather_row(const PackedDims& dm, long row) {
+    if (dm.gs <= 1) return row;
+    const long n = row / dm.gHoWo;
+    const int rem = (int)(row - n * dm.gHoWo);
+    const int yo = rem / dm.gWo, xo = rem - yo * dm.gWo;
+    return n * dm.gHW + (long)(yo * dm.gs) * dm.gW + xo * dm.gs;
+}
 
 template <int WC, bool RELU, bool HAS_RES>
 __global__ void __launch_bounds__(256, 2)
@@ -55,7 +65,7 @@ linear_packed_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wp
         for (int j = 0; j < kLoads; ++j) {
             const int p = tid + 256 * j;
             long row = row0 + p / kPieces;
-            row = row < dm.M ? row : dm.M - 1;   // rows past the end are read from the last row and never stored
+            row = gather_row(dm, row < dm.M ? row : dm.M - 1);   // rows past the end are read from the last row and never stored
             r[j] = *reinterpret_cast<const u32x4*>(X + row * dm.K + chunk * KC + (p % kPieces) * 8);
         }
     };
@@ -186,6 +196,11 @@ int launch_packed(const void* x, const void* w, const void* bias, const void* re
 
 using namespace alo;
 
+namespace {
+int dispatch_packed(const void* x, const void* w_packed, const void* bias, const void* residual, void* y, const PackedDims& dm,
+                    int relu, void* stream);
+}
+
 extern "C" int alo_linear_packed(const void* x, const void* w_packed, const void* bias, const void* residual, void* y, long M,
                                  int N, int K, int relu, int dtype, void* stream) {
     ALO_REQUIRE(x && w_packed && y, ALO_ERR_INVALID_ARGUMENT, "alo_linear_packed: null pointer argument");
@@ -198,6 +213,40 @@ extern "C" int alo_linear_packed(const void* x, const void* w_packed, const void
     ALO_REQUIRE((M + 63) / 64 < (1L << 31), ALO_ERR_UNSUPPORTED, "alo_linear_packed: too many rows");
     PackedDims dm;
     dm.M = M; dm.N = N; dm.K = K;
+    dm.gs = 1; dm.gWo = dm.gHoWo = dm.gW = dm.gHW = 1;
+    return dispatch_packed(x, w_packed, bias, residual, y, dm, relu, stream);
+}
+
+extern "C" int alo_internal_shortk_gather(const void* x, const void* weight, const void* bias, const void* residual, void* y,
+                                          long M, int N, int K, int relu, const int* gather, void* stream);
+
+extern "C" int alo_conv1x1_nhwc(const void* x, const void* weight, int weight_is_packed, const void* bias, const void* residual,
+                                void* y, int N, int H, int W, int Cin, int Cout, int stride, int relu, int dtype, void* stream) {
+    ALO_REQUIRE(x && weight && y, ALO_ERR_INVALID_ARGUMENT, "alo_conv1x1_nhwc: null pointer argument");
+    ALO_REQUIRE(N > 0 && H > 0 && W > 0 && stride >= 1, ALO_ERR_INVALID_ARGUMENT, "alo_conv1x1_nhwc: N, H, W, stride must be positive");
+    ALO_REQUIRE(dtype == ALO_BF16, ALO_ERR_UNSUPPORTED, "alo_conv1x1_nhwc: bf16 only (dtype %d)", dtype);
+    ALO_REQUIRE((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_conv1x1_nhwc: pointers must be 16-byte aligned");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long M = (long)N * Ho * Wo;
+    ALO_REQUIRE((long)H * W < (1L << 30), ALO_ERR_UNSUPPORTED, "alo_conv1x1_nhwc: map too large");
+    const int gather[5] = {stride, Ho, Wo, H, W};
+    if (!weight_is_packed) {
+        ALO_REQUIRE(Cout % 64 == 0, ALO_ERR_UNSUPPORTED, "alo_conv1x1_nhwc: Cout must be a multiple of 64 (got %d)", Cout);
+        return alo_internal_shortk_gather(x, weight, bias, residual, y, M, Cout, Cin, relu, gather, stream);
+    }
+    ALO_REQUIRE(Cin % 256 == 0 && Cout % 128 == 0, ALO_ERR_UNSUPPORTED,
+                "alo_conv1x1_nhwc: packed weights need Cin %% 256 == 0 and Cout %% 128 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    PackedDims dm;
+    dm.M = M; dm.N = Cout; dm.K = Cin;
+    dm.gs = stride; dm.gWo = Wo; dm.gHoWo = Ho * Wo; dm.gW = W; dm.gHW = H * W;
+    return dispatch_packed(x, weight, bias, residual, y, dm, relu, stream);
+}
+
+namespace {
+int dispatch_packed(const void* x, const void* w_packed, const void* bias, const void* residual, void* y, const PackedDims& dm,
+                    int relu, void* stream) {
+    const int N = dm.N;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool r = relu != 0, res = residual != nullptr;
     if (N % 256 == 0) {
@@ -207,3 +256,4 @@ extern "C" int alo_linear_packed(const void* x, const void* w_packed, const void
     if (res) return r ? launch_packed<2, true, true>(x, w_packed, bias, residual, y, dm, s) : launch_packed<2, false, true>(x, w_packed, bias, residual, y, dm, s);
     return r ? launch_packed<2, true, false>(x, w_packed, bias, residual, y, dm, s) : launch_packed<2, false, false>(x, w_packed, bias, residual, y, dm, s);
 }
+}  // namespace

@@ -251,6 +251,16 @@ int alo_linear_packed(const void* x, const void* w_packed, const void* bias, con
                       int relu, int dtype, void* stream);
 
 /*
+ * alo_conv1x1_nhwc: y (N, Ho, Wo, Cout) = act(conv1x1(x (N, H, W, Cin), stride) + bias [+ residual]) over NHWC maps: the strided
+ * `downsample` convolutions of the bottlenecks (alonet/detr/backbone.py:84-92; torchvision Bottleneck) without a gathered copy of the
+ * kept pixels — the tile loader of alo_linear_shortk (weight (Cout, Cin) row-major, weight_is_packed = 0, Cin in {64, 128, 256}) or
+ * alo_linear_packed (weight = alo_pack_mfma_b(w), weight_is_packed = 1, Cin % 256 == 0, Cout % 128 == 0) addresses pixel
+ * (n, stride * yo, stride * xo) itself.  Ho = (H - 1) / stride + 1.  residual (N, Ho, Wo, Cout) or NULL.
+ */
+int alo_conv1x1_nhwc(const void* x, const void* weight, int weight_is_packed, const void* bias, const void* residual, void* y, int N,
+                     int H, int W, int Cin, int Cout, int stride, int relu, int dtype, void* stream);
+
+/*
  * alo_conv3x3_nhwc: y (N, Ho, Wo, Cout) = act(conv3x3(x (N, H, W, Cin), stride 1 or 2, padding 1) + bias), bf16 with fp32
  * accumulation: Bottleneck.conv2 + the folded FrozenBatchNorm2d + ReLU of the ResNet backbone (alonet/detr/backbone.py:19-47,
  * 84-92; torchvision Bottleneck), an implicit GEMM on MFMA.  Ho = (H - 1) / stride + 1.  w_packed = alo_pack_mfma_b of the

@@ -425,3 +425,21 @@ def test_encoder_reference_points_match_the_torch_construction():
     want = DeformableTransformerEncoder.get_reference_points(spatial_shapes, ratios, device=ratios.device, is_tracing=True)
     assert got.shape == want.shape == (8, sum(h * w for h, w in shapes), 4, 2)
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout", [((2, 256, 17, 23), 512), ((1, 512, 10, 12), 1024), ((3, 64, 9, 9), 128), ((1, 1024, 5, 8), 2048)])
+@pytest.mark.parametrize("stride", [2, 3])
+def test_conv1x1_strided_matches_convolution(shape, cout, stride):
+    """alo_conv1x1_nhwc (stride folded into the GEMM's tile loader) against F.conv2d in fp32."""
+    n, c, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(c + h + stride)
+    x = torch.randn(n, c, h, w, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, c, device="cuda", generator=g) / c ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, device="cuda", generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        assert alo_hip.conv1x1_strided_supported(x, wt)
+        got = alo_hip.conv1x1_strided(x, wt, b, stride, relu=True)
+        ref = F.relu(F.conv2d(x.float(), wt.float()[:, :, None, None], b.float(), stride))
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
