@@ -1,3 +1,4 @@
+from .hip_graph import GraphedForward
 from .weights import load_weights
 
-__all__ = ["load_weights"]
+__all__ = ["load_weights", "GraphedForward"]

@@ -1,0 +1,58 @@
+"""HIP-graph replay of a model's inference forward.
+
+A DETR-family forward at fixed input shape is ~330 kernel launches of 2-250 us; eagerly launched, the GPU idles a few
+microseconds between dependent small kernels.  Captured once in a HIP graph (``torch.cuda.CUDAGraph`` is a hipGraph on
+ROCm) the same kernels replay with one host call and back-to-back dispatch: 10.1 -> 9.7 ms per step of DeformableDETR-R50
+on 8 frames of 1333x800 (MI355X), bit-identical outputs.  No tracing compiler is involved: the graph is the recorded launch
+sequence of the eager code, hand-written kernels included.
+"""
+import torch
+
+
+class GraphedForward:
+    """``GraphedForward(model)(frames)`` == ``model(frames)`` under ``torch.no_grad()`` for batched ``aloscene.Frame`` inputs.
+
+    The first call with a new (shape, dtype, device) warms the model up on a side stream, captures one forward on buffers
+    of its own and replays it; later calls copy ``frames`` (data and padding mask) into the captured input and replay.
+    The returned tensors are the graph's output buffers: they are overwritten by the next call with the same key, so
+    consume them (``model.inference(out)``) before calling again.  Anything that synchronises with the host
+    (``inference()``, ``.cpu()``) stays outside the captured region.
+    """
+
+    def __init__(self, model, warmup=3):
+        self.model = model
+        self.warmup = warmup
+        self._graphs = {}
+
+    @staticmethod
+    def _key(frames):
+        return (tuple(frames.shape), frames.dtype, str(frames.device))
+
+    def _capture(self, frames):
+        static_in = frames.clone()
+        side = torch.cuda.Stream(device=frames.device)
+        side.wait_stream(torch.cuda.current_stream(frames.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):  # lazy caches (folded / packed weights, level geometry, solver choices) fill here
+                self.model(static_in)
+        torch.cuda.current_stream(frames.device).wait_stream(side)
+        torch.cuda.synchronize(frames.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            out = self.model(static_in)
+        return static_in, graph, out
+
+    def __call__(self, frames):
+        if not frames.is_cuda:
+            raise RuntimeError("GraphedForward: needs CUDA frames")
+        key = self._key(frames)
+        entry = self._graphs.get(key)
+        if entry is None:
+            entry = self._graphs[key] = self._capture(frames)
+        static_in, graph, out = entry
+        if frames is not static_in:
+            static_in.as_tensor().copy_(frames.as_tensor(), non_blocking=True)
+            if getattr(frames, "mask", None) is not None and getattr(static_in, "mask", None) is not None:
+                static_in.mask.as_tensor().copy_(frames.mask.as_tensor(), non_blocking=True)
+        graph.replay()
+        return out

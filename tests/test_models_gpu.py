@@ -146,3 +146,29 @@ def test_panoptic_head_on_deformable_detr_hip_vs_torch_branch():
     with torch.no_grad():
         out2 = model(frames, threshold=0.0)
     assert out2["pred_masks"].shape[:2] == (2, 300)
+
+
+def test_graphed_forward_replays_the_eager_forward_bit_for_bit():
+    """alonet.common.GraphedForward: a HIP graph of DeformableDETR-R50's forward gives the eager outputs exactly, for the captured
+    batch and for new batches (data AND padding mask) copied into the captured input."""
+    from alonet.common import GraphedForward
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=False, device=torch.device(DEV)).eval().to(torch.bfloat16)
+    gen = torch.Generator().manual_seed(5)
+
+    def batch(pad):
+        fr = [aloscene.Frame(torch.rand(3, 256 - pad * i, 320, generator=gen) * 255, normalization="255").norm_resnet()
+              for i in range(2)]
+        return aloscene.Frame.batch_list(fr).to(DEV).to(torch.bfloat16)
+
+    first, second = batch(0), batch(32)   # same padded shape (the second batch has a padded frame)
+    assert first.shape == second.shape and bool(second.mask.as_tensor().any()) and not bool(first.mask.as_tensor().any())
+    graphed = GraphedForward(model)
+    with torch.no_grad():
+        for frames in (first, second, first):
+            want = model(frames)
+            got = graphed(frames)
+            for key in ("pred_logits", "pred_boxes"):
+                assert torch.equal(got[key], want[key]), key
+    assert len(graphed._graphs) == 1
