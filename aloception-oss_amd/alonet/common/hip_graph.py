@@ -38,7 +38,9 @@ class GraphedForward:
         torch.cuda.current_stream(frames.device).wait_stream(side)
         torch.cuda.synchronize(frames.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
+        # thread_local: other threads of the process (the RCCL watchdog of a torch.distributed job polls events) may keep
+        # making HIP calls while this thread captures
+        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = self.model(static_in)
         return static_in, graph, out
 
