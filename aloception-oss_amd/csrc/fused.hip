@@ -236,34 +236,53 @@ gru_update_kernel(const float* q, const float* __restrict__ bias_q, const float*
 
 // ---- sine positional encoding of the flattened pyramid (alonet/transformers/position_encoding.py:29-72) ---------------------
 // Pass 1: per (level, image) the cumulative count of un-padded pixels along y and along x, centred / normalised the way the
-// module does it, as (ey, ex) per pixel.  One thread walks one column (then one row): maps are at most a few hundred wide.
+// module does it, as (ey, ex) per pixel.  Work items are WAVES: one per 64 columns (a lane walks its column: coalesced byte loads,
+// two passes — total, then running count) and one per image row (a lane owns a run of ceil(W / 64) pixels; wave-level inclusive
+// scan of the run totals).  grid = (workers, L, B); the 4 waves of worker w take items 4 w + wave, + 4 * workers, ...
 __global__ void __launch_bounds__(kThreads)
 pos_prefix_kernel(const unsigned char* __restrict__ mask, const int32_t* __restrict__ shapes,
                   const int32_t* __restrict__ lstart, float* __restrict__ emb, int S, int normalize, int center,
                   float scale, float eps) {
-    const int l = blockIdx.x, b = blockIdx.y;
+    const int l = blockIdx.y, b = blockIdx.z;
     const int H = shapes[2 * l], W = shapes[2 * l + 1], start = lstart[l];
     const unsigned char* mk = mask + (size_t)b * S + start;
     float* e = emb + ((size_t)b * S + start) * 2;
     const float shift = (normalize && center) ? 0.5f : 0.0f;
-    for (int x = threadIdx.x; x < W; x += kThreads) {
-        float cum = 0.f;
-        for (int y = 0; y < H; ++y) cum += mk[y * W + x] ? 0.f : 1.f;
-        const float denom = (cum - shift) + eps;  // y_embed[:, -1:, :] + eps
-        float run = 0.f;
-        for (int y = 0; y < H; ++y) {
-            run += mk[y * W + x] ? 0.f : 1.f;
-            e[(y * W + x) * 2] = normalize ? (run - shift) / denom * scale : run;
-        }
-    }
-    for (int y = threadIdx.x; y < H; y += kThreads) {
-        float cum = 0.f;
-        for (int x = 0; x < W; ++x) cum += mk[y * W + x] ? 0.f : 1.f;
-        const float denom = (cum - shift) + eps;
-        float run = 0.f;
-        for (int x = 0; x < W; ++x) {
-            run += mk[y * W + x] ? 0.f : 1.f;
-            e[(y * W + x) * 2 + 1] = normalize ? (run - shift) / denom * scale : run;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col_items = (W + 63) / 64, items = col_items + H;
+    for (int item = blockIdx.x * (kThreads / 64) + wave; item < items; item += gridDim.x * (kThreads / 64)) {
+        if (item < col_items) {   // ---- y_embed of 64 columns ----
+            const int x = item * 64 + lane;
+            if (x < W) {
+                float cum = 0.f;
+#pragma unroll 4
+                for (int y = 0; y < H; ++y) cum += mk[y * W + x] ? 0.f : 1.f;
+                const float denom = (cum - shift) + eps;  // y_embed[:, -1:, :] + eps
+                float run = 0.f;
+#pragma unroll 4
+                for (int y = 0; y < H; ++y) {
+                    run += mk[y * W + x] ? 0.f : 1.f;
+                    e[(y * W + x) * 2] = normalize ? (run - shift) / denom * scale : run;
+                }
+            }
+        } else {                  // ---- x_embed of one row ----
+            const int y = item - col_items;
+            const int per = (W + 63) / 64, x0 = lane * per, x1 = min(W, x0 + per);
+            float mine = 0.f;
+            for (int x = x0; x < x1; ++x) mine += mk[y * W + x] ? 0.f : 1.f;
+            float incl = mine;   // inclusive scan of the lanes' run totals (exact: small integers)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const float total = __shfl(incl, 63, 64);
+            const float denom = (total - shift) + eps;
+            float run = incl - mine;
+            for (int x = x0; x < x1; ++x) {
+                run += mk[y * W + x] ? 0.f : 1.f;
+                e[(y * W + x) * 2 + 1] = normalize ? (run - shift) / denom * scale : run;
+            }
         }
     }
 }
@@ -285,11 +304,15 @@ pos_generate_kernel(const float* __restrict__ emb, const float* __restrict__ dim
         const float e = emb[pix * 2 + (c0 < F ? 0 : 1)];
         float le[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
         if (level_embed != nullptr) load4(level_embed + (size_t)l * C + c0, le);
+        // channels (2 i, 2 i + 1) are (sin, cos) of the SAME argument (dim_t[2 i] == dim_t[2 i + 1]): one sincosf per pair
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int f = (c0 + k) % F;
+        for (int k = 0; k < 4; k += 2) {
+            const int f = (c0 + k) % F;   // even: c0 % 4 == 0 and F % 4 == 0
             const float p = e / dim_t[f];
-            v[k] = ((f & 1) ? cosf(p) : sinf(p)) + le[k];
+            float sn, cs;
+            sincosf(p, &sn, &cs);
+            v[k] = sn + le[k];
+            v[k + 1] = (dim_t[f + 1] == dim_t[f] ? cs : cosf(e / dim_t[f + 1])) + le[k + 1];
         }
         store4(out + pix * C + c0, v);
     }
@@ -447,7 +470,7 @@ extern "C" int alo_pos_sine_flat(const void* padding_mask, const int32_t* spatia
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         void* args[] = {&padding_mask, &spatial_shapes, &level_start_index, &workspace, &S, &normalize, &center, &scale, &eps};
-        hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(pos_prefix_kernel), dim3(L, B), dim3(kThreads), args, 0, st);
+        hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(pos_prefix_kernel), dim3(32, L, B), dim3(kThreads), args, 0, st);
         if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_pos_sine_flat: %s", hipGetErrorString(e));
     }
     long n4 = (long)B * S * (2 * num_pos_feats) / 4;
