@@ -10,10 +10,11 @@ import torch
 
 
 class GraphedForward:
-    """``GraphedForward(model)(frames)`` == ``model(frames)`` under ``torch.no_grad()`` for batched ``aloscene.Frame`` inputs.
+    """``GraphedForward(model)(*frames, **options)`` == ``model(*frames, **options)`` under ``torch.no_grad()`` for batched
+    ``aloscene.Frame`` inputs (one for the detectors, two for RAFT) and hashable keyword options (``iters=32``).
 
-    The first call with a new (shape, dtype, device) warms the model up on a side stream, captures one forward on buffers
-    of its own and replays it; later calls copy ``frames`` (data and padding mask) into the captured input and replay.
+    The first call with a new (shapes, dtypes, device, options) warms the model up on a side stream, captures one forward on
+    buffers of its own and replays it; later calls copy the frames (data and padding mask) into the captured inputs and replay.
     The returned tensors are the graph's output buffers: they are overwritten by the next call with the same key, so
     consume them (``model.inference(out)``) before calling again.  Anything that synchronises with the host
     (``inference()``, ``.cpu()``) stays outside the captured region.
@@ -25,36 +26,39 @@ class GraphedForward:
         self._graphs = {}
 
     @staticmethod
-    def _key(frames):
-        return (tuple(frames.shape), frames.dtype, str(frames.device))
+    def _key(frames, options):
+        return (tuple((tuple(f.shape), f.dtype, str(f.device)) for f in frames), tuple(sorted(options.items())))
 
-    def _capture(self, frames):
-        static_in = frames.clone()
-        side = torch.cuda.Stream(device=frames.device)
-        side.wait_stream(torch.cuda.current_stream(frames.device))
+    def _capture(self, frames, options):
+        device = frames[0].device
+        static_in = tuple(f.clone() for f in frames)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(self.warmup):  # lazy caches (folded / packed weights, level geometry, solver choices) fill here
-                self.model(static_in)
-        torch.cuda.current_stream(frames.device).wait_stream(side)
-        torch.cuda.synchronize(frames.device)
+                self.model(*static_in, **options)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
         graph = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (the RCCL watchdog of a torch.distributed job polls events) may keep
         # making HIP calls while this thread captures
         with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            out = self.model(static_in)
+            out = self.model(*static_in, **options)
         return static_in, graph, out
 
-    def __call__(self, frames):
-        if not frames.is_cuda:
+    def __call__(self, *frames, **options):
+        if not frames or not all(f.is_cuda for f in frames):
             raise RuntimeError("GraphedForward: needs CUDA frames")
-        key = self._key(frames)
+        key = self._key(frames, options)
         entry = self._graphs.get(key)
         if entry is None:
-            entry = self._graphs[key] = self._capture(frames)
+            entry = self._graphs[key] = self._capture(frames, options)
         static_in, graph, out = entry
-        if frames is not static_in:
-            static_in.as_tensor().copy_(frames.as_tensor(), non_blocking=True)
-            if getattr(frames, "mask", None) is not None and getattr(static_in, "mask", None) is not None:
-                static_in.mask.as_tensor().copy_(frames.mask.as_tensor(), non_blocking=True)
+        for new, static in zip(frames, static_in):
+            if new is static:
+                continue
+            static.as_tensor().copy_(new.as_tensor(), non_blocking=True)
+            if getattr(new, "mask", None) is not None and getattr(static, "mask", None) is not None:
+                static.mask.as_tensor().copy_(new.mask.as_tensor(), non_blocking=True)
         graph.replay()
         return out

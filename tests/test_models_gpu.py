@@ -172,3 +172,22 @@ def test_graphed_forward_replays_the_eager_forward_bit_for_bit():
             for key in ("pred_logits", "pred_boxes"):
                 assert torch.equal(got[key], want[key]), key
     assert len(graphed._graphs) == 1
+
+
+def test_graphed_forward_replays_raft_bit_for_bit(golden):
+    """Two frame inputs + keyword options through one HIP graph: RAFT's iterations replay to the eager flow exactly."""
+    from alonet.common import GraphedForward
+
+    g = golden("g7_raft.npz")
+    model = RAFT().eval()
+    model.load_state_dict(formula_state_dict(model.state_dict()))
+    model = model.to(DEV)
+    mk = lambda a: aloscene.Frame(t(a).float(), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)  # noqa: E731
+    f1, f2 = mk(g["img1"]), mk(g["img2"])
+    graphed = GraphedForward(model)
+    with torch.no_grad():
+        for a, b in ((f1, f2), (f2, f1)):
+            want = model(a, b, iters=3, only_last=True)
+            got = graphed(a, b, iters=3, only_last=True)
+            assert torch.equal(got[-1]["up_flow"], want[-1]["up_flow"])
+    assert len(graphed._graphs) == 1
