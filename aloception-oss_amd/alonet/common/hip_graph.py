@@ -20,9 +20,12 @@ class GraphedForward:
     (``inference()``, ``.cpu()``) stays outside the captured region.
     """
 
-    def __init__(self, model, warmup=3):
+    def __init__(self, model, warmup=3, adopt_inputs=False):
+        """``adopt_inputs``: capture on the caller's own frame objects instead of on clones — a caller that refills those very
+        buffers with each new batch (an H2D copy lands there) then replays without any device-to-device copy."""
         self.model = model
         self.warmup = warmup
+        self.adopt_inputs = adopt_inputs
         self._graphs = {}
 
     @staticmethod
@@ -31,7 +34,7 @@ class GraphedForward:
 
     def _capture(self, frames, options):
         device = frames[0].device
-        static_in = tuple(f.clone() for f in frames)
+        static_in = tuple(frames) if self.adopt_inputs else tuple(f.clone() for f in frames)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():
