@@ -9,10 +9,16 @@ exactly K steps between barrier + synchronize fences, max over ranks.  Frames sh
 collective (weak scaling).  Inputs are resident in HBM before the timed region starts.
 
 Beside it, in the same line:
-  roofline      the dominant hand-written kernel (MSDA forward, encoder call Lq = S = 22223), timed with HIP events on
-                the launch stream INSIDE the timed region: algorithmic bytes / average launch time vs
-                the 8 TB/s HBM peak.  ``kernels`` lists every hot-path kernel the same way (MSDA decoder call, RAFT
-                correlation build = fp32 MFMA vs 157.3 TFLOP/s, lookup).
+  roofline      the dominant hand-written kernel (MSDA forward, encoder call Lq = S = 22223), timed live with HIP events on
+                the launch stream: algorithmic bytes / average launch time vs the 8 TB/s HBM peak.
+                ``ms_per_launch`` = 20 back-to-back re-launches on the buffers of the kernel's last in-model call (what
+                ``achieved`` uses; agrees with rocprofv3's average); ``ms_per_launch_in_step`` = mean of the single-launch
+                event pairs — inside the timed steps with ``--no-graph``; with the default HIP-graph replay no host wrapper
+                runs in the timed steps, so the pairs come from two instrumented eager steps right after them.
+                ``kernels`` lists every hot-path kernel the same way (MSDA decoder call, RAFT correlation build = fp32
+                MFMA vs 157.3 TFLOP/s, lookup).
+  launch        the forward at a fixed input shape is captured once as a HIP graph and replayed per step (same kernels,
+                same bits; ``--no-graph`` launches eagerly); ``inference()`` — the device-to-host hand-over — is eager.
   raft          BASELINE.json configs[2]: RAFT, 32 iterations, 4 synthetic 1280x720 pairs per GPU (fp32), pairs/s.
   cpu_baseline  rank 0, N = 1 only: the reference's CPU path (oracle/torch_ref.py, the torch restatement of
                 ms_deform_attn_core_pytorch) inside the same model graph on the host cores, on a bounded sample.
