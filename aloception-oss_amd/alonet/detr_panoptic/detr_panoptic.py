@@ -100,17 +100,25 @@ class PanopticHead(nn.Module):
         masks_all = F.threshold(masks_all.sigmoid(), maskth, 0.0)
         pred_masks = []
         zero = torch.zeros(*frame_size, device=masks_all.device, dtype=torch.long)
-        for boxes, masks, b_filter, m_filter in zip(pred_boxes, masks_all, b_filters, m_filters):
+        # which mask row (if any) belongs to each kept box: worked out on the host from ONE transfer of the two filters — the
+        # per-box `(ib == kept).nonzero().item()` of the straightforward loop is three device synchronisations per box
+        b_host = torch.stack(list(b_filters)).cpu() if len(b_filters) else None
+        m_host = torch.stack(list(m_filters)).cpu() if len(m_filters) else None
+        for img, (boxes, masks, b_filter, m_filter) in enumerate(zip(pred_boxes, masks_all, b_filters, m_filters)):
             nothing = (~masks.bool()).all(dim=0, keepdim=True)  # pixels where no query passes the threshold
             onehot = torch.zeros_like(masks)
             if onehot.numel():
                 onehot.scatter_(0, masks.argmax(dim=0, keepdim=True), 1)
             masks = onehot.long() * (~nothing)
-            kept = torch.where(m_filter)[0]
-            aligned = []
-            for ib in torch.where(b_filter)[0]:
-                pos = (ib == kept).nonzero()
-                aligned.append(masks[pos.item()] if pos.numel() > 0 and pos.item() < len(masks) else zero)
-            masks = torch.stack(aligned, dim=0) if aligned else zero[[]].view(0, *frame_size)
+            kept = torch.where(m_host[img])[0].tolist()
+            row_of = {q: r for r, q in enumerate(kept)}
+            rows = [row_of.get(q, -1) for q in torch.where(b_host[img])[0].tolist()]
+            rows = [r if r < len(masks) else -1 for r in rows]
+            if not rows:
+                masks = zero[[]].view(0, *frame_size)
+            elif all(r >= 0 for r in rows):
+                masks = masks[torch.tensor(rows, device=masks.device)] if rows != list(range(len(masks))) else masks
+            else:
+                masks = torch.stack([masks[r] if r >= 0 else zero for r in rows], dim=0)
             pred_masks.append(aloscene.Mask(masks, names=("N", "H", "W"), labels=boxes.labels))
         return pred_boxes, pred_masks
