@@ -90,6 +90,8 @@ def _declare(lib):
     lib.alo_encoder_reference_points.argtypes = [vp, vp, ip, ip, c.POINTER(c.c_int), vp]
     lib.alo_conv1x1_nhwc.restype = ip
     lib.alo_conv1x1_nhwc.argtypes = [vp, vp, ip, vp, vp, vp] + [ip] * 8 + [vp]
+    lib.alo_panoptic_onehot.restype = ip
+    lib.alo_panoptic_onehot.argtypes = [vp, vp] + [ip] * 6 + [c.c_float, vp]
     lib.alo_ffn256.restype = ip
     lib.alo_ffn256.argtypes = [vp] * 6 + [c.c_long, ip, ip, vp]
     lib.alo_linear_shortk.restype = ip
@@ -919,4 +921,20 @@ def value_proj_head_major(x, weight, bias, padding_mask, heads):
         _check(lib().alo_value_proj_head_major(_ptr(x), _ptr(weight.contiguous()), None if bias is None else _ptr(bias.contiguous()),
                                                None if padding_mask is None else _ptr(padding_mask), _ptr(out), N, S, heads, K,
                                                ALO_BF16, _stream(x.device)))
+    return out
+
+
+
+def panoptic_onehot(mask_logits, frame_size, threshold=0.5):
+    """(B, Q, h, w) mask logits -> (B, Q, H, W) int64 one-hot instance masks: bilinear up-sampling, sigmoid, threshold and the
+    per-pixel arg-max over the queries in one pass (PanopticHead.inference)."""
+    if not mask_logits.is_cuda or mask_logits.dim() != 4:
+        raise RuntimeError("panoptic_onehot: needs CUDA (B, Q, h, w) logits")
+    x = mask_logits.float().contiguous()
+    b_, q, h, w_ = x.shape
+    H, W = int(frame_size[0]), int(frame_size[1])
+    out = torch.empty((b_, q, H, W), dtype=torch.long, device=x.device)
+    if out.numel():
+        with torch.cuda.device(x.device), _timed("panoptic_onehot", 8.0 * out.numel()):
+            _check(lib().alo_panoptic_onehot(_ptr(x), _ptr(out), b_, q, h, w_, H, W, float(threshold), _stream(x.device)))
     return out

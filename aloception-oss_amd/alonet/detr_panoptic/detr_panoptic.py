@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+import alo_hip
 import aloscene
 from alonet.common import load_weights
 from alonet.detr.misc import assert_and_export_onnx
@@ -93,23 +94,29 @@ class PanopticHead(nn.Module):
         frame_size = tuple(frame_size or forward_out["pred_masks"].shape[-2:])
         pred_boxes = self.detr.inference(forward_out, filters=b_filters, **kwargs)
         masks_all = forward_out["pred_masks"].float()
-        if masks_all.numel() > 0:
+        # on the GPU the whole chain below (up-sample, sigmoid, threshold, arg-max one-hot) is one kernel writing the int64 masks
+        fused = masks_all.is_cuda and masks_all.numel() > 0 and maskth >= 0 and alo_hip.is_available()
+        if fused:
+            onehot_all = alo_hip.panoptic_onehot(masks_all, frame_size, maskth)
+        elif masks_all.numel() > 0:
             masks_all = F.interpolate(masks_all, size=frame_size, mode="bilinear", align_corners=False)
         else:
             masks_all = masks_all.view(masks_all.shape[0], 0, *frame_size)
-        masks_all = F.threshold(masks_all.sigmoid(), maskth, 0.0)
+        if not fused:
+            masks_all = F.threshold(masks_all.sigmoid(), maskth, 0.0)
         pred_masks = []
         zero = torch.zeros(*frame_size, device=masks_all.device, dtype=torch.long)
         # which mask row (if any) belongs to each kept box: worked out on the host from ONE transfer of the two filters — the
         # per-box `(ib == kept).nonzero().item()` of the straightforward loop is three device synchronisations per box
         b_host = torch.stack(list(b_filters)).cpu() if len(b_filters) else None
         m_host = torch.stack(list(m_filters)).cpu() if len(m_filters) else None
-        for img, (boxes, masks, b_filter, m_filter) in enumerate(zip(pred_boxes, masks_all, b_filters, m_filters)):
-            nothing = (~masks.bool()).all(dim=0, keepdim=True)  # pixels where no query passes the threshold
-            onehot = torch.zeros_like(masks)
-            if onehot.numel():
-                onehot.scatter_(0, masks.argmax(dim=0, keepdim=True), 1)
-            masks = onehot.long() * (~nothing)
+        for img, (boxes, masks, b_filter, m_filter) in enumerate(zip(pred_boxes, onehot_all if fused else masks_all, b_filters, m_filters)):
+            if not fused:
+                nothing = (~masks.bool()).all(dim=0, keepdim=True)  # pixels where no query passes the threshold
+                onehot = torch.zeros_like(masks)
+                if onehot.numel():
+                    onehot.scatter_(0, masks.argmax(dim=0, keepdim=True), 1)
+                masks = onehot.long() * (~nothing)
             kept = torch.where(m_host[img])[0].tolist()
             row_of = {q: r for r, q in enumerate(kept)}
             rows = [row_of.get(q, -1) for q in torch.where(b_host[img])[0].tolist()]

@@ -151,3 +151,59 @@ extern "C" int alo_encoder_reference_points(const float* valid_ratios, float* re
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_encoder_reference_points: %s", hipGetErrorString(e));
     return check_launch("alo_encoder_reference_points");
 }
+
+// ---- panoptic post-processing: logits at mask resolution -> one-hot instance masks at frame resolution ----------------------------
+// alonet/detr_panoptic/detr_panoptic.py:96-110 (inference): F.interpolate(pred_masks.float(), frame_size, "bilinear") -> sigmoid ->
+// F.threshold(., maskth, 0) -> per pixel the arg-max query gets 1 unless no query passed the threshold.  Stock: ~10 element-wise
+// passes over (B, Q, H, W) fp32 / int64 tensors (1.1 GB each at 8 x 16 x 800 x 1333).  Here: one pass, the only full-size tensor
+// touched is the int64 output.
+namespace alo {
+namespace {
+struct OnehotDims {
+    int B, Q, h, w, H, W;
+    float thr;
+};
+
+__global__ void __launch_bounds__(256)
+panoptic_onehot_kernel(const float* __restrict__ logits, long long* __restrict__ out, const OnehotDims dm) {
+    const long total = (long)dm.B * dm.H * dm.W;
+    const float sh = (float)dm.h / (float)dm.H, sw = (float)dm.w / (float)dm.W;   // ATen: area_pixel_compute_scale, align_corners = False
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / ((long)dm.H * dm.W));
+        const int rem = (int)(i - (long)b * dm.H * dm.W), y = rem / dm.W, x = rem - y * dm.W;
+        float fy = sh * ((float)y + 0.5f) - 0.5f, fx = sw * ((float)x + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y1 = (int)fy, x1 = (int)fx;
+        const int yp = y1 < dm.h - 1 ? 1 : 0, xp = x1 < dm.w - 1 ? 1 : 0;
+        const float ly1 = fy - (float)y1, lx1 = fx - (float)x1, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* base = logits + (size_t)b * dm.Q * dm.h * dm.w + (size_t)y1 * dm.w + x1;
+        float best = 0.f;
+        int arg = -1;
+        for (int q = 0; q < dm.Q; ++q) {
+            const float* p = base + (size_t)q * dm.h * dm.w;
+            const float v = ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[yp * dm.w] + lx1 * p[yp * dm.w + xp]);
+            float s = 1.f / (1.f + expf(-v));
+            s = s > dm.thr ? s : 0.f;          // F.threshold(s, thr, 0)
+            if (s > best) { best = s; arg = q; }   // strict: ties keep the lowest query, as torch.argmax
+        }
+        long long* o = out + (size_t)b * dm.Q * dm.H * dm.W + rem;
+        for (int q = 0; q < dm.Q; ++q) o[(size_t)q * dm.H * dm.W] = q == arg ? 1 : 0;
+    }
+}
+}  // namespace
+}  // namespace alo
+
+extern "C" int alo_panoptic_onehot(const float* mask_logits, long long* onehot, int B, int Q, int h, int w, int H, int W,
+                                   float threshold, void* stream) {
+    ALO_REQUIRE(mask_logits && onehot, ALO_ERR_INVALID_ARGUMENT, "alo_panoptic_onehot: null pointer argument");
+    ALO_REQUIRE(B > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0, ALO_ERR_INVALID_ARGUMENT, "alo_panoptic_onehot: sizes must be positive");
+    ALO_REQUIRE(threshold >= 0.f, ALO_ERR_UNSUPPORTED, "alo_panoptic_onehot: the threshold must be non-negative (got %f)", (double)threshold);
+    alo::OnehotDims dm;
+    dm.B = B; dm.Q = Q; dm.h = h; dm.w = w; dm.H = H; dm.W = W; dm.thr = threshold;
+    void* args[] = {&mask_logits, &onehot, &dm};
+    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(alo::panoptic_onehot_kernel), dim3(alo::geo_blocks((long)B * H * W) * 4), dim3(256),
+                                   args, 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_panoptic_onehot: %s", hipGetErrorString(e));
+    return check_launch("alo_panoptic_onehot");
+}

@@ -311,6 +311,15 @@ int alo_encoder_reference_points(const float* valid_ratios, float* reference_poi
                                  void* stream);
 
 /*
+ * alo_panoptic_onehot: PanopticHead.inference's mask post-processing in one pass (alonet/detr_panoptic/detr_panoptic.py:96-110):
+ * onehot[b][q][y][x] = 1 where q is the arg-max over the image's queries of threshold(sigmoid(bilinear(mask_logits[b][q], (H, W))))
+ * (F.threshold(., threshold, 0); lowest query on ties) and at least one query passed the threshold, else 0.  mask_logits (B, Q, h, w)
+ * fp32, onehot (B, Q, H, W) int64 (aloscene.Mask's dtype).  Bilinear arithmetic as ATen's upsample_bilinear2d, align_corners = False.
+ */
+int alo_panoptic_onehot(const float* mask_logits, long long* onehot, int B, int Q, int h, int w, int H, int W, float threshold,
+                        void* stream);
+
+/*
  * alo_pos_sine_flat: the sine positional encoding of every level of the pyramid, written straight into the flattened
  * (B, S, 2F) layout the encoder consumes, level embedding added: what PositionEmbeddingSine.forward + the
  * `pos.flatten(2).transpose(1, 2) + level_embed[lvl]` / cat of DeformableTransformer.forward compute with ~15 PyTorch

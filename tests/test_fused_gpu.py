@@ -443,3 +443,25 @@ def test_conv1x1_strided_matches_convolution(shape, cout, stride):
         ref = F.relu(F.conv2d(x.float(), wt.float()[:, :, None, None], b.float(), stride))
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert (got.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,h,w,H,W", [(2, 16, 50, 84, 200, 334), (1, 3, 13, 21, 97, 160), (3, 1, 8, 8, 64, 64), (1, 5, 10, 10, 10, 10)])
+def test_panoptic_onehot_matches_the_torch_chain(B, Q, h, w, H, W):
+    """alo_panoptic_onehot against interpolate -> sigmoid -> threshold -> argmax one-hot (detr_panoptic.py:96-110).  A pixel can
+    only differ where two queries' probabilities (or a probability and the threshold) are within float rounding of each other."""
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + Q)
+    logits = torch.randn(B, Q, h, w, device="cuda", generator=g) * 3
+    logits[:, :, : h // 3] -= 6.0     # a region where no query passes the threshold
+    got = alo_hip.panoptic_onehot(logits, (H, W), 0.5)
+    m = F.threshold(F.interpolate(logits, size=(H, W), mode="bilinear", align_corners=False).sigmoid(), 0.5, 0.0)
+    want = []
+    for masks in m:
+        nothing = (~masks.bool()).all(dim=0, keepdim=True)
+        onehot = torch.zeros_like(masks)
+        onehot.scatter_(0, masks.argmax(dim=0, keepdim=True), 1)
+        want.append(onehot.long() * (~nothing))
+    want = torch.stack(want)
+    assert got.shape == want.shape and got.dtype == torch.long
+    assert int(got.sum(1).max()) <= 1 and bool((want.sum(1) == 0).any())
+    assert (got != want).float().mean().item() <= 1e-5
