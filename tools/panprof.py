@@ -24,7 +24,7 @@ except Exception as e:
 step(); torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
-rows = [(e.key, e.count, e.self_device_time_total, str(e.input_shapes)[:110]) for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 50]
+rows = [(e.key, e.count, e.device_time_total, str(e.input_shapes)[:110]) for e in prof.key_averages(group_by_input_shape=True) if e.device_time_total > 50 and e.key.startswith("aten::")]
 rows.sort(key=lambda r: -r[2])
 for k, c, t, sh in rows[:28]:
     print("%-34s x%-4d %8.1f us  %s" % (k[:34], c, t, sh))
