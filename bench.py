@@ -47,8 +47,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak, same guide
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)   # 30 x ~10 ms: long enough to average out dispatch jitter
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU (detection)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--raft-steps", type=int, default=2)
