@@ -480,6 +480,27 @@ def fusable(*tensors):
     return first.is_cuda and first.dtype in (torch.float32, torch.bfloat16)
 
 
+def add_layernorm_supported(x):
+    """What ``alo_add_layernorm`` can take: rows of C % 4 == 0, C <= 1024 elements, 16-byte aligned (callers fall back to
+    ``norm(x + y)`` otherwise, e.g. for a non-default d_model)."""
+    C = x.shape[-1]
+    return C % 4 == 0 and 0 < C <= 1024 and (C * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0
+
+
+def invalidate_caches(module):
+    """Drop every derived inference-time tensor this library cached on ``module``'s parameters and sub-modules (packed MFMA
+    weights, folded batch-norm convolutions, merged projections).  The caches are keyed on ``(tensor._version, data_ptr)``;
+    in-place writes through ``.data`` (``p.data.copy_``, EMA updates, ``nn.init.*_(w.data)``) do not bump the version
+    counter, so call this after such weight surgery — ``alonet.common.load_weights`` and ``GraphedForward`` do."""
+    for p in list(module.parameters()) + list(module.buffers()):
+        for key in ("_alo_packed", "_alo_2d"):
+            if key in getattr(p, "__dict__", {}):
+                delattr(p, key)
+    for m in module.modules():
+        for key in [k for k in m.__dict__ if k.startswith("_alo_") or k in ("_folded", "_mask_quarter") or k.startswith("_zr")]:
+            del m.__dict__[key]
+
+
 def add_layernorm(x, residual, weight, bias, eps=1e-5, pos=None):
     """``LayerNorm(x + residual)`` over the last dim in one pass; with ``pos`` also returns ``out + pos`` (the next
     layer's ``with_pos_embed``).  Replaces ``norm(src + dropout(src2))`` of the (de)formable transformer layers at

@@ -33,6 +33,9 @@ class GraphedForward:
         return (tuple((tuple(f.shape), f.dtype, str(f.device)) for f in frames), tuple(sorted(options.items())))
 
     def _capture(self, frames, options):
+        import alo_hip
+
+        alo_hip.invalidate_caches(self.model)  # weights edited through .data since the last forward: re-derive before pinning
         device = frames[0].device
         static_in = tuple(frames) if self.adopt_inputs else tuple(f.clone() for f in frames)
         side = torch.cuda.Stream(device=device)

@@ -28,5 +28,8 @@ def load_weights(model, weights, device=None, strict_load_weights=True):
     else:
         state = blob["model"] if isinstance(blob, dict) and "model" in blob else blob
     model.load_state_dict(state, strict=strict_load_weights)
+    import alo_hip
+
+    alo_hip.invalidate_caches(model)  # packed / folded / merged inference-time copies of the old weights
     print(f"Weights loaded from {path}")
     return model

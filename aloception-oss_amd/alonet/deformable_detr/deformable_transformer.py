@@ -29,8 +29,11 @@ def _level_geometry(shapes, device):
     key = (shapes, str(device))
     if key not in _GEOMETRY:
         sizes = [h * w for h, w in shapes]
-        spatial_shapes = torch.tensor(shapes, dtype=torch.int32, device=device)
-        level_start_index = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int32, device=device)
+        # built outside inference mode whatever the caller's mode: an inference tensor cached here would later fail in
+        # MSDeformAttnFunction's save_for_backward when a training step reuses the same pyramid shape
+        with torch.inference_mode(False):
+            spatial_shapes = torch.tensor(shapes, dtype=torch.int32, device=device)
+            level_start_index = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], dtype=torch.int32, device=device)
         spatial_shapes._alo_total = sum(sizes)
         spatial_shapes._alo_shapes = list(shapes)
         _GEOMETRY[key] = (spatial_shapes, level_start_index)
@@ -40,7 +43,8 @@ def _level_geometry(shapes, device):
 def _fused_ok(module, kwargs, *tensors):
     """The one-pass HIP epilogues (alo_add_layernorm) stand in for ``norm(x + dropout(y))`` when nothing is lost: eval mode
     (dropout is the identity), no autograd graph, CUDA, fp32 / bf16, and not the pure-torch export branch."""
-    return not module.training and "is_tracing" not in kwargs and alo_hip.fusable(*tensors)
+    return (not module.training and "is_tracing" not in kwargs and alo_hip.fusable(*tensors)
+            and alo_hip.add_layernorm_supported(tensors[0]))
 
 
 def _add_norm(norm, x, residual, pos=None):

@@ -10,6 +10,8 @@ Mirrors the public names of the reference's ``alonet/deformable_detr/ops/functio
 * ``ms_deform_attn_core_pytorch`` (reference :85-107) — the pure-torch formulation the reference keeps for ONNX /
   TorchScript tracing (``is_tracing`` branch of ``MSDeformAttn.forward``).  It is kept for that explicit branch only;
   nothing in this package falls back to it: on a missing library or a CPU tensor the ops raise.
+* ``bilinear_grid_sample`` (reference :110-190) — the export-friendly stand-in for ``F.grid_sample(mode="bilinear",
+  padding_mode="zeros")`` the reference's pure-torch formulation calls; same signature, written with index masks.
 """
 import torch
 import torch.nn.functional as F
@@ -120,3 +122,33 @@ def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations,
     sampled = torch.stack(sampled, dim=-2).reshape(N * M, D, Lq, L * P)
     weights = attention_weights.permute(0, 2, 1, 3, 4).reshape(N * M, 1, Lq, L * P)
     return (sampled * weights).sum(-1).reshape(N, M * D, Lq).transpose(1, 2).contiguous()
+
+
+def bilinear_grid_sample(im, grid, align_corners=False):
+    """``F.grid_sample(im, grid, mode="bilinear", padding_mode="zeros", align_corners=...)`` from elementary ops
+    (floor / gather / multiply-add), for exporters without a grid-sample operator.
+
+    ``im (N, C, H, W)``, ``grid (N, Hg, Wg, 2)`` with (x, y) in [-1, 1] -> ``(N, C, Hg, Wg)``.  Taps that fall outside
+    the map contribute zero (their index is clamped for the gather and their weight is masked).
+    """
+    n, c, h, w = im.shape
+    gn, gh, gw, two = grid.shape
+    assert n == gn and two == 2
+    gx, gy = grid[..., 0].reshape(n, -1), grid[..., 1].reshape(n, -1)
+    if align_corners:
+        x, y = (gx + 1) / 2 * (w - 1), (gy + 1) / 2 * (h - 1)
+    else:
+        x, y = ((gx + 1) * w - 1) / 2, ((gy + 1) * h - 1) / 2
+    x0, y0 = torch.floor(x), torch.floor(y)
+    fx, fy = x - x0, y - y0
+    flat = im.reshape(n, c, h * w)
+    out = None
+    for dy, wy in ((0, 1 - fy), (1, fy)):
+        for dx, wx in ((0, 1 - fx), (1, fx)):
+            xi, yi = x0 + dx, y0 + dy
+            inside = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1)
+            idx = (yi.clamp(0, h - 1) * w + xi.clamp(0, w - 1)).long()
+            tap = torch.gather(flat, 2, idx[:, None, :].expand(-1, c, -1))
+            term = tap * (wx * wy * inside.to(im.dtype))[:, None, :]
+            out = term if out is None else out + term
+    return out.reshape(n, c, gh, gw)

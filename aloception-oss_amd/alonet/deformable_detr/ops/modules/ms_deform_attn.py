@@ -109,8 +109,10 @@ class MSDeformAttn(nn.Module):
             raise ValueError(
                 "Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1])
             )
-        needs_grad = torch.is_grad_enabled() and any(
-            t.requires_grad for t in (query, input_flatten, reference_points, self.value_proj.weight))
+        # any trainable parameter of the layer counts (partial fine-tuning): the fused inference path has no backward
+        needs_grad = torch.is_grad_enabled() and (
+            any(t.requires_grad for t in (query, input_flatten, reference_points))
+            or any(p.requires_grad for p in self.parameters()))
         fused = "is_tracing" not in kwargs and not needs_grad and self.fused_prologue and query.is_cuda
         # inference: the four K = d_model linears go through the streaming MFMA kernel when it fits (bf16, d_model = 256)
         proj = (lambda lin, t: alo_hip.linear_auto(t, lin.weight, lin.bias)) if fused else (lambda lin, t: lin(t))

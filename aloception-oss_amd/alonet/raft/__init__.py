@@ -1,4 +1,5 @@
 from .corr import CorrBlock
 from .raft import RAFT, RAFTBase
+from .raft_small import RAFTSmall
 
-__all__ = ["CorrBlock", "RAFT", "RAFTBase"]
+__all__ = ["CorrBlock", "RAFT", "RAFTBase", "RAFTSmall"]

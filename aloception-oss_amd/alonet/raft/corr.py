@@ -11,18 +11,30 @@ import torch
 import alo_hip
 
 
+def _no_backward(*tensors):
+    """The HIP correlation kernels are forward-only: say so instead of silently cutting the graph (the reference's
+    CorrBlock is differentiable torch code, so RAFT's feature encoder would otherwise stop receiving gradients)."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        raise RuntimeError(
+            "alonet.raft.CorrBlock (HIP) has no backward: the correlation volume / lookup kernels are inference-only. "
+            "Run RAFT under torch.no_grad(), or pass a differentiable corr_block= to the model for training.")
+
+
 class CorrBlock:
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        _no_backward(fmap1, fmap2)
         self.num_levels = num_levels
         self.radius = radius
         self.corr_pyramid = alo_hip.corr_build(fmap1.float(), fmap2.float(), num_levels)
 
     def __call__(self, coords):
+        _no_backward(coords)
         return alo_hip.corr_lookup(self.corr_pyramid, coords.float(), self.radius)
 
     @staticmethod
     def corr(fmap1, fmap2):
         """All-pairs correlation only: (B,C,H,W) x2 -> (B,H,W,1,H,W), scaled by 1/sqrt(C)."""
+        _no_backward(fmap1, fmap2)
         B, _, H, W = fmap1.shape
         (vol,) = alo_hip.corr_build(fmap1.float(), fmap2.float(), 1)
         return vol.view(B, H, W, 1, H, W)

@@ -605,180 +605,6 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Head-major forward, x-PAIRED gathers (D == 32, fused prologue).
-//
-// The vector L1 serves LINES: tools/micro/l1_gather.hip measures the same number of gathered pieces per second whether a
-// piece is 32, 64 or 128 bytes of one 128-byte line (and half of it for 256-byte pieces).  A head's row is 64 bytes, so in
-// msda_fwd_bf16_mfma_kernel every corner costs a line slot of which half is used.  But the two corners of a bilinear tap that
-// share an image row, (y, x) and (y, x + 1), are ADJACENT in the head-major slab: when x is even they are one line.
-//
-// Here a (query, head) pair is served by EIGHT lanes: lanes 0-3 (side 0) own the tap's left column, lanes 4-7 (side 1) the
-// right column, 8 channels each.  A load instruction fetches, for 8 pairs at once, the left AND right corner of one row of one
-// tap: 128 contiguous bytes per pair — one line request when x is even, two when it is odd, 1.5 on average instead of 2.
-// The MFMA blocks (4 lanes) are independent, so each side accumulates its two corners of TWO taps per v_mfma_f32_4x4x4bf16_1k
-// (K = {top(s), bottom(s), top(s + 1), bottom(s + 1)}), with the same exact three-term bf16 split of the fp32 weights; the two
-// sides are added once per pair at the end.  Instruction counts per pair are those of the 4-lane kernel.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int kPairedWaveLds = 8 * kMfmaPairStride;
-
-__device__ __forceinline__ float oct_max(float v) {  // all-reduce over an aligned group of 8 lanes: quad all-reduce + half-row mirror
-    v = quad_max(v);
-    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));
-}
-__device__ __forceinline__ float oct_sum(float v) {
-    v = quad_sum(v);
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));
-}
-
-template <int SB>
-__global__ void __launch_bounds__(64)
-msda_fwd_hm_paired_kernel(const bf16_t* __restrict__ value, const int32_t* __restrict__ shapes,
-                          const int32_t* __restrict__ lstart, const void* __restrict__ loc_,
-                          const void* __restrict__ attn_, const float* __restrict__ ref, bf16_t* __restrict__ out,
-                          const Dims dm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using Ld = Loader<bf16_t, float, 8>;
-
-    const unsigned lb = xcd_contiguous_block(blockIdx.x, dm.nblocks);
-    const int b = lb / dm.blocks_per_batch;
-    const int chunk = lb % dm.blocks_per_batch;
-    const int ps = threadIdx.x >> 3, l8 = threadIdx.x & 7;   // pair slot in the wave; lane in the pair's group of 8
-    const int level = l8 >> 1, half = l8 & 1;                // stage 1: points 2 half, 2 half + 1 of level `level`
-    const int side = l8 >> 2, cq = l8 & 3;                   // stage 2: tap column (left / right), channels 8 cq .. + 7
-
-    const unsigned row_bytes = 64u;                          // D = 32 bf16
-    const long batch_pair0 = (long)b * dm.pairs_per_batch;
-    const int Lq = dm.pairs_per_batch / dm.M;
-
-    const int Hl = shapes[2 * level], Wl = shapes[2 * level + 1], start = lstart[level];
-    const float inv_w = 1.0f / (float)Wl, inv_h = 1.0f / (float)Hl;
-    unsigned char* dp = smem + ps * kMfmaPairStride;
-
-    for (int it = 0; it < dm.iters_per_block; ++it) {
-        const int run = chunk * dm.iters_per_block + it;
-        if (run >= dm.runs_per_batch) break;  // uniform
-        const int m = dm.m_shift >= 0 ? (run & (dm.M - 1)) : run % dm.M;
-        const int q = (dm.m_shift >= 0 ? (run >> dm.m_shift) : run / dm.M) * 8 + ps;
-        const bool dead = q >= Lq;
-        const int qc = min(q, Lq - 1);
-        const int pair = qc * dm.M + m;
-        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(value + ((size_t)b * dm.M + m) * dm.S * 32, (unsigned)dm.S * row_bytes);
-
-        // ---- stage 1: two sampling points -> the left-column and the right-column descriptor of sample pair l8 --------------
-        {
-            const long qrow = (long)b * Lq + qc;
-            const u32x2 lr = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(loc_) + qrow * dm.loc_row_elems + 32 * m + 8 * level + 4 * half);
-            const unsigned ar = *reinterpret_cast<const unsigned*>(static_cast<const bf16_t*>(attn_) + qrow * dm.attn_row_elems + 16 * m + 4 * level + 2 * half);
-            const float* rp = ref + (((long)b * Lq + qc) * dm.L + level) * dm.ref_dim;
-            float r0, r1, r2 = 0.f, r3 = 0.f;
-            if (dm.ref_dim == 2) {
-                const float2 rv = *reinterpret_cast<const float2*>(rp);
-                r0 = rv.x; r1 = rv.y;
-            } else {
-                const float4 rv = *reinterpret_cast<const float4*>(rp);
-                r0 = rv.x; r1 = rv.y; r2 = rv.z; r3 = rv.w;
-            }
-            float x[2] = {__uint_as_float(lr.x << 16), __uint_as_float(lr.y << 16)};
-            float y[2] = {__uint_as_float(lr.x & 0xffff0000u), __uint_as_float(lr.y & 0xffff0000u)};
-            float a[2] = {__uint_as_float(ar << 16), __uint_as_float(ar & 0xffff0000u)};
-            // softmax over the pair's 16 logits (2 here, 14 in the other lanes of the group); hardware exp / reciprocal as in
-            // the 4-lane kernel
-            const float mx = oct_max(fmaxf(a[0], a[1]));
-            a[0] = __expf(a[0] - mx); a[1] = __expf(a[1] - mx);
-            const float inv = __builtin_amdgcn_rcpf(oct_sum(a[0] + a[1]));
-            FwdDesc<float> fd[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] *= inv;
-                if (dm.ref_dim == 2) {
-                    x[i] = r0 + x[i] * inv_w;
-                    y[i] = r1 + y[i] * inv_h;
-                } else {
-                    x[i] = r0 + x[i] / (float)dm.P * r2 * 0.5f;
-                    y[i] = r1 + y[i] / (float)dm.P * r3 * 0.5f;
-                }
-                // a query past the end samples far outside the map: every corner becomes "not read, weight 0" by itself
-                fd[i] = make_desc<float, true>(dead ? -8.0f : x[i], dead ? -8.0f : y[i], a[i], Hl, Wl, start, row_bytes);
-            }
-#pragma unroll
-            for (int sd = 0; sd < 2; ++sd) {   // corners 0 / 2 = left column (top, bottom), 1 / 3 = right column
-                MfmaDesc d;
-                const float w4[4] = {fd[0].w[sd], fd[0].w[2 + sd], fd[1].w[sd], fd[1].w[2 + sd]};
-                d.off[0] = fd[0].off[sd]; d.off[1] = fd[0].off[2 + sd]; d.off[2] = fd[1].off[sd]; d.off[3] = fd[1].off[2 + sd];
-                unsigned wb[4], r1b[4], r2b[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    wb[k] = __float_as_uint(w4[k]);
-                    const float e1 = w4[k] - __uint_as_float(wb[k] & 0xffff0000u);    // exact: the low 16 mantissa bits
-                    r1b[k] = __float_as_uint(e1);
-                    const float e2 = e1 - __uint_as_float(r1b[k] & 0xffff0000u);      // exact: <= 8 significant bits left
-                    r2b[k] = __float_as_uint(e2);
-                }
-                d.arow[0][0] = __builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u);
-                d.arow[0][1] = __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u);
-                d.arow[1][0] = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u);
-                d.arow[1][1] = __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u);
-                d.arow[2][0] = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u);
-                d.arow[2][1] = __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u);
-                d.arow[3][0] = 0u;
-                d.arow[3][1] = 0u;
-                *reinterpret_cast<MfmaDesc*>(dp + (2 * l8 + sd) * (int)sizeof(MfmaDesc)) = d;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- stage 2: gather + MFMA accumulate: 8 sample pairs, this lane's column of each --------------------------------------
-        {
-            const unsigned coff = (unsigned)cq * 16u;
-            f32x4 acc[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int s0 = 0; s0 < 8; s0 += SB) {
-                u32x4 raw[SB][4];
-                s16x4 arow[SB];
-#pragma unroll
-                for (int j = 0; j < SB; ++j) {
-                    const unsigned char* e = dp + (2 * (s0 + j) + side) * (int)sizeof(MfmaDesc);
-                    const u32x4 off = *reinterpret_cast<const u32x4*>(e);
-                    const u32x2 ar = *reinterpret_cast<const u32x2*>(e + 16 + 8 * cq);
-                    arow[j] = as_s16x4(ar.x, ar.y);
-                    raw[j][0] = Ld::load(rsrc, off.x + coff);
-                    raw[j][1] = Ld::load(rsrc, off.y + coff);
-                    raw[j][2] = Ld::load(rsrc, off.z + coff);
-                    raw[j][3] = Ld::load(rsrc, off.w + coff);
-                }
-#pragma unroll
-                for (int j = 0; j < SB; ++j) {
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        const unsigned t0 = raw[j][0][qd], t1 = raw[j][1][qd], t2 = raw[j][2][qd], t3 = raw[j][3][qd];
-                        const s16x4 b_even = as_s16x4(__builtin_amdgcn_perm(t1, t0, 0x05040100u),
-                                                      __builtin_amdgcn_perm(t3, t2, 0x05040100u));
-                        const s16x4 b_odd = as_s16x4(__builtin_amdgcn_perm(t1, t0, 0x07060302u),
-                                                     __builtin_amdgcn_perm(t3, t2, 0x07060302u));
-                        acc[2 * qd] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[j], b_even, acc[2 * qd], 0, 0, 0);
-                        acc[2 * qd + 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[j], b_odd, acc[2 * qd + 1], 0, 0, 0);
-                    }
-                }
-            }
-            float o[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                o[i] = (acc[i][0] + acc[i][1]) + acc[i][2];
-                o[i] += __shfl_xor(o[i], 4, 64);   // left column + right column
-            }
-            if (!dead && side == 0) store_vec<bf16_t, float, 8>(out + (batch_pair0 + pair) * 32 + cq * 8, o);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT>
@@ -924,29 +750,6 @@ struct Plan {
     bool lp16;
 };
 
-// Kernel-tuning knobs, read once from the environment (results never depend on them).
-//   ALO_MSDA_FWD_BATCH  2 | 4 | 8   sampling points whose 4 corner loads are put in flight together (forward)
-//   ALO_MSDA_ITERS      1..64       runs of pairs per workgroup (0 = automatic)
-struct Tuning {
-    int fwd_batch = 4;
-    int iters = 0;
-    int bwd_lanes = 1;     // ALO_MSDA_BWD_LANES=0: vector lanes (16 B per lane) in backward; 1: one channel per lane
-    int mfma = 1;          // ALO_MSDA_MFMA=0: keep bf16 forward on the VALU kernel
-    int paired = 0;        // ALO_MSDA_PAIRED=1: head-major forward on the x-paired 8-lane kernel (measured 6 % slower in the model)
-};
-const Tuning& tuning() {
-    static const Tuning t = [] {
-        Tuning x;
-        if (const char* e = getenv("ALO_MSDA_FWD_BATCH")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8) x.fwd_batch = v; }
-        if (const char* e = getenv("ALO_MSDA_BWD_LANES")) x.bwd_lanes = atoi(e);
-        if (const char* e = getenv("ALO_MSDA_MFMA")) x.mfma = atoi(e);
-        if (const char* e = getenv("ALO_MSDA_PAIRED")) x.paired = atoi(e);
-        if (const char* e = getenv("ALO_MSDA_ITERS")) { const int v = atoi(e); if (v >= 0 && v <= 64) x.iters = v; }
-        return x;
-    }();
-    return t;
-}
-
 inline int pick_group(int lanes_needed) {
     static const int kGroups[] = {4, 8, 16, 64};
     for (int g : kGroups)
@@ -982,7 +785,6 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G, long tar
     long ipb = iters_total * N / target_blocks;  // keep >= ~4096 workgroups of 4 waves in flight when the problem allows it
     if (ipb < 1) ipb = 1;
     if (ipb > 8) ipb = 8;
-    if (tuning().iters > 0) ipb = tuning().iters;
     d.iters_per_block = (int)ipb;
     d.runs_per_batch = (int)iters_total;
     d.blocks_per_batch = (int)((iters_total + ipb - 1) / ipb);
@@ -1007,15 +809,8 @@ int launch(K kernel, const Dims& dm, size_t lds, hipStream_t stream, const char*
 #define ALO_FWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
     if (plan.vec == VEC && plan.g == G && plan.lp16 == (LPCT == 16)) {                                             \
         const size_t lds = kMetaBytes + (size_t)(kThreads / G) * ((size_t)L * P * sizeof(FwdDesc<CT>) + 16);       \
-        if (fused) {                                                                                               \
-            if (LPCT == 16 && sb == 2)                                                                             \
-                return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, 2, true>, dm, lds, stream, "alo_msda_forward_fused", args); \
+        if (fused)                                                                                                 \
             return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 2), true>, dm, lds, stream, "alo_msda_forward_fused", args); \
-        }                                                                                                          \
-        if (LPCT == 16 && sb == 2)                                                                                 \
-            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, 2, false>, dm, lds, stream, "alo_msda_forward", args); \
-        if (LPCT == 16 && sb == 8)                                                                                 \
-            return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 8 : 2), false>, dm, lds, stream, "alo_msda_forward", args); \
         return launch(msda_fwd_kernel<T, LT, CT, VEC, G, LPCT, (LPCT ? 4 : 2), false>, dm, lds, stream, "alo_msda_forward", args);     \
     }
 #define ALO_BWD_CASE(T, LT, CT, VEC, G, LPCT)                                                                     \
@@ -1067,7 +862,6 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
     const Plan plan = make_plan(D, L, P, elem, aligned);
     Dims dm = make_dims(N, S, M, D, L, Lq, P, plan.g);
     dm.ref_dim = ref_dim;
-    const int sb = tuning().fwd_batch;
     void* args[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm};
     const bool in_aligned = (((uintptr_t)loc | (uintptr_t)attn | (uintptr_t)(fused ? ref : nullptr)) & 15) == 0;
     const bool wave_kernel = value_dtype == ALO_BF16 && aligned && in_aligned && L == 4 && P == 4 && D % 8 == 0 &&
@@ -1079,38 +873,21 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
         dm.ref_dim = ref_dim;
         if (loc_row_elems > 0) dm.loc_row_elems = (int)loc_row_elems;
         if (attn_row_elems > 0) dm.attn_row_elems = (int)attn_row_elems;
-        const int loc_rs = dm.loc_row_elems, attn_rs = dm.attn_row_elems;
         // runs are (16 consecutive queries, head) tiles; heads of one query block stay on neighbouring waves
         const long runs = (long)((Lq + 15) / 16) * M;
         dm.runs_per_batch = (int)runs;
         dm.blocks_per_batch = (int)((runs + dm.iters_per_block - 1) / dm.iters_per_block);
         dm.nblocks = (unsigned)(dm.blocks_per_batch * N);
-        if (D == 32 && tuning().paired) {
-            // x-paired gathers: a wave serves 8 consecutive queries of one head (see msda_fwd_hm_paired_kernel)
-            dm = make_dims(N, S, M, D, L, Lq, P, 32, 16384);
-            dm.ref_dim = ref_dim;
-            dm.loc_row_elems = loc_rs;
-            dm.attn_row_elems = attn_rs;
-            const long runs8 = (long)((Lq + 7) / 8) * M;
-            dm.runs_per_batch = (int)runs8;
-            dm.blocks_per_batch = (int)((runs8 + dm.iters_per_block - 1) / dm.iters_per_block);
-            dm.nblocks = (unsigned)(dm.blocks_per_batch * N);
-            if (sb == 2) return launch(msda_fwd_hm_paired_kernel<2>, dm, kPairedWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
-            return launch(msda_fwd_hm_paired_kernel<4>, dm, kPairedWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
-        }
-        if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, true, true>, dm, kWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
         return launch(msda_fwd_bf16_mfma_kernel<4, true, true>, dm, kWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
     }
-    if (wave_kernel && tuning().mfma) {
+    if (wave_kernel) {
         // bf16 rows go to the matrix pipe untouched, one wave per 16 pairs (see msda_fwd_bf16_mfma_kernel)
         dm = make_dims(N, S, M, D, L, Lq, P, 16, 16384);
         dm.ref_dim = ref_dim;
         const char* what = fused ? "alo_msda_forward_fused" : "alo_msda_forward";
         if (fused) {
-            if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, true, false>, dm, kWaveLds, stream, what, args, 64);
             return launch(msda_fwd_bf16_mfma_kernel<4, true, false>, dm, kWaveLds, stream, what, args, 64);
         }
-        if (sb == 2) return launch(msda_fwd_bf16_mfma_kernel<2, false, false>, dm, kWaveLds, stream, what, args, 64);
         return launch(msda_fwd_bf16_mfma_kernel<4, false, false>, dm, kWaveLds, stream, what, args, 64);
     }
     if (value_dtype == ALO_F32) { ALO_ALL_CASES(ALO_FWD_CASE, float, float, float, 4) }
@@ -1184,7 +961,7 @@ extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shape
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: memset: %s", hipGetErrorString(e));
     const bool aligned = (((uintptr_t)value | (uintptr_t)grad_out) & 15) == 0;
     Plan plan = make_plan(D, L, P, elem, aligned);
-    if (tuning().bwd_lanes == 1 && D <= 64) {
+    if (D <= 64) {
         // one channel per lane: each of the four atomics of a sampling point then covers D consecutive elements of ONE row
         // (a whole 128-byte line for D = 32 fp32) instead of every VEC-th element of it
         plan.vec = 1;

@@ -155,3 +155,107 @@ def test_cached_derived_weights_follow_parameter_updates():
         lin.weight.add_(1.0)  # in-place update bumps the version counter
     second = _cached(lin, "_double", (lin.weight,), lambda: 2 * lin.weight)
     assert second is not first and torch.equal(second, 2 * lin.weight)
+
+
+# ---- round 2: API surface completed, advisor findings -----------------------------------------------------------------
+def test_bilinear_grid_sample_is_grid_sample():
+    """ops/functions/ms_deform_attn_func.py:110-190 of the reference == F.grid_sample(bilinear, zeros); so is ours."""
+    from alonet.deformable_detr.ops.functions import bilinear_grid_sample
+
+    gen = torch.Generator().manual_seed(5)
+    im = torch.randn(2, 3, 7, 9, generator=gen, dtype=torch.float64)
+    grid = torch.rand(2, 5, 6, 2, generator=gen, dtype=torch.float64) * 2.6 - 1.3  # taps inside, on the border and outside
+    for align in (False, True):
+        want = torch.nn.functional.grid_sample(im, grid, mode="bilinear", padding_mode="zeros", align_corners=align)
+        assert (bilinear_grid_sample(im, grid, align) - want).abs().max().item() <= 1e-12
+
+
+def test_bilinear_sampler_and_padder():
+    import aloscene
+    from alonet.raft.utils.utils import Padder, bilinear_sampler
+
+    gen = torch.Generator().manual_seed(6)
+    img = torch.randn(1, 2, 6, 8, generator=gen)
+    ys, xs = torch.meshgrid(torch.arange(6.0), torch.arange(8.0), indexing="ij")
+    coords = torch.stack([xs, ys], -1)[None]
+    assert (bilinear_sampler(img, coords) - img).abs().max().item() <= 1e-6  # integer pixel coordinates: identity
+    out, inside = bilinear_sampler(img, coords + 0.5, mask=True)
+    assert out.shape == img.shape and inside.shape == (1, 6, 8, 1) and inside[0, -1, -1, 0] == 0 and inside[0, 2, 3, 0] == 1
+    frame = aloscene.Frame(torch.rand(3, 30, 45), normalization="minmax_sym")
+    p = Padder()
+    padded = p.pad(frame)
+    assert padded.shape[-2] % 8 == 0 and padded.normalization == "minmax_sym"
+    # the reference derives the width padding from the HEIGHT (utils.py:41): ((30 // 8) + 1) * 8 - 45 mod 8 = 3
+    assert (p.pad_h, p.pad_w) == (2, 3) and tuple(padded.shape[-2:]) == (32, 48)
+    assert torch.equal(p.unpad(padded.as_tensor()), frame.as_tensor())
+
+
+def test_raft_small_builds_with_reference_layout():
+    from alonet.raft import RAFTSmall
+
+    m = RAFTSmall()
+    keys = set(m.state_dict())
+    assert m.corr_radius == 3 and m.hidden_dim == 96 and m.context_dim == 64
+    assert {"update_block.encoder.convc1.weight", "update_block.gru.convz.weight", "update_block.flow_head.conv2.bias",
+            "fnet.layer1.0.conv3.weight"} <= keys
+    assert tuple(m.update_block.encoder.convc1.weight.shape) == (96, 4 * 49, 1, 1)
+    assert tuple(m.fnet.conv2.weight.shape) == (128, 96, 1, 1) and tuple(m.cnet.conv2.weight.shape) == (160, 96, 1, 1)
+
+
+def test_level_geometry_built_under_inference_mode_is_not_an_inference_tensor():
+    """A validation forward under torch.inference_mode() (Lightning's default) fills the cache; a later training step at the
+    same pyramid shape must be able to save these tensors for backward."""
+    from alonet.deformable_detr.deformable_transformer import _level_geometry
+
+    with torch.inference_mode():
+        shapes, start = _level_geometry(((6, 9), (3, 5)), torch.device("cpu"))
+    assert not shapes.is_inference() and not start.is_inference()
+
+    class Keep(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, meta):
+            ctx.save_for_backward(x, meta)
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2, None
+
+    x = torch.ones(3, requires_grad=True)
+    Keep.apply(x, shapes).sum().backward()
+    assert torch.equal(x.grad, torch.full((3,), 2.0))
+
+
+def test_corr_block_refuses_to_cut_the_autograd_graph():
+    f1 = torch.randn(1, 8, 4, 4, requires_grad=True)
+    with pytest.raises(RuntimeError, match="no backward"):
+        CorrBlock(f1, torch.randn(1, 8, 4, 4))
+    with pytest.raises(RuntimeError, match="no backward"):
+        CorrBlock.corr(f1, f1)
+
+
+def test_fused_inference_path_is_off_when_any_layer_parameter_trains():
+    """Partial fine-tuning: inputs detached, value_proj frozen, sampling_offsets trainable -> the differentiable branch runs
+    (on the CPU that is the tracing formulation) and the trainable parameter receives a gradient."""
+    m = MSDeformAttn(32, 2, 4, 2)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    m.sampling_offsets.bias.requires_grad_(True)
+    shapes = torch.tensor([(4, 5), (2, 3)], dtype=torch.int32)
+    start = torch.tensor([0, 20], dtype=torch.int32)
+    out = m(torch.randn(1, 6, 32), torch.rand(1, 6, 2, 2), torch.randn(1, 26, 32), shapes, start, None, is_tracing=None)
+    out.sum().backward()
+    assert m.sampling_offsets.bias.grad is not None and m.sampling_offsets.bias.grad.abs().sum() > 0
+
+
+def test_add_layernorm_support_gate_and_cache_invalidation():
+    import alo_hip
+
+    assert alo_hip.add_layernorm_supported(torch.zeros(4, 256))
+    assert not alo_hip.add_layernorm_supported(torch.zeros(4, 1280))  # above the kernel's 1024-channel rows
+    assert not alo_hip.add_layernorm_supported(torch.zeros(4, 30, dtype=torch.bfloat16))
+    lin = torch.nn.Linear(4, 4)
+    lin.weight._alo_packed = ("tag", torch.zeros(1))
+    lin.__dict__["_alo_merged"] = ("key", None)
+    alo_hip.invalidate_caches(lin)
+    assert not hasattr(lin.weight, "_alo_packed") and "_alo_merged" not in lin.__dict__

@@ -195,3 +195,95 @@ def test_graphed_forward_replays_raft(golden):
             flows.append(got[-1]["up_flow"].clone())
     assert (flows[0] - flows[1]).abs().max().item() > 0.1   # the swapped pair was really copied into the captured inputs
     assert len(graphed._graphs) == 1
+
+
+# ---- stated bf16 end-to-end tolerances -------------------------------------------------------------------
+BF16_TRANSFORMER_TOL = 6e-2   # max-abs on hs / memory (LayerNorm-ed, O(1) values) after 2 + 2 layers in bf16
+BF16_MODEL_LOGIT_TOL = 0.25   # max-abs on the raw class logits of the full R50 model, bf16 vs fp32 (same weights, same frames)
+BF16_MODEL_BOX_TOL = 0.06     # max-abs on the (sigmoid) boxes in [0, 1]
+
+
+def test_deformable_transformer_bf16_fast_path_vs_reference_golden(golden):
+    """G5 inputs through the bf16 inference path bench.py runs (merged projections, value_proj_head_major, fused head-major
+    MSDA, add_layernorm, ffn256 kernels) against the REFERENCE's fp64 outputs, with a stated max-abs tolerance."""
+    import alo_hip
+
+    g = golden("g5_deformable_transformer.npz")
+    tr, L = build_g5_transformer(g)
+    tr = tr.to(DEV, torch.bfloat16).eval()
+    bf = lambda a: t(a).to(DEV, torch.bfloat16)  # noqa: E731
+    srcs, poss = [bf(g[f"src{i}"]) for i in range(L)], [bf(g[f"pos{i}"]) for i in range(L)]
+    masks = [t(g[f"mask{i}"]).to(DEV) for i in range(L)]
+    with alo_hip.LaunchTimer() as timer, torch.no_grad():
+        out = tr(srcs, masks, poss, bf(g["query_embed"]))
+    tags = timer.summary()
+    assert any(k.startswith("msda_fwd_fused") for k in tags) and any(k.startswith("value_proj_hm") for k in tags), tags.keys()
+    errs = {"hs": np.abs(out["hs"].double().cpu().numpy() - g["hs"]).max(),
+            "ref": np.abs(out["inter_references_out"].double().cpu().numpy() - g["inter_references_out"]).max()}
+    for i in range(L):
+        errs[f"memory{i}"] = np.abs(out["memory"][i].double().cpu().numpy() - g[f"memory{i}"]).max()
+    print("bf16 fast path vs G5 golden, max-abs:", {k: float(v) for k, v in errs.items()})
+    assert max(errs.values()) <= BF16_TRANSFORMER_TOL, errs
+
+
+def test_deformable_detr_r50_bf16_vs_fp32_max_abs():
+    """The configuration of the headline number (bf16 end to end, backbone included) against the fp32 run of the same model:
+    max-abs bounds on logits and boxes, not a mean."""
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=False, device=torch.device(DEV)).eval()
+    frames = aloscene.Frame.batch_list(_frames([(384, 512), (352, 480)], seed=7)).to(DEV)
+    with torch.no_grad():
+        ref = model(frames)
+        out = model.bfloat16()(frames.to(torch.bfloat16))
+    dl = (out["pred_logits"].float() - ref["pred_logits"]).abs().max().item()
+    db = (out["pred_boxes"].float() - ref["pred_boxes"]).abs().max().item()
+    print("bf16 vs fp32 full model: max-abs logits", dl, "boxes", db)
+    assert dl <= BF16_MODEL_LOGIT_TOL and db <= BF16_MODEL_BOX_TOL
+
+
+# ---- BASELINE configs[3] / configs[4] at their per-GPU size -------------------------------------------------------------------
+def test_config4_training_step_at_per_gpu_size():
+    """configs[3]: global batch 32 on 8 GPUs = 4 frames of 1333x800 per GPU, fp32: two full training steps
+    (forward, Hungarian match, set loss, alo_msda_backward at Lq = S = 22223, clip, AdamW)."""
+    from alonet.deformable_detr.training import build_criterion, configure_optimizers, training_step
+    import alo_hip
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=True, device=torch.device(DEV)).train()
+    gen = torch.Generator().manual_seed(11)
+    names = [f"class_{i}" for i in range(91)]
+    frs = []
+    for _ in range(4):
+        lab = aloscene.Labels(torch.randint(0, 91, (10,), generator=gen).float(), encoding="id", labels_names=names)
+        cxcy, wh = torch.rand(10, 2, generator=gen) * 0.6 + 0.2, torch.rand(10, 2, generator=gen) * 0.3 + 0.05
+        bx = aloscene.BoundingBoxes2D(torch.cat([cxcy, wh], 1), "xcyc", False, labels=lab)
+        frs.append(aloscene.Frame(torch.rand(3, 800, 1333, generator=gen) * 255, normalization="255", boxes2d=bx).norm_resnet())
+    frames = aloscene.Frame.batch_list(frs).to(DEV)
+    crit, opt = build_criterion(), configure_optimizers(model)
+    with alo_hip.LaunchTimer(only="msda_bwd") as timer:
+        loss0, _ = training_step(model, crit, opt, frames)
+        loss1, _ = training_step(model, crit, opt, frames)
+    tags = timer.summary()
+    assert any(k == "msda_bwd/Lq=22223" for k in tags), tags.keys()
+    assert torch.isfinite(loss0) and torch.isfinite(loss1)
+    for p in model.transformer.parameters():
+        assert p.grad is None or torch.isfinite(p.grad).all()
+
+
+def test_config5_panoptic_at_per_gpu_size():
+    """configs[4]: batch 64 on 8 GPUs = 8 frames of 1333x800 per GPU, bf16, 16 kept queries per frame: forward + inference()."""
+    from alonet.deformable_detr_panoptic import DeformableDetrR50Panoptic
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50Panoptic(num_classes=250, device=torch.device(DEV)).eval().to(torch.bfloat16)
+    model = model.to(memory_format=torch.channels_last)
+    frames = aloscene.Frame.batch_list(_frames([(800, 1333)] * 8, seed=9)).to(DEV).to(torch.bfloat16)
+    keep = [torch.zeros(300, dtype=torch.bool, device=DEV) for _ in range(8)]
+    for k in keep:
+        k[torch.arange(16, device=DEV) * 18] = True
+    with torch.no_grad():
+        out = model(frames, filters=keep)
+        boxes, masks = model.inference(out, filters=keep)
+    assert out["pred_masks"].shape[:2] == (8, 16) and torch.isfinite(out["pred_masks"].float()).all()
+    assert len(masks) == 8 and tuple(masks[0].shape) == (16, 800, 1333) and int(masks[0].as_tensor().sum(0).max()) <= 1
+    assert boxes[0].shape == (16, 4)

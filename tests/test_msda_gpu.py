@@ -1,6 +1,4 @@
 """Parity of the HIP multi-scale deformable attention (through the C ABI) with the golden vectors and the oracle."""
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -330,19 +328,13 @@ def test_head_major_path_is_bit_identical_and_masks_padding(N, M, D, Lq, ref_dim
     assert torch.equal(alo_hip.value_head_major(value, None), value.permute(0, 2, 1, 3))
     got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
     want = alo_hip.msda_forward_fused(value.masked_fill(mask[..., None, None], 0), shapes, start, offsets, logits, ref)
-    paired = D == 32 and os.environ.get("ALO_MSDA_PAIRED", "0") == "1"
-    if os.environ.get("ALO_MSDA_MFMA") == "0" or paired:
-        # tuning knob: the pixel-major call then runs the generic (VALU) kernel; D = 32: the x-paired kernel adds the left and the
-        # right tap columns separately (same exact products, another order of the fp32 additions): one bf16 ulp at most
-        assert ((got.float() - want.float()).abs() <= want.float().abs() * 2.0 ** -7 + 1e-6).all()
-        # ... and against the float64 definition itself
-        loc, attn = _prologue_in_torch(offsets.float(), logits.float(), ref, shapes, 4)
-        exact = O.msda_forward(value.masked_fill(mask[..., None, None], 0).double().cpu().numpy(), shapes.cpu().numpy(),
-                               start.cpu().numpy(), loc.double().cpu().numpy(), attn.double().cpu().numpy())
-        err = np.abs(got.double().cpu().numpy() - exact)
-        assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)   # half a bf16 ulp + the fp32 prologue (hardware exp / rcp)
-    else:
-        assert torch.equal(got, want)
+    assert torch.equal(got, want)
+    # ... and directly against the float64 definition (oracle), not only against the sibling kernel
+    loc, attn = _prologue_in_torch(offsets.float(), logits.float(), ref, shapes, 4)
+    exact = O.msda_forward(value.masked_fill(mask[..., None, None], 0).double().cpu().numpy(), shapes.cpu().numpy(),
+                           start.cpu().numpy(), loc.double().cpu().numpy(), attn.double().cpu().numpy())
+    err = np.abs(got.double().cpu().numpy() - exact)
+    assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)   # half a bf16 ulp + the fp32 prologue (hardware exp / rcp)
 
 
 def test_head_major_rejects_other_shapes():
@@ -375,3 +367,114 @@ def test_head_major_takes_offsets_and_logits_as_slices_of_a_merged_projection(N,
     got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
     want = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets.contiguous(), logits.contiguous(), ref)
     assert torch.equal(got, want)
+
+
+# ---- the exact kernel bench.py times: bf16, fused prologue, head-major, merged-projection slices, padding mask ---------
+def _bench_path_case(N, Lq_is_S, shapes_l, seed, encoder_like):
+    """Inputs shaped as MSDeformAttn.forward hands them to alo_msda_forward_fused_hm_rows in the bf16 inference path."""
+    M, D, L, P = 8, 32, 4, 4
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    shapes = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
+    start = dev(level_start(shapes_l))
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    Lq = S if Lq_is_S else 300
+    value = torch.randn(N, S, M, D, generator=gen, device=DEV).bfloat16()
+    mask = torch.rand(N, S, generator=gen, device=DEV) < 0.1
+    both = torch.randn(N, Lq, M * L * P * 3, generator=gen, device=DEV)
+    both[..., :M * L * P * 2] *= 3.0   # offsets of a few pixels
+    both = both.bfloat16()
+    if encoder_like:   # reference points = every pixel's own centre on every level (what the encoder passes)
+        refs = []
+        for (h, w) in shapes_l:
+            ys, xs = torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w, device=DEV), indexing="ij")
+            refs.append(torch.stack([(xs.reshape(-1) + 0.5) / w, (ys.reshape(-1) + 0.5) / h], -1))
+        ref = torch.cat(refs, 0)[None, :, None, :].expand(N, S, L, 2).contiguous()
+    else:
+        ref = torch.rand(N, Lq, L, 2, generator=gen, device=DEV)
+    offsets = both[..., :M * L * P * 2].view(N, Lq, M, L, P, 2)
+    logits = both[..., M * L * P * 2:].view(N, Lq, M, L * P)
+    return value, mask, offsets, logits, ref, shapes, start
+
+
+def _oracle_on_queries(value, mask, offsets, logits, ref, shapes, start, qsel):
+    """oracle.msda_forward (float64) on the query subset ``qsel``, fed the kernel's own bf16-rounded inputs."""
+    loc, attn = _prologue_in_torch(offsets[:, qsel].double(), logits[:, qsel].double(), ref[:, qsel].double(), shapes, 4)
+    v = value.masked_fill(mask[..., None, None], 0).double().cpu().numpy()
+    return O.msda_forward(v, shapes.cpu().numpy(), start.cpu().numpy(), loc.cpu().numpy(), attn.cpu().numpy())
+
+
+@pytest.mark.parametrize("encoder_like", [True, False])
+def test_bench_kernel_direct_vs_oracle_small(encoder_like):
+    shapes_l = [(16, 21), (8, 11), (4, 6), (2, 3)]
+    value, mask, offsets, logits, ref, shapes, start = _bench_path_case(2, encoder_like, shapes_l, 31, encoder_like)
+    vhm = alo_hip.value_head_major(value, mask)
+    assert not offsets.is_contiguous()   # the merged-projection slices go to alo_msda_forward_fused_hm_rows as they are
+    got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    exact = _oracle_on_queries(value, mask, offsets, logits, ref, shapes, start, slice(None))
+    err = np.abs(got.double().cpu().numpy() - exact)
+    assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)   # half a bf16 ulp of the result + the fp32 prologue
+
+
+def test_bench_kernel_direct_vs_oracle_full_size_batch8():
+    """BASELINE configs[1] shape of the encoder call (N = 8, S = Lq = 22223): every 41st query of the launch bench.py times
+    against the float64 oracle."""
+    value, mask, offsets, logits, ref, shapes, start = _bench_path_case(8, True, DETR_SHAPES, 32, True)
+    vhm = alo_hip.value_head_major(value, mask)
+    got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    qsel = slice(0, None, 41)
+    exact = _oracle_on_queries(value, mask, offsets, logits, ref, shapes, start, qsel)
+    err = np.abs(got[:, qsel].double().cpu().numpy() - exact)
+    assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)
+    # the last queries of the launch (tail tiles) too
+    tail = slice(22223 - 70, None)
+    exact = _oracle_on_queries(value, mask, offsets, logits, ref, shapes, start, tail)
+    err = np.abs(got[:, tail].double().cpu().numpy() - exact)
+    assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)
+
+
+# ---- backward at the config-4 encoder size -------------------------------------------------------------------------------
+def _encoder_like_loc(N, shapes_l, rng, spread_px=4.0):
+    """Sampling locations of an encoder call: every query is a pixel of the pyramid, its points lie within a few pixels of
+    its own position on every level (N, S, 8, 4, 4, 2)."""
+    refs = []
+    for (h, w) in shapes_l:
+        ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        refs.append(np.stack([(xs.reshape(-1) + 0.5) / w, (ys.reshape(-1) + 0.5) / h], -1))
+    ref = np.concatenate(refs, 0)
+    S = ref.shape[0]
+    norm = np.array([[w, h] for h, w in shapes_l], np.float64)
+    off = rng.uniform(-spread_px, spread_px, (N, S, 8, 4, 4, 2)) / norm[None, None, None, :, None, :]
+    return (ref[None, :, None, None, None, :] + off).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["encoder", "uniform"])
+def test_full_size_backward_vs_oracle(kind):
+    """alo_msda_backward at N = 1, S = Lq = 22223 (fp32) against the C oracle: encoder-like locations (the tiled path) and
+    uniformly random ones (no locality at all: the per-corner path)."""
+    rng = np.random.default_rng(21)
+    c = _full_size_case(1, 22223, 13)
+    if kind == "encoder":
+        c["loc"] = _encoder_like_loc(1, DETR_SHAPES, rng)
+    c["grad_out"] = rng.standard_normal((1, 22223, 256)).astype(np.float32)
+    gv, gl, ga = (x.cpu().numpy() for x in hip_backward(c, torch.float32))
+    rgv, rgl, rga = O.msda_backward(c["value"].astype(np.float64), c["shapes"], c["level_start"], c["loc"].astype(np.float64),
+                                    c["attn"].astype(np.float64), c["grad_out"].astype(np.float64))
+    assert np.abs(gv - rgv).max() <= 2e-4 * max(1.0, np.abs(rgv).max())   # sums of up to hundreds of fp32 terms per pixel
+    assert np.abs(ga - rga).max() <= 1e-4
+    assert np.abs(gl - rgl).max() <= 2e-5 * max(1.0, np.abs(rgl).max())
+
+
+def test_backward_is_linear_in_grad_out_at_batch4():
+    """Config-4 per-GPU batch (N = 4): grad(2 g1 + g2) == 2 grad(g1) + grad(g2) on all three gradients."""
+    rng = np.random.default_rng(22)
+    c = _full_size_case(4, 22223, 14)
+    c["loc"] = _encoder_like_loc(4, DETR_SHAPES, rng)
+    sh, st = dev(c["shapes"]), dev(c["level_start"])
+    v, loc, attn = dev(c["value"]), dev(c["loc"]), dev(c["attn"])
+    g1 = torch.randn(4, 22223, 256, device=DEV)
+    g2 = torch.randn(4, 22223, 256, device=DEV)
+    a = alo_hip.msda_backward(v, sh, st, loc, attn, g1, 64)
+    b = alo_hip.msda_backward(v, sh, st, loc, attn, g2, 64)
+    ab = alo_hip.msda_backward(v, sh, st, loc, attn, 2 * g1 + g2, 64)
+    for x, y, z in zip(a, b, ab):
+        assert (z - (2 * x + y)).abs().max().item() <= 1e-3 * max(1.0, z.abs().max().item())
