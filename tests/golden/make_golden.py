@@ -25,6 +25,8 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
   g8_known_answers.npz   hand-checkable micro cases (pixel-centre sample, corner sample)
   g10_detr_transformer.npz   the reference's vanilla DETR Transformer (2 enc + 2 dec layers, d_model 64), fp64
   g11_panoptic_nn.npz    MHAttentionMap + FPNstyleCNN of the reference's PanopticHead (fp64)
+  g12_deformable_transformer_d256.npz   DeformableTransformer at the DETR-family width (d_model 256, 8 heads, 4 levels,
+                         4 points, 1 + 1 layers), fp64 run stored as fp32: pins the bf16 inference fast path
   g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
@@ -295,6 +297,41 @@ def g5(ref):
     np.savez_compressed(os.path.join(OUT, "g5_deformable_transformer.npz"), **save)
 
 
+def g12(ref):
+    """DeformableTransformer at the DETR-family width (d_model 256, 8 heads of 32 channels, 4 levels, 4 points; 1 encoder +
+    1 decoder layer, ffn 1024): the shape the bf16 inference fast path of this repository is specialised for.  Inputs are
+    float32-representable (stored as float32), the reference runs them in fp64."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from helpers import formula_state_dict
+
+    DT = importlib.import_module("alonet.deformable_detr.deformable_transformer")
+    torch.manual_seed(1212)
+    d_model, nhead, L = 256, 8, 4
+    tr = DT.DeformableTransformer(d_model=d_model, nhead=nhead, num_encoder_layers=1, num_decoder_layers=1,
+                                  dim_feedforward=1024, dropout=0.0, return_intermediate_dec=True,
+                                  num_feature_levels=L, dec_n_points=4, enc_n_points=4).double().eval()
+    tr.load_state_dict(formula_state_dict(tr.state_dict()))
+    B, sizes = 2, [(12, 16), (6, 8), (3, 4), (2, 2)]
+    srcs = [torch.randn(B, d_model, h, w).double() for h, w in sizes]
+    poss = [(torch.randn(B, d_model, h, w) * 0.5).double() for h, w in sizes]
+    masks = []
+    for h, w in sizes:  # image 1 is padded on its right/bottom quarter
+        m = torch.zeros(B, h, w, dtype=torch.bool)
+        m[1, :, w - max(1, w // 4):] = True
+        m[1, h - max(1, h // 4):, :] = True
+        masks.append(m)
+    query_embed = torch.randn(20, 2 * d_model).double()
+    with torch.no_grad():
+        out = tr(srcs, masks, poss, query_embed, is_tracing=None)
+    f32 = lambda x: _np(x).astype(np.float32)  # noqa: E731
+    save = dict(cfg=np.array([d_model, nhead, 1, 1, 1024, L, 4, 4]), query_embed=f32(query_embed),
+                hs=f32(out["hs"]), inter_references_out=f32(out["inter_references_out"]))
+    for i in range(L):
+        save[f"src{i}"], save[f"pos{i}"], save[f"mask{i}"] = f32(srcs[i]), f32(poss[i]), _np(masks[i])
+        save[f"memory{i}"] = f32(out["memory"][i])
+    np.savez_compressed(os.path.join(OUT, "g12_deformable_transformer_d256.npz"), **save)
+
+
 def g7(ref):
     """Full RAFT forward (reference model, formula weights), 128x160 pair, 4 iterations, fp32 on CPU.
 
@@ -387,7 +424,9 @@ def main():
         sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
     torch.set_num_threads(4)
     ref = load_reference()
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12)
+            if len(sys.argv) == 1 or fn.__name__ in sys.argv[1:]]   # `make_golden.py g12` regenerates one fixture
+    for fn in todo:
         fn(ref)
         print("wrote", fn.__name__)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))

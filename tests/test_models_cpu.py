@@ -5,6 +5,7 @@ own explicit escape hatches: ``is_tracing`` (pure-torch MSDA branch) and RAFT's 
 torch CorrBlock).  What is pinned is everything AROUND the kernels: module wiring, parameter names, arithmetic.
 """
 import numpy as np
+import pytest
 import torch
 
 import aloscene
@@ -36,19 +37,23 @@ def build_g5_transformer(g):
     return tr, L
 
 
-def test_deformable_transformer_graph_matches_reference(golden):
-    g = golden("g5_deformable_transformer.npz")
+@pytest.mark.parametrize("fixture", ["g5_deformable_transformer.npz", "g12_deformable_transformer_d256.npz"])
+def test_deformable_transformer_graph_matches_reference(golden, fixture):
+    g = golden(fixture)
     tr, L = build_g5_transformer(g)
-    srcs = [t(g[f"src{i}"]) for i in range(L)]
-    poss = [t(g[f"pos{i}"]) for i in range(L)]
+    srcs = [t(g[f"src{i}"]).double() for i in range(L)]
+    poss = [t(g[f"pos{i}"]).double() for i in range(L)]
     masks = [t(g[f"mask{i}"]) for i in range(L)]
     with torch.no_grad():
-        out = tr(srcs, masks, poss, t(g["query_embed"]), is_tracing=None)
-    np.testing.assert_allclose(out["hs"].numpy(), g["hs"], rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(out["inter_references_out"].numpy(), g["inter_references_out"], rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(out["init_reference_out"].numpy(), g["init_reference_out"], rtol=1e-9, atol=1e-10)
+        out = tr(srcs, masks, poss, t(g["query_embed"]).double(), is_tracing=None)
+    # G5 is stored in float64; G12 (the DETR-family width) holds the reference's fp64 outputs rounded to float32
+    tol = dict(rtol=1e-9, atol=1e-10) if g["hs"].dtype == np.float64 else dict(rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["hs"].numpy(), g["hs"], **tol)
+    np.testing.assert_allclose(out["inter_references_out"].numpy(), g["inter_references_out"], **tol)
+    if "init_reference_out" in g.files:
+        np.testing.assert_allclose(out["init_reference_out"].numpy(), g["init_reference_out"], **tol)
     for i in range(L):
-        np.testing.assert_allclose(out["memory"][i].numpy(), g[f"memory{i}"], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(out["memory"][i].numpy(), g[f"memory{i}"], **tol)
 
 
 def test_raft_graph_matches_reference(golden):
