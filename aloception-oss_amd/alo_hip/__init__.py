@@ -48,6 +48,8 @@ def _declare(lib):
     lib.alo_msda_forward_fused.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_msda_backward.restype = ip
     lib.alo_msda_backward.argtypes = [vp] * 9 + [ip] * 9 + [vp]
+    lib.alo_msda_backward_hinted.restype = ip
+    lib.alo_msda_backward_hinted.argtypes = [vp] * 9 + [ip] * 9 + [c.POINTER(c.c_int32), vp]
     lib.alo_corr_level_shape.restype = None
     lib.alo_corr_level_shape.argtypes = [ip, ip, ip, c.POINTER(ip), c.POINTER(ip)]
     lib.alo_corr_build_workspace_bytes.restype = sz
@@ -393,6 +395,24 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     return out
 
 
+_HOST_SHAPES = {}
+
+
+def _host_spatial_shapes(spatial_shapes):
+    """Host copy of a device ``spatial_shapes`` tensor: the ``_alo_shapes`` attribute DeformableTransformer attaches, else one
+    device-to-host read per distinct tensor (cached on storage pointer + version; the geometry tensors live as long as the
+    model does)."""
+    host = getattr(spatial_shapes, "_alo_shapes", None)
+    if host is not None:
+        return host
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(spatial_shapes.shape))
+    if key not in _HOST_SHAPES:
+        if len(_HOST_SHAPES) > 64:
+            _HOST_SHAPES.clear()
+        _HOST_SHAPES[key] = [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
+    return _HOST_SHAPES[key]
+
+
 def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight].  Replaces ``alonet_custom::ms_deform_attn_backward``."""
     dims, vdt, ldt, loc, attn = _msda_prepare(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
@@ -405,10 +425,16 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
     grad_loc = torch.empty(loc.shape, dtype=gdt, device=value.device)
     grad_attn = torch.empty(attn.shape, dtype=gdt, device=value.device)
     nbytes = msda_backward_bytes(N, S, M, D, L, Lq, P, value.element_size(), loc.element_size())
-    with torch.cuda.device(value.device), _timed(f"msda_bwd/Lq={Lq}", nbytes):
-        _check(lib().alo_msda_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
-                                       _ptr(grad_output), _ptr(grad_value), _ptr(grad_loc), _ptr(grad_attn),
-                                       N, S, M, D, L, Lq, P, vdt, ldt, _stream(value.device)))
+    host = _host_spatial_shapes(spatial_shapes) if Lq == S else None   # only the encoder's self-attention can use the hint
+    hint = None if host is None else (ctypes.c_int32 * (2 * L))(*[int(v) for hw in host for v in hw])
+
+    def launch():
+        _check(lib().alo_msda_backward_hinted(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(loc), _ptr(attn),
+                                              _ptr(grad_output), _ptr(grad_value), _ptr(grad_loc), _ptr(grad_attn),
+                                              N, S, M, D, L, Lq, P, vdt, ldt, hint, _stream(value.device)))
+
+    with torch.cuda.device(value.device), _timed(f"msda_bwd/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
+        launch()
     return [grad_value.to(value.dtype), grad_loc.to(sampling_loc.dtype), grad_attn.to(attn_weight.dtype)]
 
 

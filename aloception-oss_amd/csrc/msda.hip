@@ -743,6 +743,516 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// backward, fp32, D = 32, L = P = 4 (the DETR-family shape): tiled, window-dense, on the matrix cores.
+//
+// msda_bwd_kernel above scatters one 128-byte atomic row per (query, head, point, corner): 45.5 M rows per encoder-size
+// call, and the memory-side atomic units retire ~16 G rows/s — 2.9 of its 4.1 ms.  Queries that are neighbours in the image
+// sample overlapping pixels, so the sums can be formed on chip first.  Here a workgroup owns a SUPER-TILE of up to 64 queries
+// (an 8x8 block of one pyramid level when the queries are the pyramid's own pixels, Lq == S; 64 consecutive queries
+// otherwise) of ONE head; each of its 4 waves owns a sub-tile of 16 queries (a 4x4 quadrant):
+//   1. lane (query i, level l) turns its 4 sampling points into taps; the wave reduces the per-level bounding box of all its
+//      taps (the WINDOW) and writes the scalar weights w_corner * attn into a dense matrix A[window pixel][16 queries] in LDS:
+//      plain read-add-write, no LDS atomics — lane (i, l) is the only writer of column i of level l's rows.
+//   2. grad_value of the window is the dense product  dV[pixel][ch] = sum_q A[pixel][q] * grad_out[q][ch].  The windows of the
+//      4 sub-tiles overlap: the workgroup walks the rows of their common bounding box once, the 32-row blocks dealt round-robin
+//      to the waves, summing all four sub-tiles' contributions in the accumulators — ONE atomic row per touched pixel per
+//      super-tile (about 1/20 of the per-corner count).
+//   3. the channel dot products every sample needs, d[pixel][q] = <value[pixel], grad_out[q]>, are the transposed dense
+//      product over the same window, the value rows going from memory straight into the matrix operand; D lands in the wave's
+//      LDS region in place of A and lane (i, l) picks its 16 corner values from there:
+//      grad_attn = sum_k w_k d_k,  grad_loc = attn * (W, H) * (...).
+// Both products run on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split EXACTLY into three bf16 terms
+// (8 + 8 + 8 significant bits, x = hi + mid + lo) and the six largest of the nine cross products are accumulated in fp32
+// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; the dropped ones are below 2^-24 relative) — 6 instructions of K = 16 / 32
+// take 192 / 96 cycles where the exact-fp32 MFMA forms (K = 2 / 4 per instruction) take 512 / 256.
+// The wave's LDS region holds 312 window pixels; the levels are made resident in up to two passes.  A level whose window does
+// not fit (queries of a coarse level looking at a fine one, decoder queries, arbitrary locations) takes the per-corner route of
+// msda_bwd_kernel for that level only: same results, old cost.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef ALO_EXP
+#define ALO_EXP 0
+#endif
+constexpr int kTileWaves = 4;
+constexpr int kPxBudget = 312;                      // window pixels per wave resident in LDS (64 B each): 2 workgroups / CU
+constexpr int kWaveRegion = kPxBudget * 64;         // bytes
+constexpr int kTileLds = kTileWaves * kWaveRegion + kTileWaves * 4 * 5 * 4 + 16;
+
+struct TileDims {
+    int S, M, Lq;
+    int pyramid;        // 1: Lq == S and the queries are tiled as 8x8 blocks of their level; 0: 64 consecutive queries
+    int n_super;        // super-tiles per batch item
+    int tile0[4];       // pyramid: first super-tile of each level
+    int tiles_w[4];     // pyramid: super-tiles per row of each level
+    unsigned nblocks;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
+    union { u32x4 u; bf16x8_t b; } x;
+    x.u = v;
+    return x.b;
+}
+// 8 fp32 values -> three packed bf16 operands with x = hi + mid + lo exactly (truncation splits, each remainder exact)
+struct Split3 { u32x4 hi, mid, lo; };
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = __float_as_uint(x[e]);
+        const float r1 = x[e] - __uint_as_float(h[e] & 0xffff0000u);
+        m[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
+        l[e] = __float_as_uint(r2);
+    }
+    Split3 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o.hi[i] = __builtin_amdgcn_perm(h[2 * i + 1], h[2 * i], 0x07060302u);
+        o.mid[i] = __builtin_amdgcn_perm(m[2 * i + 1], m[2 * i], 0x07060302u);
+        o.lo[i] = __builtin_amdgcn_perm(l[2 * i + 1], l[2 * i], 0x07060302u);
+    }
+    return o;
+}
+// acc += A * B in fp32 accuracy from the split operands: small cross terms first
+__device__ __forceinline__ f32x16 mfma_split_32(const Split3& a, const Split3& b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.lo), as_bf16x8(b.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.hi), as_bf16x8(b.lo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.mid), as_bf16x8(b.mid), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.mid), as_bf16x8(b.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.hi), as_bf16x8(b.mid), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.hi), as_bf16x8(b.hi), acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f32x4 mfma_split_16(const Split3& a, const Split3& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.lo), as_bf16x8(b.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.hi), as_bf16x8(b.lo), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.mid), as_bf16x8(b.mid), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.mid), as_bf16x8(b.hi), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.hi), as_bf16x8(b.mid), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.hi), as_bf16x8(b.hi), acc, 0, 0, 0);
+    return acc;
+}
+
+// All-reduce of a packed (x, y) pair of int16 over the 16 lanes that share (lane & 3): two DPP row rotations, two shuffles.
+template <bool MIN>
+__device__ __forceinline__ int same_level_pk(int v) {
+    auto op = [](int a, int b) {
+        const s16x2 x = __builtin_bit_cast(s16x2, a), y = __builtin_bit_cast(s16x2, b);
+        return __builtin_bit_cast(int, MIN ? __builtin_elementwise_min(x, y) : __builtin_elementwise_max(x, y));
+    };
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    v = op(v, __shfl_xor(v, 16, 64));
+    v = op(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float half_wave_sum(float v) {   // sum over each 32-lane half; valid in lanes 16-31 / 48-63
+    v = row16_sum(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+    return v;
+}
+
+__global__ void __launch_bounds__(256, 2)
+msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
+                      const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
+                      float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
+                      const TileDims td) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float* region = reinterpret_cast<float*>(smem + wave * kWaveRegion);
+    int* table = reinterpret_cast<int*>(smem + kTileWaves * kWaveRegion);   // [wave][level]{x0, y0, ww, wh, off}; ww = 0: not resident
+    int* npass_slot = table + kTileWaves * 4 * 5;                           // [wave] passes this wave needs
+
+    const unsigned lb = xcd_contiguous_block(blockIdx.x, td.nblocks);
+    const int m = lb % td.M;
+    // super-tiles in reverse order: those of the coarse levels (whose queries look at wide windows of the fine levels and take
+    // the per-corner route there) start first and overlap the many light ones instead of forming the tail
+    const int st = td.n_super - 1 - (int)((lb / td.M) % td.n_super);
+    const int b = lb / (td.M * td.n_super);
+    const int M = td.M, S = td.S, Lq = td.Lq;
+
+    // ---- which queries --------------------------------------------------------------------------------------------------
+    int lq = 0;
+    if (td.pyramid) {
+#pragma unroll
+        for (int l = 1; l < 4; ++l)
+            if (st >= td.tile0[l]) lq = l;
+    }
+    const int trow = td.pyramid ? (st - td.tile0[lq]) / td.tiles_w[lq] : 0;
+    const int tcol = td.pyramid ? (st - td.tile0[lq]) - trow * td.tiles_w[lq] : 0;
+    const int Hq = shapes[2 * lq], Wq = shapes[2 * lq + 1], Sq = lstart[lq];
+    auto query_of = [&](int j, int i) -> int {   // sub-tile j, slot i -> query index, -1 past the edge
+        if (td.pyramid) {
+            const int qy = trow * 8 + (j >> 1) * 4 + (i >> 2), qx = tcol * 8 + (j & 1) * 4 + (i & 3);
+            return (qy < Hq && qx < Wq) ? Sq + qy * Wq + qx : -1;
+        }
+        const int q = st * 64 + j * 16 + i;
+        return q < Lq ? q : -1;
+    };
+    const long bq0 = (long)b * Lq;
+
+    // grad_out rows of all four sub-tiles as B operands of the 32x32x16 product: lane (kg = lane >> 5, ch = lane & 31) holds
+    // G_j[8 kg + s][ch], s = 0..7.  Issued first: their latency hides behind stage 1.
+    float Graw[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int q = query_of(j, 8 * (lane >> 5) + s);
+            Graw[j][s] = q >= 0 ? grad_out[((bq0 + q) * M + m) * 32 + (lane & 31)] : 0.f;
+        }
+
+    // ---- stage 1: taps and windows ------------------------------------------------------------------------------------------
+    const int qi = lane >> 2, lev = lane & 3;
+    const int q_own = query_of(wave, qi);
+    const bool live = q_own >= 0;
+    const int Hl = shapes[2 * lev], Wl = shapes[2 * lev + 1];
+    const long qm = (bq0 + (live ? q_own : 0)) * M + m;
+    float lh[4], lw[4], at[4];
+    int h_low[4], w_low[4];
+    unsigned flags[4];   // bit k: corner k is inside the map; bit 4: the sample is valid (cuh:285-291, :38-78)
+    {
+        const float* lp = loc + (qm * 4 + lev) * 8;
+        const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp), l1 = *reinterpret_cast<const f32x4*>(lp + 4);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(attn + (qm * 4 + lev) * 4);
+        const float xs[4] = {l0[0], l0[2], l1[0], l1[2]}, ys[4] = {l0[1], l0[3], l1[1], l1[3]};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float h_im = ys[p] * (float)Hl - 0.5f, w_im = xs[p] * (float)Wl - 0.5f;
+            const bool valid = live && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
+            const float hs = valid ? h_im : 0.f, ws = valid ? w_im : 0.f;
+            const float hf = floorf(hs), wf = floorf(ws);
+            h_low[p] = (int)hf;
+            w_low[p] = (int)wf;
+            lh[p] = hs - hf;
+            lw[p] = ws - wf;
+            at[p] = av[p];
+            const bool hl = h_low[p] >= 0, hh = h_low[p] + 1 <= Hl - 1, wl = w_low[p] >= 0, wh = w_low[p] + 1 <= Wl - 1;
+            flags[p] = valid ? ((hl && wl ? 1u : 0u) | (hl && wh ? 2u : 0u) | (hh && wl ? 4u : 0u) | (hh && wh ? 8u : 0u) | 16u) : 0u;
+        }
+    }
+    const bool small_map = Hl < 32768 && Wl < 32768;   // window coordinates travel as packed int16
+    int x0 = 32767, x1 = -32768, y0 = 32767, y1 = -32768;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if ((flags[p] & 16u) && small_map) {   // a valid sample has w_low in [-1, W-1]: a column (row) of its footprint is inside
+            x0 = min(x0, max(w_low[p], 0));
+            x1 = max(x1, min(w_low[p] + 1, Wl - 1));
+            y0 = min(y0, max(h_low[p], 0));
+            y1 = max(y1, min(h_low[p] + 1, Hl - 1));
+        }
+    {
+        const int lo = same_level_pk<true>((x0 & 0xffff) | (y0 << 16));
+        const int hi = same_level_pk<false>((x1 & 0xffff) | (y1 << 16));
+        x0 = (int)(short)(lo & 0xffff); y0 = lo >> 16;
+        x1 = (int)(short)(hi & 0xffff); y1 = hi >> 16;
+    }
+    const int ww = x1 >= x0 ? x1 - x0 + 1 : 0, wh = x1 >= x0 ? y1 - y0 + 1 : 0;
+    // a level without a window: no valid sample (nothing to do) or a map too large for the packed coordinates (per-corner route)
+    const long np_l = (long)ww * wh;
+    int vmask = (int)((flags[0] | flags[1] | flags[2] | flags[3]) >> 4);   // any valid sample on this level in the sub-tile?
+    vmask |= __builtin_amdgcn_update_dpp(0, vmask, 0x124, 0xf, 0xf, false);
+    vmask |= __builtin_amdgcn_update_dpp(0, vmask, 0x128, 0xf, 0xf, false);
+    vmask |= __shfl_xor(vmask, 16, 64);
+    vmask |= __shfl_xor(vmask, 32, 64);
+    const int np_own = (np_l > kPxBudget || (vmask && !small_map)) ? kPxBudget + 1 : (int)np_l;
+    // residency plan: levels in order, up to two passes over the wave's region (wave-uniform)
+    int np4[4], off4[4], pass4[4];   // pass4: 0 / 1 = resident in that pass, 2 = per-corner route, 3 = nothing to do
+    {
+        int used = 0, pass = 0;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            np4[l] = __builtin_amdgcn_readlane(np_own, l);
+            if (np4[l] == 0) { pass4[l] = 3; off4[l] = 0; continue; }
+            if (np4[l] > kPxBudget) { pass4[l] = 2; off4[l] = 0; continue; }
+            if (used + np4[l] > kPxBudget && pass == 0) { pass = 1; used = 0; }
+            if (used + np4[l] <= kPxBudget) { pass4[l] = pass; off4[l] = used; used += np4[l]; }
+            else { pass4[l] = 2; off4[l] = 0; }
+        }
+    }
+    const int my_pass = lev == 0 ? pass4[0] : (lev == 1 ? pass4[1] : (lev == 2 ? pass4[2] : pass4[3]));
+    const int off = lev == 0 ? off4[0] : (lev == 1 ? off4[1] : (lev == 2 ? off4[2] : off4[3]));
+    const bool two = pass4[0] == 1 || pass4[1] == 1 || pass4[2] == 1 || pass4[3] == 1;
+    const bool any_corner_route = pass4[0] == 2 || pass4[1] == 2 || pass4[2] == 2 || pass4[3] == 2;
+    if (lane == 0) npass_slot[wave] = two ? 2 : 1;
+    int base[4];   // window row of the (h_low, w_low) corner; the others are +1, +ww, +ww+1
+#pragma unroll
+    for (int p = 0; p < 4; ++p) base[p] = (h_low[p] - y0) * ww + (w_low[p] - x0);
+
+    // split grad_out operands (B of stage 2)
+    Split3 Gs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Gs[j] = split3(Graw[j]);
+    // own grad_out rows as the B operand of stage 3: lane (kg = lane >> 4, q = lane & 15) holds g[q][8 kg .. 8 kg + 7]
+    Split3 Gown;
+    {
+        const int qb = query_of(wave, lane & 15);
+        float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (qb >= 0) {
+            const float* gp = grad_out + ((bq0 + qb) * M + m) * 32 + 8 * (lane >> 4);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gp), c = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g8[e] = a[e]; g8[4 + e] = c[e]; }
+        }
+        Gown = split3(g8);
+    }
+
+    float* gv_b = grad_value + (size_t)b * S * M * 32 + m * 32 + (lane & 31);
+    const float* vb3 = value + (size_t)b * S * M * 32 + m * 32 + 8 * (lane >> 4);
+    int npass = 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        // ---- stage 1b: A of this pass's levels -------------------------------------------------------------------------------
+        const bool mine = my_pass == pass;
+        if (lane < 4) {
+            int* t = table + (wave * 4 + lane) * 5;
+            t[0] = x0; t[1] = y0; t[2] = mine ? ww : 0; t[3] = wh; t[4] = off;
+        }
+        int used = 0;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (pass4[l] == pass) used = off4[l] + np4[l];
+        for (int o = lane * 4; o < used * 16; o += 256) *reinterpret_cast<f32x4*>(region + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (mine && (flags[p] & 16u)) {
+                const float hh = 1.f - lh[p], hw = 1.f - lw[p];
+                const float w4[4] = {hh * hw * at[p], hh * lw[p] * at[p], lh[p] * hw * at[p], lh[p] * lw[p] * at[p]};
+                const int idx[4] = {base[p], base[p] + 1, base[p] + ww, base[p] + ww + 1};
+                float cur[4];
+                // the 4 corners of one point are 4 different pixels: independent read-add-writes; the next point of this lane may
+                // hit the same entries and is ordered behind these by the wave's in-order LDS queue
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cur[k] = (flags[p] >> k) & 1u ? region[(off + idx[k]) * 16 + qi] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((flags[p] >> k) & 1u) region[(off + idx[k]) * 16 + qi] = cur[k] + w4[k];
+            }
+        }
+        __syncthreads();
+        if (pass == 0) npass = max(max(npass_slot[0], npass_slot[1]), max(npass_slot[2], npass_slot[3]));
+        npass = __builtin_amdgcn_readfirstlane(npass);
+
+        // ---- stage 2: grad_value over the windows -------------------------------------------------------------------------------
+        int deal = 0;   // 32-row blocks of merged walks are dealt round-robin to the waves across all levels
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+            int X0[4], Y0[4], WW[4], WH[4], OF[4];
+            int sx0 = 0x7fffffff, sy0 = 0x7fffffff, sx1 = -0x7fffffff, sy1 = -0x7fffffff, sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int* t = table + (j * 4 + lv) * 5;
+                X0[j] = __builtin_amdgcn_readfirstlane(t[0]);
+                Y0[j] = __builtin_amdgcn_readfirstlane(t[1]);
+                WW[j] = __builtin_amdgcn_readfirstlane(t[2]);
+                WH[j] = __builtin_amdgcn_readfirstlane(t[3]);
+                OF[j] = __builtin_amdgcn_readfirstlane(t[4]);
+                if (WW[j]) {
+                    sx0 = min(sx0, X0[j]); sy0 = min(sy0, Y0[j]);
+                    sx1 = max(sx1, X0[j] + WW[j] - 1); sy1 = max(sy1, Y0[j] + WH[j] - 1);
+                    sum += WW[j] * WH[j];
+                }
+            }
+            if (sum == 0 || (ALO_EXP & 4)) continue;
+            // windows that overlap or abut share one walk over their common bounding box (every sub-tile contributing to a block);
+            // windows far apart (no locality between the sub-tiles) are walked one per wave
+            const long sbox = (long)(sx1 - sx0 + 1) * (sy1 - sy0 + 1);
+            const bool merged = sbox <= 2L * sum;
+            const int own_w = wave == 0 ? WW[0] : (wave == 1 ? WW[1] : (wave == 2 ? WW[2] : WW[3]));
+            const int own_h = wave == 0 ? WH[0] : (wave == 1 ? WH[1] : (wave == 2 ? WH[2] : WH[3]));
+            const int own_x = wave == 0 ? X0[0] : (wave == 1 ? X0[1] : (wave == 2 ? X0[2] : X0[3]));
+            const int own_y = wave == 0 ? Y0[0] : (wave == 1 ? Y0[1] : (wave == 2 ? Y0[2] : Y0[3]));
+            const int rx0 = merged ? sx0 : own_x, ry0 = merged ? sy0 : own_y;
+            const int rw = merged ? sx1 - sx0 + 1 : own_w, rh = merged ? sy1 - sy0 + 1 : own_h;
+            const int nrows = __builtin_amdgcn_readfirstlane(rw * rh);
+            const int nblk = (nrows + 31) >> 5;
+            // merged: this wave takes the blocks whose deal number is its own
+            const int first = merged ? ((wave - deal) & 3) : 0, step = merged ? kTileWaves : 1;
+            if (merged) deal += nblk;
+            const int Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
+            for (int blk = __builtin_amdgcn_readfirstlane(first); blk < nblk; blk += step) {
+                const int r = blk * 32 + (lane & 31);
+                const bool rin = r < nrows;
+                const int ry = rin ? r / rw : 0, rx = rin ? r - ry * rw : 0;
+                const int gx = rx0 + rx, gy = ry0 + ry;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!WW[j] || !(merged || j == wave)) continue;   // wave-uniform
+                    const int wx = gx - X0[j], wy = gy - Y0[j];
+                    const bool in = rin && wx >= 0 && wx < WW[j] && wy >= 0 && wy < WH[j];
+                    if (__ballot(in) == 0) continue;                  // wave-uniform
+                    any = true;
+                    const float* ap = reinterpret_cast<const float*>(smem + j * kWaveRegion) + (OF[j] + wy * WW[j] + wx) * 16 + 8 * (lane >> 5);
+                    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (in) {
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a8[e] = a0[e]; a8[4 + e] = a1[e]; }
+                    }
+                    acc = mfma_split_32(split3(a8), Gs[j], acc);
+                }
+                if (!any) continue;
+                // C/D layout: col = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): one atomic instruction =
+                // two whole 128-byte rows; rows nothing was scattered to hold exact zeros and are skipped
+                const int pix = rin ? Slv + gy * Wlv + gx : -1;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const int pr = __shfl(pix, rr, 64);
+#if !(ALO_EXP & 2)
+                    if (pr >= 0 && acc[reg] != 0.f) unsafeAtomicAdd(gv_b + (size_t)pr * M * 32, acc[reg]);
+#else
+                    if (pr >= 0 && acc[reg] == 123.456f) unsafeAtomicAdd(gv_b + (size_t)pr * M * 32, acc[reg]);
+#endif
+                }
+            }
+        }
+        __syncthreads();   // every wave is done reading every A: the regions are re-used for D
+
+        // ---- stage 3: d[pixel][q] = <value[pixel], grad_out[q]> over the own windows, then the per-sample gradients -----------------
+#pragma unroll
+        for (int lv = 0; lv < 4; ++lv) {
+            if (pass4[lv] != pass || (ALO_EXP & 8)) continue;   // wave-uniform
+            const int wx0 = __builtin_amdgcn_readlane(x0, lv), wy0 = __builtin_amdgcn_readlane(y0, lv);
+            const int wwl = __builtin_amdgcn_readlane(ww, lv);
+            const int nrows = np4[lv], offl = off4[lv];
+            const int nblk = (nrows + 15) >> 4;
+            const int Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
+            // value rows go from memory straight into the A operand: lane (row = lane & 15, kg = lane >> 4) takes channels
+            // 8 kg .. 8 kg + 7 of its row (32 contiguous bytes); the next block's rows are in flight during this block's product
+            auto fetch = [&](int blk, f32x4& v0, f32x4& v1) {
+                const int r = blk * 16 + (lane & 15);
+                const bool rin = r < nrows;
+                const int ry = rin ? r / wwl : 0, rx = rin ? r - ry * wwl : 0;
+                const float* vp = vb3 + (size_t)(Slv + (wy0 + ry) * Wlv + wx0 + rx) * M * 32;
+                v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0;
+                if (rin) { v0 = *reinterpret_cast<const f32x4*>(vp); v1 = *reinterpret_cast<const f32x4*>(vp + 4); }
+            };
+            f32x4 n0, n1;
+            fetch(0, n0, n1);
+            for (int blk = 0; blk < nblk; ++blk) {
+                const f32x4 c0 = n0, c1 = n1;
+                if (blk + 1 < nblk) fetch(blk + 1, n0, n1);
+                const float v8[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                d = mfma_split_16(split3(v8), Gown, d);
+                // C/D layout: col = lane & 15 (query), row = 4 * (lane >> 4) + reg
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = blk * 16 + 4 * (lane >> 4) + reg;
+                    if (row < nrows) region[(offl + row) * 16 + (lane & 15)] = d[reg];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (mine && live) {
+            f32x4 ga, gl0, gl1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float gx = 0.f, gy = 0.f, gat = 0.f;
+                if (flags[p] & 16u) {
+                    const int idx[4] = {base[p], base[p] + 1, base[p] + ww, base[p] + ww + 1};
+                    float dk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dk[k] = (flags[p] >> k) & 1u ? region[(off + idx[k]) * 16 + qi] : 0.f;
+                    const float hh = 1.f - lh[p], hw = 1.f - lw[p];
+                    gat = hh * hw * dk[0] + hh * lw[p] * dk[1] + lh[p] * hw * dk[2] + lh[p] * lw[p] * dk[3];
+                    const float gww = -hh * dk[0] + hh * dk[1] - lh[p] * dk[2] + lh[p] * dk[3];
+                    const float ghw = -hw * dk[0] - lw[p] * dk[1] + hw * dk[2] + lw[p] * dk[3];
+                    gx = (float)Wl * gww * at[p];
+                    gy = (float)Hl * ghw * at[p];
+                }
+                ga[p] = gat;
+                if (p < 2) { gl0[2 * p] = gx; gl0[2 * p + 1] = gy; } else { gl1[2 * p - 4] = gx; gl1[2 * p - 3] = gy; }
+            }
+            float* glp = grad_loc + (qm * 4 + lev) * 8;
+            *reinterpret_cast<f32x4*>(glp) = gl0;
+            *reinterpret_cast<f32x4*>(glp + 4) = gl1;
+            *reinterpret_cast<f32x4*>(grad_attn + (qm * 4 + lev) * 4) = ga;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // levels with nothing to do (no valid sample of the sub-tile): their gradients are zero
+    if (my_pass == 3 && live) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        float* glp = grad_loc + (qm * 4 + lev) * 8;
+        *reinterpret_cast<f32x4*>(glp) = z;
+        *reinterpret_cast<f32x4*>(glp + 4) = z;
+        *reinterpret_cast<f32x4*>(grad_attn + (qm * 4 + lev) * 4) = z;
+    }
+
+    // ---- stage 4: levels that are not resident: one 128-byte row per corner, as msda_bwd_kernel does ---------------------------------
+    if (!any_corner_route || (ALO_EXP & 1)) return;   // wave-uniform
+    // sample descriptors through the wave's region (free now): 8 words per (level, point, query), read back as broadcasts
+    {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4* dst = reinterpret_cast<u32x4*>(region) + ((lev * 4 + p) * 16 + qi) * 2;
+            dst[0] = u32x4{flags[p], (unsigned)q_own, (unsigned)h_low[p], (unsigned)w_low[p]};
+            dst[1] = u32x4{__float_as_uint(lh[p]), __float_as_uint(lw[p]), __float_as_uint(at[p]), 0u};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv) {
+        if (pass4[lv] != 2) continue;   // wave-uniform
+        const int Hlv = shapes[2 * lv], Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
+        const int ch = lane & 31, half = lane >> 5;
+        const float* vb = value + (size_t)b * S * M * 32 + m * 32 + ch;
+        float* gvb = grad_value + (size_t)b * S * M * 32 + m * 32 + ch;
+#pragma unroll 2
+        for (int it = 0; it < 32; ++it) {   // 4 points x 16 queries, one sample per half-wave per step
+            const int p = it >> 3, i = 2 * (it & 7) + half;
+            const u32x4* src = reinterpret_cast<const u32x4*>(region) + ((lv * 4 + p) * 16 + i) * 2;
+            const u32x4 d0 = src[0], d1 = src[1];
+            const unsigned f = d0.x;
+            const int q = (int)d0.y, hl_ = (int)d0.z, wl_ = (int)d0.w;
+            const float lh_ = __uint_as_float(d1.x), lw_ = __uint_as_float(d1.y), at_ = __uint_as_float(d1.z);
+            float s_attn = 0.f, s_w = 0.f, s_h = 0.f;
+            if (f & 16u) {
+                const float top = grad_out[((bq0 + q) * M + m) * 32 + ch];
+                const float tgv = top * at_;
+                const float hh = 1.f - lh_, hw = 1.f - lw_;
+                const float w4[4] = {hh * hw, hh * lw_, lh_ * hw, lh_ * lw_};
+                const long pix0 = (long)Slv + (long)hl_ * Wlv + wl_;
+                const long px[4] = {pix0, pix0 + 1, pix0 + Wlv, pix0 + Wlv + 1};
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (f >> k) & 1u ? vb[(size_t)px[k] * M * 32] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((f >> k) & 1u) unsafeAtomicAdd(gvb + (size_t)px[k] * M * 32, w4[k] * tgv);
+                s_attn = top * (w4[0] * v[0] + w4[1] * v[1] + w4[2] * v[2] + w4[3] * v[3]);
+                s_w = tgv * (-hh * v[0] + hh * v[1] - lh_ * v[2] + lh_ * v[3]);
+                s_h = tgv * (-hw * v[0] - lw_ * v[1] + hw * v[2] + lw_ * v[3]);
+            }
+            s_attn = half_wave_sum(s_attn);
+            s_w = half_wave_sum(s_w);
+            s_h = half_wave_sum(s_h);
+            if (ch == 16 && q >= 0) {
+                const long g = (((bq0 + q) * M + m) * 4 + lv) * 4 + p;
+                grad_attn[g] = s_attn;
+                grad_loc[2 * g] = (float)Wlv * s_w;
+                grad_loc[2 * g + 1] = (float)Hlv * s_h;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------------------------
 struct Plan {
@@ -945,10 +1455,11 @@ extern "C" int alo_msda_forward_fused_hm_rows(const void* value_hm, const int32_
                         logits_row_elems);
 }
 
-extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                                 const void* sampling_loc, const void* attn_weight, const void* grad_out,
-                                 void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M,
-                                 int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
+namespace {
+int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                  const void* sampling_loc, const void* attn_weight, const void* grad_out, void* grad_value,
+                  void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
+                  int value_dtype, int loc_dtype, const int32_t* host_shapes, void* stream_) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, N, S, M, D, L, Lq, P,
                           value_dtype, loc_dtype, &elem))
@@ -960,6 +1471,48 @@ extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shape
     hipError_t e = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * gelem, stream);
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: memset: %s", hipGetErrorString(e));
     const bool aligned = (((uintptr_t)value | (uintptr_t)grad_out) & 15) == 0;
+    const bool all_aligned = aligned && (((uintptr_t)sampling_loc | (uintptr_t)attn_weight | (uintptr_t)grad_value |
+                                          (uintptr_t)grad_sampling_loc | (uintptr_t)grad_attn_weight) & 15) == 0;
+    if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && all_aligned && (double)S * M * 32 < 2.0e9) {
+        // the DETR-family shape: tiled, window-dense backward on the fp32 matrix cores (msda_bwd_tiled_kernel)
+        TileDims td;
+        td.S = S; td.M = M; td.Lq = Lq;
+        td.pyramid = 0;
+        td.n_super = (Lq + 63) / 64;
+        for (int l = 0; l < 4; ++l) { td.tile0[l] = 0; td.tiles_w[l] = 1; }
+        if (host_shapes && Lq == S) {
+            // queries = the pyramid's own pixels (encoder self-attention): 8x8 blocks of each level.  Only how queries are
+            // grouped depends on this; the kernel reads the geometry it computes with from the device copy.
+            long total = 0;
+            int tiles = 0;
+            bool ok = true;
+            for (int l = 0; l < 4; ++l) {
+                const int h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
+                ok = ok && h > 0 && w > 0;
+                td.tile0[l] = tiles;
+                td.tiles_w[l] = (w + 7) / 8;
+                tiles += ((h + 7) / 8) * ((w + 7) / 8);
+                total += (long)h * w;
+            }
+            if (ok && total == S) { td.pyramid = 1; td.n_super = tiles; }
+        }
+        const long nb = (long)N * td.n_super * M;
+        ALO_REQUIRE(nb < 0x7fffffffL, ALO_ERR_UNSUPPORTED, "alo_msda_backward: grid too large");
+        td.nblocks = (unsigned)nb;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_tiled_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds);
+            if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: %s", hipGetErrorString(ea));
+            attr_set = true;
+        }
+        void* targs[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &grad_out,
+                         &grad_value, &grad_sampling_loc, &grad_attn_weight, &td};
+        hipError_t el = hipLaunchKernel(reinterpret_cast<const void*>(msda_bwd_tiled_kernel), dim3(td.nblocks), dim3(256),
+                                        targs, kTileLds, stream);
+        if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: %s", hipGetErrorString(el));
+        return check_launch("alo_msda_backward");
+    }
     Plan plan = make_plan(D, L, P, elem, aligned);
     if (D <= 64) {
         // one channel per lane: each of the four atomics of a sampling point then covers D consecutive elements of ONE row
@@ -975,4 +1528,23 @@ extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shape
     if (value_dtype == ALO_F64) { ALO_ALL_CASES(ALO_BWD_CASE, double, double, double, 2) }
     if (value_dtype == ALO_BF16) { ALO_ALL_CASES(ALO_BWD_CASE, bf16_t, float, float, 8) }
     return fail(ALO_ERR_UNSUPPORTED, "alo_msda_backward: no kernel for vec=%d group=%d", plan.vec, plan.g);
+}
+}  // namespace
+
+extern "C" int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                 const void* sampling_loc, const void* attn_weight, const void* grad_out,
+                                 void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M,
+                                 int D, int L, int Lq, int P, int value_dtype, int loc_dtype, void* stream_) {
+    return backward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
+                         grad_sampling_loc, grad_attn_weight, N, S, M, D, L, Lq, P, value_dtype, loc_dtype, nullptr, stream_);
+}
+
+extern "C" int alo_msda_backward_hinted(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                                        const void* sampling_loc, const void* attn_weight, const void* grad_out,
+                                        void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, int N, int S,
+                                        int M, int D, int L, int Lq, int P, int value_dtype, int loc_dtype,
+                                        const int32_t* host_spatial_shapes, void* stream_) {
+    return backward_impl(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
+                         grad_sampling_loc, grad_attn_weight, N, S, M, D, L, Lq, P, value_dtype, loc_dtype,
+                         host_spatial_shapes, stream_);
 }

@@ -149,6 +149,20 @@ int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const in
                       int N, int S, int M, int D, int L, int Lq, int P,
                       int value_dtype, int loc_dtype, void* stream);
 
+/*
+ * The same operation with a scheduling hint: `host_spatial_shapes` is a HOST copy of spatial_shapes (L x 2 int32, may be NULL).
+ * When the queries are the pyramid's own pixels (Lq == S, the encoder's self-attention) the fp32 D = 32, L = P = 4 kernel
+ * then groups them as 8x8 blocks of their level instead of runs of 64 consecutive queries, so that the sampling windows of
+ * a workgroup's queries overlap as much as possible (one atomic row per touched pixel per block).  Results do not depend on
+ * the hint (up to the order of the floating-point additions, which atomics leave undefined anyway); alo_msda_backward is this
+ * call with a NULL hint.
+ */
+int alo_msda_backward_hinted(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
+                             const void* sampling_loc, const void* attn_weight, const void* grad_out,
+                             void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
+                             int N, int S, int M, int D, int L, int Lq, int P,
+                             int value_dtype, int loc_dtype, const int32_t* host_spatial_shapes, void* stream);
+
 /* Size of level l of the correlation pyramid of an (H, W) feature grid: level 0 = (H, W), level l+1 = floor(level l / 2)
  * (F.avg_pool2d(2, stride=2), corr.py:25-27). */
 void alo_corr_level_shape(int H, int W, int level, int* h_out, int* w_out);

@@ -85,6 +85,8 @@ CASES = [  # (N, M, D, Lq, shapes, P)          which plan it exercises (fp32)
     (2, 2, 71, 11, [(6, 4), (3, 2)], 2),  # scalar path, two chunks
     (1, 2, 2, 2, [(6, 4), (3, 2)], 2),  # scalar path, group 8 (the reference test's D)
     (1, 2, 8, 13, [(7, 3)], 1),  # vec4 / group 4, L*P = 1
+    (2, 8, 32, 454, [(16, 21), (8, 11), (4, 6), (2, 3)], 4),  # Lq == S: the tiled backward groups queries as 8x8 blocks
+    (1, 4, 32, 130, [(9, 13), (5, 7), (3, 4), (2, 2)], 4),  # tiled backward, 64-query runs with a ragged tail, 4 heads
 ]
 
 
@@ -433,6 +435,15 @@ def test_bench_kernel_direct_vs_oracle_full_size_batch8():
 
 
 # ---- backward at the config-4 encoder size -------------------------------------------------------------------------------
+def _away_from_pixel_edges(loc, shapes_l, eps=1e-3):
+    """grad_sampling_loc is the derivative of a piecewise-bilinear function: it JUMPS where a coordinate crosses an integer.
+    A sample within fp32 rounding of such an edge may legitimately take either side (fp32 vs fp64 evaluation of loc * size - 0.5,
+    fused or unfused): mask those samples out of the grad_loc comparison.  (N, Lq, M, L, P, 1) bool."""
+    size = np.array([[w, h] for h, w in shapes_l], np.float64)[None, None, None, :, None, :]
+    im = loc.astype(np.float64) * size - 0.5
+    return (np.abs(im - np.round(im)) > eps).all(-1, keepdims=True)
+
+
 def _encoder_like_loc(N, shapes_l, rng, spread_px=4.0):
     """Sampling locations of an encoder call: every query is a pixel of the pyramid, its points lie within a few pixels of
     its own position on every level (N, S, 8, 4, 4, 2)."""
@@ -461,7 +472,34 @@ def test_full_size_backward_vs_oracle(kind):
                                     c["attn"].astype(np.float64), c["grad_out"].astype(np.float64))
     assert np.abs(gv - rgv).max() <= 2e-4 * max(1.0, np.abs(rgv).max())   # sums of up to hundreds of fp32 terms per pixel
     assert np.abs(ga - rga).max() <= 1e-4 * max(1.0, np.abs(rga).max())   # 32-term fp32 dot products of O(1) values
-    assert np.abs(gl - rgl).max() <= 1e-4 * max(1.0, np.abs(rgl).max())
+    ok = _away_from_pixel_edges(c["loc"], DETR_SHAPES)
+    assert ok.mean() > 0.99 and np.abs((gl - rgl) * ok).max() <= 1e-4 * max(1.0, np.abs(rgl).max())
+
+
+@pytest.mark.parametrize("spread", [1.5, 6.0, 40.0])
+def test_tiled_backward_on_encoder_like_locations(spread):
+    """The window-dense route of the tiled fp32 backward (Lq == S, taps within `spread` pixels of the query's own position on
+    every level: windows resident in LDS for small spreads, per-corner route for the levels whose window outgrows it), incl.
+    taps off the border and queries whose whole window is outside, against the float64 oracle."""
+    shapes_l = [(21, 30), (11, 15), (6, 8), (3, 4)]
+    rng = np.random.default_rng(int(spread * 10))
+    N, M = 2, 8
+    loc = _encoder_like_loc(N, shapes_l, rng, spread_px=spread)
+    S = loc.shape[1]
+    loc[0, :7] += 2.0      # a few queries sample entirely outside
+    value = rng.standard_normal((N, S, M, 32)).astype(np.float32)
+    attn = rng.random((N, S, M, 4, 4)).astype(np.float32)
+    attn /= attn.reshape(N, S, M, 16).sum(-1)[..., None, None]
+    go = rng.standard_normal((N, S, M * 32)).astype(np.float32)
+    shapes = np.asarray(shapes_l, np.int32)
+    c = dict(value=value, shapes=shapes, level_start=level_start(shapes), loc=loc, attn=attn, grad_out=go)
+    gv, gl, ga = (x.cpu().numpy() for x in hip_backward(c, torch.float32))
+    rgv, rgl, rga = O.msda_backward(value.astype(np.float64), shapes, c["level_start"], loc.astype(np.float64),
+                                    attn.astype(np.float64), go.astype(np.float64))
+    assert np.abs(gv - rgv).max() <= 1e-4 * max(1.0, np.abs(rgv).max())
+    assert np.abs(ga - rga).max() <= 1e-4 * max(1.0, np.abs(rga).max())
+    ok = _away_from_pixel_edges(loc, shapes_l)
+    assert ok.mean() > 0.98 and np.abs((gl - rgl) * ok).max() <= 1e-4 * max(1.0, np.abs(rgl).max())
 
 
 def test_backward_is_linear_in_grad_out_at_batch4():
