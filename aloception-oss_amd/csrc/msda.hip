@@ -761,21 +761,20 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
 //      product over the same window, the value rows going from memory straight into the matrix operand; D lands in the wave's
 //      LDS region in place of A and lane (i, l) picks its 16 corner values from there:
 //      grad_attn = sum_k w_k d_k,  grad_loc = attn * (W, H) * (...).
-// Both products run on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split EXACTLY into three bf16 terms
-// (8 + 8 + 8 significant bits, x = hi + mid + lo) and the six largest of the nine cross products are accumulated in fp32
-// (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; the dropped ones are below 2^-24 relative) — 6 instructions of K = 16 / 32
-// take 192 / 96 cycles where the exact-fp32 MFMA forms (K = 2 / 4 per instruction) take 512 / 256.
-// The wave's LDS region holds 312 window pixels; the levels are made resident in up to two passes.  A level whose window does
+// Both products run on the fp32 matrix instructions (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32 FMA chains).
+// Measured (profiles/r02_pmc_counters.md): the kernel is bound by VALU issue and load latency, the matrix pipe is < 10 % busy —
+// an exact three-way bf16 split of the operands (6 bf16 MFMAs instead of 8 fp32 ones, 2.7x less matrix time) was tried and
+// cost more in split arithmetic than it saved.
+// The wave's LDS region holds 310 window pixels; the levels are made resident in as many passes as it takes.  A level whose window does
 // not fit (queries of a coarse level looking at a fine one, decoder queries, arbitrary locations) takes the per-corner route of
 // msda_bwd_kernel for that level only: same results, old cost.
 // ------------------------------------------------------------------------------------------------------------------
-#ifndef ALO_EXP
-#define ALO_EXP 0
-#endif
 constexpr int kTileWaves = 4;
-constexpr int kPxBudget = 312;                      // window pixels per wave resident in LDS (64 B each): 2 workgroups / CU
+constexpr int kPxBudget = 310;                      // window pixels per wave resident in LDS at a time (64 B each): 2 workgroups / CU
 constexpr int kWaveRegion = kPxBudget * 64;         // bytes
-constexpr int kTileLds = kTileWaves * kWaveRegion + kTileWaves * 4 * 5 * 4 + 16;
+constexpr int kBatch = 4;               // 16-row blocks of value rows in flight in stage 3
+constexpr int kTableEntry = 6;                      // {x0, y0, ww, wh, off, pass} per (wave, level)
+constexpr int kTileLds = kTileWaves * kWaveRegion + kTileWaves * 4 * kTableEntry * 4 + 16 + kTileWaves * 32 * 4;
 
 struct TileDims {
     int S, M, Lq;
@@ -786,53 +785,8 @@ struct TileDims {
     unsigned nblocks;
 };
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
-__device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
-    union { u32x4 u; bf16x8_t b; } x;
-    x.u = v;
-    return x.b;
-}
-// 8 fp32 values -> three packed bf16 operands with x = hi + mid + lo exactly (truncation splits, each remainder exact)
-struct Split3 { u32x4 hi, mid, lo; };
-__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = __float_as_uint(x[e]);
-        const float r1 = x[e] - __uint_as_float(h[e] & 0xffff0000u);
-        m[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(m[e] & 0xffff0000u);
-        l[e] = __float_as_uint(r2);
-    }
-    Split3 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        o.hi[i] = __builtin_amdgcn_perm(h[2 * i + 1], h[2 * i], 0x07060302u);
-        o.mid[i] = __builtin_amdgcn_perm(m[2 * i + 1], m[2 * i], 0x07060302u);
-        o.lo[i] = __builtin_amdgcn_perm(l[2 * i + 1], l[2 * i], 0x07060302u);
-    }
-    return o;
-}
-// acc += A * B in fp32 accuracy from the split operands: small cross terms first
-__device__ __forceinline__ f32x16 mfma_split_32(const Split3& a, const Split3& b, f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.lo), as_bf16x8(b.hi), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.hi), as_bf16x8(b.lo), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.mid), as_bf16x8(b.mid), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.mid), as_bf16x8(b.hi), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.hi), as_bf16x8(b.mid), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a.hi), as_bf16x8(b.hi), acc, 0, 0, 0);
-    return acc;
-}
-__device__ __forceinline__ f32x4 mfma_split_16(const Split3& a, const Split3& b, f32x4 acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.lo), as_bf16x8(b.hi), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.hi), as_bf16x8(b.lo), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.mid), as_bf16x8(b.mid), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.mid), as_bf16x8(b.hi), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.hi), as_bf16x8(b.mid), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a.hi), as_bf16x8(b.hi), acc, 0, 0, 0);
-    return acc;
-}
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // All-reduce of a packed (x, y) pair of int16 over the 16 lanes that share (lane & 3): two DPP row rotations, two shuffles.
 template <bool MIN>
@@ -861,8 +815,9 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     float* region = reinterpret_cast<float*>(smem + wave * kWaveRegion);
-    int* table = reinterpret_cast<int*>(smem + kTileWaves * kWaveRegion);   // [wave][level]{x0, y0, ww, wh, off}; ww = 0: not resident
-    int* npass_slot = table + kTileWaves * 4 * 5;                           // [wave] passes this wave needs
+    int* table = reinterpret_cast<int*>(smem + kTileWaves * kWaveRegion);   // [wave][level]{x0, y0, ww, wh, off, pass}
+    int* npass_slot = table + kTileWaves * 4 * kTableEntry;                           // [wave] passes this wave needs
+    int* pixbuf = npass_slot + 4 + wave * 32;                               // [wave][32] pixel index of a block's rows
 
     const unsigned lb = xcd_contiguous_block(blockIdx.x, td.nblocks);
     const int m = lb % td.M;
@@ -892,17 +847,6 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     };
     const long bq0 = (long)b * Lq;
 
-    // grad_out rows of all four sub-tiles as B operands of the 32x32x16 product: lane (kg = lane >> 5, ch = lane & 31) holds
-    // G_j[8 kg + s][ch], s = 0..7.  Issued first: their latency hides behind stage 1.
-    float Graw[4][8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int q = query_of(j, 8 * (lane >> 5) + s);
-            Graw[j][s] = q >= 0 ? grad_out[((bq0 + q) * M + m) * 32 + (lane & 31)] : 0.f;
-        }
-
     // ---- stage 1: taps and windows ------------------------------------------------------------------------------------------
     const int qi = lane >> 2, lev = lane & 3;
     const int q_own = query_of(wave, qi);
@@ -912,10 +856,23 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     float lh[4], lw[4], at[4];
     int h_low[4], w_low[4];
     unsigned flags[4];   // bit k: corner k is inside the map; bit 4: the sample is valid (cuh:285-291, :38-78)
+    const float* lp = loc + (qm * 4 + lev) * 8;
+    const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp), l1 = *reinterpret_cast<const f32x4*>(lp + 4);
+    const f32x4 av = *reinterpret_cast<const f32x4*>(attn + (qm * 4 + lev) * 4);
+    // grad_out rows of all four sub-tiles as B operands of the 32x32x2 product: lane (kg = lane >> 5, ch = lane & 31) holds
+    // G_j[8 kg + s][ch], s = 0..7.  Issued behind the (smaller) location loads: their latency hides behind the tap arithmetic.
+    float G[4][8];
     {
-        const float* lp = loc + (qm * 4 + lev) * 8;
-        const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp), l1 = *reinterpret_cast<const f32x4*>(lp + 4);
-        const f32x4 av = *reinterpret_cast<const f32x4*>(attn + (qm * 4 + lev) * 4);
+        const float* gb = grad_out + (bq0 * M + m) * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int q = query_of(j, 8 * (lane >> 5) + s);
+                G[j][s] = q >= 0 ? gb[(unsigned)(q * M) * 32u] : 0.f;
+            }
+    }
+    {
         const float xs[4] = {l0[0], l0[2], l1[0], l1[2]}, ys[4] = {l0[1], l0[3], l1[1], l1[3]};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -957,57 +914,52 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     vmask |= __shfl_xor(vmask, 16, 64);
     vmask |= __shfl_xor(vmask, 32, 64);
     const int np_own = (np_l > kPxBudget || (vmask && !small_map)) ? kPxBudget + 1 : (int)np_l;
-    // residency plan: levels in order, up to two passes over the wave's region (wave-uniform)
-    int np4[4], off4[4], pass4[4];   // pass4: 0 / 1 = resident in that pass, 2 = per-corner route, 3 = nothing to do
+    // residency plan: levels in order, as many passes over the wave's region as it takes (wave-uniform)
+    int np4[4], off4[4], pass4[4];   // pass4: 0..3 = resident in that pass, 8 = per-corner route, 9 = nothing to do
+    int my_npass = 1;
     {
         int used = 0, pass = 0;
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             np4[l] = __builtin_amdgcn_readlane(np_own, l);
-            if (np4[l] == 0) { pass4[l] = 3; off4[l] = 0; continue; }
-            if (np4[l] > kPxBudget) { pass4[l] = 2; off4[l] = 0; continue; }
-            if (used + np4[l] > kPxBudget && pass == 0) { pass = 1; used = 0; }
-            if (used + np4[l] <= kPxBudget) { pass4[l] = pass; off4[l] = used; used += np4[l]; }
-            else { pass4[l] = 2; off4[l] = 0; }
+            off4[l] = 0;
+            if (np4[l] == 0) { pass4[l] = 9; continue; }
+            if (np4[l] > kPxBudget) { pass4[l] = 8; continue; }
+            if (used + np4[l] > kPxBudget) { ++pass; used = 0; }
+            pass4[l] = pass; off4[l] = used; used += np4[l];
+            my_npass = pass + 1;
         }
     }
     const int my_pass = lev == 0 ? pass4[0] : (lev == 1 ? pass4[1] : (lev == 2 ? pass4[2] : pass4[3]));
     const int off = lev == 0 ? off4[0] : (lev == 1 ? off4[1] : (lev == 2 ? off4[2] : off4[3]));
-    const bool two = pass4[0] == 1 || pass4[1] == 1 || pass4[2] == 1 || pass4[3] == 1;
-    const bool any_corner_route = pass4[0] == 2 || pass4[1] == 2 || pass4[2] == 2 || pass4[3] == 2;
-    if (lane == 0) npass_slot[wave] = two ? 2 : 1;
+    const bool any_corner_route = pass4[0] == 8 || pass4[1] == 8 || pass4[2] == 8 || pass4[3] == 8;
+    if (lane == 0) npass_slot[wave] = my_npass;
+    if (lane < 4) {
+        int* t = table + (wave * 4 + lane) * kTableEntry;
+        t[0] = x0; t[1] = y0; t[2] = ww; t[3] = wh; t[4] = off; t[5] = my_pass;
+    }
     int base[4];   // window row of the (h_low, w_low) corner; the others are +1, +ww, +ww+1
 #pragma unroll
     for (int p = 0; p < 4; ++p) base[p] = (h_low[p] - y0) * ww + (w_low[p] - x0);
 
-    // split grad_out operands (B of stage 2)
-    Split3 Gs[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Gs[j] = split3(Graw[j]);
-    // own grad_out rows as the B operand of stage 3: lane (kg = lane >> 4, q = lane & 15) holds g[q][8 kg .. 8 kg + 7]
-    Split3 Gown;
+    // own grad_out rows as the B operand of stage 3 (16x16x4): lane (kg = lane >> 4, q = lane & 15) holds g[q][16 c + 4 kg + s];
+    // the A operand uses the same (c, kg, s) -> channel map, so every channel meets itself
+    f32x4 g4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     {
         const int qb = query_of(wave, lane & 15);
-        float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (qb >= 0) {
-            const float* gp = grad_out + ((bq0 + qb) * M + m) * 32 + 8 * (lane >> 4);
-            const f32x4 a = *reinterpret_cast<const f32x4*>(gp), c = *reinterpret_cast<const f32x4*>(gp + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { g8[e] = a[e]; g8[4 + e] = c[e]; }
+            const float* gp = grad_out + ((bq0 + qb) * M + m) * 32 + 4 * (lane >> 4);
+            g4[0] = *reinterpret_cast<const f32x4*>(gp);
+            g4[1] = *reinterpret_cast<const f32x4*>(gp + 16);
         }
-        Gown = split3(g8);
     }
 
     float* gv_b = grad_value + (size_t)b * S * M * 32 + m * 32 + (lane & 31);
-    const float* vb3 = value + (size_t)b * S * M * 32 + m * 32 + 8 * (lane >> 4);
+    const float* vb3 = value + (size_t)b * S * M * 32 + m * 32 + 4 * (lane >> 4);
     int npass = 1;
     for (int pass = 0; pass < npass; ++pass) {
         // ---- stage 1b: A of this pass's levels -------------------------------------------------------------------------------
         const bool mine = my_pass == pass;
-        if (lane < 4) {
-            int* t = table + (wave * 4 + lane) * 5;
-            t[0] = x0; t[1] = y0; t[2] = mine ? ww : 0; t[3] = wh; t[4] = off;
-        }
         int used = 0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
@@ -1038,25 +990,27 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
 
         // ---- stage 2: grad_value over the windows -------------------------------------------------------------------------------
         int deal = 0;   // 32-row blocks of merged walks are dealt round-robin to the waves across all levels
-#pragma unroll
+#pragma unroll 1
         for (int lv = 0; lv < 4; ++lv) {
             int X0[4], Y0[4], WW[4], WH[4], OF[4];
             int sx0 = 0x7fffffff, sy0 = 0x7fffffff, sx1 = -0x7fffffff, sy1 = -0x7fffffff, sum = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int* t = table + (j * 4 + lv) * 5;
-                X0[j] = __builtin_amdgcn_readfirstlane(t[0]);
-                Y0[j] = __builtin_amdgcn_readfirstlane(t[1]);
-                WW[j] = __builtin_amdgcn_readfirstlane(t[2]);
-                WH[j] = __builtin_amdgcn_readfirstlane(t[3]);
-                OF[j] = __builtin_amdgcn_readfirstlane(t[4]);
+                const int* t = table + (j * 4 + lv) * kTableEntry;
+                const bool on = __builtin_amdgcn_readfirstlane(t[5]) == pass;
+                WW[j] = on ? __builtin_amdgcn_readfirstlane(t[2]) : 0;
+                X0[j] = Y0[j] = WH[j] = OF[j] = 0;
                 if (WW[j]) {
+                    X0[j] = __builtin_amdgcn_readfirstlane(t[0]);
+                    Y0[j] = __builtin_amdgcn_readfirstlane(t[1]);
+                    WH[j] = __builtin_amdgcn_readfirstlane(t[3]);
+                    OF[j] = __builtin_amdgcn_readfirstlane(t[4]);
                     sx0 = min(sx0, X0[j]); sy0 = min(sy0, Y0[j]);
                     sx1 = max(sx1, X0[j] + WW[j] - 1); sy1 = max(sy1, Y0[j] + WH[j] - 1);
                     sum += WW[j] * WH[j];
                 }
             }
-            if (sum == 0 || (ALO_EXP & 4)) continue;
+            if (sum == 0) continue;
             // windows that overlap or abut share one walk over their common bounding box (every sub-tile contributing to a block);
             // windows far apart (no locality between the sub-tiles) are walked one per wave
             const long sbox = (long)(sx1 - sx0 + 1) * (sy1 - sy0 + 1);
@@ -1069,6 +1023,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
             const int rw = merged ? sx1 - sx0 + 1 : own_w, rh = merged ? sy1 - sy0 + 1 : own_h;
             const int nrows = __builtin_amdgcn_readfirstlane(rw * rh);
             const int nblk = (nrows + 31) >> 5;
+            const float inv_rw = 1.0f / (float)(rw > 0 ? rw : 1);
             // merged: this wave takes the blocks whose deal number is its own
             const int first = merged ? ((wave - deal) & 3) : 0, step = merged ? kTileWaves : 1;
             if (merged) deal += nblk;
@@ -1076,7 +1031,8 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
             for (int blk = __builtin_amdgcn_readfirstlane(first); blk < nblk; blk += step) {
                 const int r = blk * 32 + (lane & 31);
                 const bool rin = r < nrows;
-                const int ry = rin ? r / rw : 0, rx = rin ? r - ry * rw : 0;
+                // r / rw through the reciprocal: exact while rows * width < 2^20 ((r + 0.5) / rw is 0.5 / rw away from an integer)
+                const int ry = rin ? (int)(((float)r + 0.5f) * inv_rw) : 0, rx = rin ? r - ry * rw : 0;
                 const int gx = rx0 + rx, gy = ry0 + ry;
                 f32x16 acc;
 #pragma unroll
@@ -1090,64 +1046,77 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                     if (__ballot(in) == 0) continue;                  // wave-uniform
                     any = true;
                     const float* ap = reinterpret_cast<const float*>(smem + j * kWaveRegion) + (OF[j] + wy * WW[j] + wx) * 16 + 8 * (lane >> 5);
-                    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    if (in) {
-                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+                    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                    if (in) { a0 = *reinterpret_cast<const f32x4*>(ap); a1 = *reinterpret_cast<const f32x4*>(ap + 4); }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a8[e] = a0[e]; a8[4 + e] = a1[e]; }
-                    }
-                    acc = mfma_split_32(split3(a8), Gs[j], acc);
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], G[j][e], acc, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], G[j][4 + e], acc, 0, 0, 0);
                 }
                 if (!any) continue;
                 // C/D layout: col = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): one atomic instruction =
-                // two whole 128-byte rows; rows nothing was scattered to hold exact zeros and are skipped
+                // two whole 128-byte rows; rows nothing was scattered to hold exact zeros and are skipped.  The rows' pixel indices
+                // pass through 128 bytes of LDS (row -> the lanes of both halves)
                 const int pix = rin ? Slv + gy * Wlv + gx : -1;
+                if (lane < 32) pixbuf[lane] = pix;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                    const int pr = __shfl(pix, rr, 64);
-#if !(ALO_EXP & 2)
-                    if (pr >= 0 && acc[reg] != 0.f) unsafeAtomicAdd(gv_b + (size_t)pr * M * 32, acc[reg]);
-#else
-                    if (pr >= 0 && acc[reg] == 123.456f) unsafeAtomicAdd(gv_b + (size_t)pr * M * 32, acc[reg]);
-#endif
+                for (int g = 0; g < 4; ++g) {
+                    const i32x4 pr4 = *reinterpret_cast<const i32x4*>(pixbuf + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = acc[4 * g + e];   // row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), reg = 4 g + e
+                        if (pr4[e] >= 0 && a != 0.f)
+                            unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gv_b) + (size_t)((unsigned)(pr4[e] * M) * 128u)), a);
+                    }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
         __syncthreads();   // every wave is done reading every A: the regions are re-used for D
 
         // ---- stage 3: d[pixel][q] = <value[pixel], grad_out[q]> over the own windows, then the per-sample gradients -----------------
-#pragma unroll
+#pragma unroll 1
         for (int lv = 0; lv < 4; ++lv) {
-            if (pass4[lv] != pass || (ALO_EXP & 8)) continue;   // wave-uniform
-            const int wx0 = __builtin_amdgcn_readlane(x0, lv), wy0 = __builtin_amdgcn_readlane(y0, lv);
-            const int wwl = __builtin_amdgcn_readlane(ww, lv);
-            const int nrows = np4[lv], offl = off4[lv];
+            const int* t = table + (wave * 4 + lv) * kTableEntry;
+            if (__builtin_amdgcn_readfirstlane(t[5]) != pass) continue;   // wave-uniform
+            const int wx0 = __builtin_amdgcn_readfirstlane(t[0]), wy0 = __builtin_amdgcn_readfirstlane(t[1]);
+            const int wwl = __builtin_amdgcn_readfirstlane(t[2]), offl = __builtin_amdgcn_readfirstlane(t[4]);
+            const int nrows = wwl * __builtin_amdgcn_readfirstlane(t[3]);
             const int nblk = (nrows + 15) >> 4;
             const int Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
             // value rows go from memory straight into the A operand: lane (row = lane & 15, kg = lane >> 4) takes channels
-            // 8 kg .. 8 kg + 7 of its row (32 contiguous bytes); the next block's rows are in flight during this block's product
-            auto fetch = [&](int blk, f32x4& v0, f32x4& v1) {
-                const int r = blk * 16 + (lane & 15);
-                const bool rin = r < nrows;
-                const int ry = rin ? r / wwl : 0, rx = rin ? r - ry * wwl : 0;
-                const float* vp = vb3 + (size_t)(Slv + (wy0 + ry) * Wlv + wx0 + rx) * M * 32;
-                v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0;
-                if (rin) { v0 = *reinterpret_cast<const f32x4*>(vp); v1 = *reinterpret_cast<const f32x4*>(vp + 4); }
-            };
-            f32x4 n0, n1;
-            fetch(0, n0, n1);
-            for (int blk = 0; blk < nblk; ++blk) {
-                const f32x4 c0 = n0, c1 = n1;
-                if (blk + 1 < nblk) fetch(blk + 1, n0, n1);
-                const float v8[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
-                d = mfma_split_16(split3(v8), Gown, d);
-                // C/D layout: col = lane & 15 (query), row = 4 * (lane >> 4) + reg
+            // 16 c + 4 kg .. + 3 of its row (two 16-byte loads); the rows of kBatch blocks are requested before the first product
+            const float inv_ww = 1.0f / (float)wwl;
+            for (int blk0 = 0; blk0 < nblk; blk0 += kBatch) {
+                f32x4 v[kBatch][2];
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int row = blk * 16 + 4 * (lane >> 4) + reg;
-                    if (row < nrows) region[(offl + row) * 16 + (lane & 15)] = d[reg];
+                for (int u = 0; u < kBatch; ++u) {
+                    const int r = (blk0 + u) * 16 + (lane & 15);
+                    const bool rin = r < nrows;
+                    const int ry = rin ? (int)(((float)r + 0.5f) * inv_ww) : 0, rx = rin ? r - ry * wwl : 0;
+                    const float* vp = vb3 + (size_t)(unsigned)((Slv + (wy0 + ry) * Wlv + wx0 + rx) * M) * 32u;
+                    v[u][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[u][1] = v[u][0];
+                    if (rin) { v[u][0] = *reinterpret_cast<const f32x4*>(vp); v[u][1] = *reinterpret_cast<const f32x4*>(vp + 16); }
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    if ((blk0 + u) * 16 >= nrows) break;   // wave-uniform
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][c][e], g4[c][e], d, 0, 0, 0);
+                    // C/D layout: col = lane & 15 (query), row = 4 * (lane >> 4) + reg
+                    const int row0 = (blk0 + u) * 16 + 4 * (lane >> 4);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (row0 + reg < nrows) region[(offl + row0 + reg) * 16 + (lane & 15)] = d[reg];
                 }
             }
         }
@@ -1184,7 +1153,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // levels with nothing to do (no valid sample of the sub-tile): their gradients are zero
-    if (my_pass == 3 && live) {
+    if (my_pass == 9 && live) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         float* glp = grad_loc + (qm * 4 + lev) * 8;
         *reinterpret_cast<f32x4*>(glp) = z;
@@ -1193,7 +1162,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     }
 
     // ---- stage 4: levels that are not resident: one 128-byte row per corner, as msda_bwd_kernel does ---------------------------------
-    if (!any_corner_route || (ALO_EXP & 1)) return;   // wave-uniform
+    if (!any_corner_route) return;   // wave-uniform
     // sample descriptors through the wave's region (free now): 8 words per (level, point, query), read back as broadcasts
     {
 #pragma unroll
@@ -1208,7 +1177,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     }
 #pragma unroll
     for (int lv = 0; lv < 4; ++lv) {
-        if (pass4[lv] != 2) continue;   // wave-uniform
+        if (pass4[lv] != 8) continue;   // wave-uniform
         const int Hlv = shapes[2 * lv], Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
         const int ch = lane & 31, half = lane >> 5;
         const float* vb = value + (size_t)b * S * M * 32 + m * 32 + ch;
