@@ -43,13 +43,19 @@ class DeformableCriterion(DetrCriterion):
 
     @torch.no_grad()
     def get_metrics(self, outputs, frames, indices, num_boxes, **kwargs):
-        if outputs.get("activation_fn") == "softmax":
+        """Precision / recall of the matched predictions at the reference's fixed score threshold 0.3
+        (deformable_detr/criterion.py:156-229)."""
+        if "activation_fn" not in outputs:
+            raise Exception("'activation_fn' must be declared in forward output.")
+        if outputs["activation_fn"] == "softmax":
             return super().get_metrics(outputs, frames, indices, num_boxes, **kwargs)
         if num_boxes == 0:
             return {}
         background = self._num_classes(frames)
         scores, pred = outputs["pred_logits"].sigmoid().max(-1)
-        pred = torch.where(scores > 0.5, pred, torch.full_like(pred, background))
         target = self._target_classes(outputs["pred_logits"], frames, indices, background)
-        is_obj = target != background
-        return {"recall": (pred[is_obj] == target[is_obj]).float().mean()} if is_obj.any() else {}
+        confident = scores >= 0.3
+        true_pos = (pred == target)[confident].sum()
+        n_pos, n_gt = confident.sum(), int((target != background).sum())
+        zero = torch.zeros((), device=pred.device)
+        return {"precision": true_pos / n_pos if n_pos > 0 else zero, "recall": true_pos / n_gt if n_gt > 0 else zero}

@@ -62,20 +62,31 @@ class DetrCriterion(nn.Module):
 
     @torch.no_grad()
     def get_metrics(self, outputs, frames, indices, num_boxes, **kwargs):
-        """Slot-level recall / precision of the matched predictions (monitoring only)."""
+        """Slot-level monitoring metrics of the matched predictions, with the reference's definitions and quirks
+        (criterion.py:214-301): a ratio is reported when numerator and denominator are both non-zero (0 when only the
+        numerator is), ``recall`` / ``precision`` are means taken in float16."""
         if num_boxes == 0:
             return {}
         background = self._num_classes(frames)
         pred = outputs["pred_logits"].argmax(-1)
         target = self._target_classes(outputs["pred_logits"], frames, indices, background)
-        is_obj = target != background
+
+        def ratio(metrics, key, num, den):
+            if num != 0 and den != 0:
+                metrics[key] = num / den
+            elif num > 0:
+                metrics[key] = 0
+
         metrics = {}
-        if is_obj.any():
-            metrics["recall"] = (pred[is_obj] == target[is_obj]).float().mean()
-            metrics["objectness_recall"] = (pred[is_obj] != background).float().mean()
-        pos = pred != background
-        if pos.any():
-            metrics["precision"] = (pred[pos] == target[pos]).float().mean()
+        is_obj, pred_pos = target != background, pred != background
+        ratio(metrics, "objectness_recall", int((is_obj & pred_pos).sum()), int(is_obj.sum()))
+        metrics["recall"] = (pred[is_obj] == target[is_obj]).to(torch.float16).mean()
+        ratio(metrics, "objectness_true_pos", int((pred_pos & is_obj).sum()), int(pred_pos.sum()))
+        if pred_pos.any():
+            metrics["precision"] = (target[pred_pos] == pred[pred_pos]).to(torch.float16).mean()
+        pred_neg = ~pred_pos
+        ratio(metrics, "true_neg", int((pred_neg & ~is_obj).sum()), int(pred_neg.sum()))
+        ratio(metrics, "slot_true_neg", int((~is_obj & pred_neg).sum()), int((~is_obj).sum()))
         return metrics
 
     def forward(self, m_outputs, frames, matcher_frames=None, compute_statistical_metrics=False, **kwargs):

@@ -27,6 +27,8 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
   g11_panoptic_nn.npz    MHAttentionMap + FPNstyleCNN of the reference's PanopticHead (fp64)
   g12_deformable_transformer_d256.npz   DeformableTransformer at the DETR-family width (d_model 256, 8 heads, 4 levels,
                          4 points, 1 + 1 layers), fp64 run stored as fp32: pins the bf16 inference fast path
+  g13_criterion.npz      (make_golden_criterion.py) the reference's DetrCriterion / DeformableCriterion + Hungarian matchers on a
+                         seeded batch: matched indices per decoder level, every loss term, totals, monitoring metrics
   g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
@@ -429,6 +431,11 @@ def main():
     for fn in todo:
         fn(ref)
         print("wrote", fn.__name__)
+    if len(sys.argv) == 1 or "g13" in sys.argv[1:]:
+        # the criterion fixture needs the reference's real aloscene: its own interpreter (see make_golden_criterion.py)
+        import subprocess
+
+        subprocess.check_call([sys.executable, os.path.join(OUT, "make_golden_criterion.py")])
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total fixture bytes: {total}")
 

@@ -1,5 +1,6 @@
 """The training step under DistributedDataParallel with world_size 2 on gloo (CPU): gradient all-reduce, the
-criterion's all_reduce(num_boxes), identical parameters on both ranks afterwards.  The attention runs through the
+criterion's all_reduce(num_boxes); the DDP-averaged gradients must equal the single-process gradients of the CONCATENATED
+batch (both ranks' frames in one forward), and both ranks must hold identical parameters after the step.  The attention runs through the
 reference's differentiable pure-torch branch (``is_tracing``) because the HIP op has no CPU implementation."""
 import os
 import subprocess
@@ -19,29 +20,52 @@ WORKER = textwrap.dedent('''
 
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    torch.manual_seed(0)  # same initial weights on both ranks
-    backbone = Joiner(Backbone("resnet50", True, True, False), PositionEmbeddingSine(32, normalize=True, center=True))
-    transformer = DeformableTransformer(d_model=64, nhead=4, num_encoder_layers=1, num_decoder_layers=2,
-                                        dim_feedforward=64, dropout=0.0, return_intermediate_dec=True)
-    model = DeformableDETR(backbone, transformer, num_classes=5, num_queries=12, aux_loss=True, device=None).train()
-    ddp = torch.nn.parallel.DistributedDataParallel(model)
+
+    def build():
+        torch.manual_seed(0)  # same initial weights everywhere
+        backbone = Joiner(Backbone("resnet50", True, True, False), PositionEmbeddingSine(32, normalize=True, center=True))
+        transformer = DeformableTransformer(d_model=64, nhead=4, num_encoder_layers=1, num_decoder_layers=2,
+                                            dim_feedforward=64, dropout=0.0, return_intermediate_dec=True)
+        return DeformableDETR(backbone, transformer, num_classes=5, num_queries=12, aux_loss=True, device=None).train()
+
     names = [f"c{i}" for i in range(5)]
-    gen = torch.Generator().manual_seed(100 + rank)  # different shard per rank
-    n_boxes = 1 + rank
-    lab = aloscene.Labels(torch.arange(n_boxes).float(), encoding="id", labels_names=names)
-    bx = aloscene.BoundingBoxes2D(torch.rand(n_boxes, 4, generator=gen) * 0.3 + 0.3, "xcyc", False, labels=lab)
-    fr = aloscene.Frame(torch.rand(3, 64, 96, generator=gen) * 255, normalization="255", boxes2d=bx).norm_resnet()
-    frames = aloscene.Frame.batch_list([fr])
+
+    def shard(r):   # the frame rank r owns
+        gen = torch.Generator().manual_seed(100 + r)
+        n_boxes = 1 + r
+        lab = aloscene.Labels(torch.arange(n_boxes).float(), encoding="id", labels_names=names)
+        bx = aloscene.BoundingBoxes2D(torch.rand(n_boxes, 4, generator=gen) * 0.3 + 0.3, "xcyc", False, labels=lab)
+        return aloscene.Frame(torch.rand(3, 64, 96, generator=gen) * 255, normalization="255", boxes2d=bx).norm_resnet()
+
+    model = build()
+    ddp = torch.nn.parallel.DistributedDataParallel(model)
+    frames = aloscene.Frame.batch_list([shard(rank)])
     crit, opt = build_criterion(aux_loss_stage=2), configure_optimizers(model)
     opt.zero_grad()
     total, parts = crit(ddp(frames, is_tracing=None), frames)
     total.backward()
+    ddp_grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    # single-process reference: BOTH frames in one batch through an identical, un-wrapped model.  (Every rank runs it, so the
+    # criterion's all_reduce(num_boxes) sums 3 + 3 and divides by the world size: the batch's own 3 boxes.)
+    ref = build()
+    both = aloscene.Frame.batch_list([shard(0), shard(1)])
+    ref_total, _ = build_criterion(aux_loss_stage=2)(ref(both, is_tracing=None), both)
+    ref_total.backward()
+    worst = 0.0
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert n not in ddp_grads, n
+            continue
+        scale = max(1e-6, float(p.grad.abs().max()))
+        worst = max(worst, float((ddp_grads[n] - p.grad).abs().max()) / scale)
     opt.step()
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(2)]
     dist.all_gather(gathered, flat)
     if rank == 0:
         print("SAME" if torch.equal(gathered[0], gathered[1]) else "DIFFERENT", float(total))
+        print("GRADDIFF", worst)
     dist.destroy_process_group()
 ''') % ROOT
 
@@ -55,3 +79,6 @@ def test_ddp_training_step_two_ranks(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith(("SAME", "DIFFERENT"))]
     assert line and line[0].startswith("SAME"), out.stdout[-2000:]
+    diff = [float(ln.split()[1]) for ln in out.stdout.splitlines() if ln.startswith("GRADDIFF")]
+    # DDP's mean of the per-rank gradients == gradient of the concatenated batch (relative to each tensor's largest entry)
+    assert diff and diff[0] <= 2e-4, out.stdout[-2000:]

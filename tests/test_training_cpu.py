@@ -1,7 +1,8 @@
 """Training-side pieces (matcher, criteria, optimizer groups) checked against closed-form answers.  CPU only.
 
-The reference's own criterion cannot be imported here (it needs the full aloscene / torchvision stack), so these are
-known-answer tests of the published formulas rather than golden comparisons.
+Known-answer tests of the published formulas, plus G13: the outputs of the reference's OWN criterion / matcher classes on a
+seeded batch (generated in the build container with the reference's real aloscene under inert torchvision / cv2 shells,
+tests/golden/make_golden_criterion.py).
 """
 import math
 
@@ -117,3 +118,60 @@ def test_optimizer_param_groups_follow_the_reference():
     assert sum(p.numel() for p in g[1]["params"]) == n_bb
     total = sum(p.numel() for x in g for p in x["params"])
     assert abs(total - 39.85e6) < 0.05e6  # the 159 MB of fp32 gradients DDP all-reduces per step
+
+
+# ---- G13: the reference's own criterion / matcher outputs (tests/golden/make_golden_criterion.py) -----------------------------
+def _g13_frames(g):
+    names = [f"c{i}" for i in range(int(g["num_classes"]))]
+    fs = []
+    for i, n in enumerate(g["counts"]):
+        lab = aloscene.Labels(torch.from_numpy(g[f"tgt_labels{i}"]).float(), encoding="id", labels_names=names)
+        bx = aloscene.BoundingBoxes2D(torch.from_numpy(g[f"tgt_boxes{i}"]).float().view(-1, 4), "xcyc", False, labels=lab)
+        fs.append(aloscene.Frame(torch.zeros(3, 16, 24), normalization="resnet", boxes2d=bx))
+    return aloscene.Frame.batch_list(fs)
+
+
+def _g13_outputs(g, tag, activation):
+    levels = []
+    s = 0
+    while f"{tag}.logits{s}" in g.files:
+        levels.append({"pred_logits": torch.from_numpy(g[f"{tag}.logits{s}"]), "pred_boxes": torch.from_numpy(g[f"{tag}.boxes{s}"]),
+                       "activation_fn": activation})
+        s += 1
+    out = dict(levels[0])
+    out["aux_outputs"] = levels[1:]
+    return out, levels
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", ["detr", "deformable"])
+def test_criterion_and_matcher_match_the_reference(golden, tag):
+    """Matched indices of every decoder level, every loss term, the weighted total and the monitoring metrics against what
+    the reference's own DetrCriterion / DeformableCriterion (+ Hungarian matchers) return on the same batch — one image
+    without ground truth included."""
+    from alonet.deformable_detr.criterion import DeformableCriterion
+
+    g = golden("g13_criterion.npz")
+    frames = _g13_frames(g)
+    if tag == "detr":
+        out, levels = _g13_outputs(g, tag, "softmax")
+        crit = DetrCriterion(matcher=DetrHungarianMatcher(1, 5, 2), loss_ce_weight=1, loss_boxes_weight=5, loss_giou_weight=2,
+                             eos_coef=0.1, aux_loss_stage=len(levels), losses=["labels", "boxes"])
+    else:
+        out, levels = _g13_outputs(g, tag, "sigmoid")
+        crit = DeformableCriterion(matcher=DeformableDetrHungarianMatcher(1, 5, 2), loss_label_weight=1, loss_boxes_weight=5,
+                                   loss_giou_weight=2, eos_coef=0.1, aux_loss_stage=len(levels), losses=["labels", "boxes"],
+                                   focal_alpha=0.25)
+    for s, lvl in enumerate(levels):
+        idx = crit.matcher(lvl, frames)
+        for bi, (pi, ti) in enumerate(idx):
+            want = g[f"{tag}.match{s}.{bi}"]
+            assert pi.tolist() == want[0].tolist() and ti.tolist() == want[1].tolist(), (s, bi)
+    total, parts = crit(out, frames)
+    assert abs(float(total) - float(g[f"{tag}.total"])) <= 1e-5 * abs(float(g[f"{tag}.total"]))
+    ref_parts = {k[len(tag) + 6:]: float(g[k]) for k in g.files if k.startswith(f"{tag}.part.")}
+    assert set(ref_parts) == set(parts), (sorted(ref_parts), sorted(parts))
+    for k, v in ref_parts.items():
+        assert abs(float(parts[k]) - v) <= 1e-5 * max(1.0, abs(v)), (k, float(parts[k]), v)
