@@ -20,8 +20,13 @@ Beside it, in the same line:
   launch        the forward at a fixed input shape is captured once as a HIP graph and replayed per step (same kernels,
                 same bits; ``--no-graph`` launches eagerly); ``inference()`` — the device-to-host hand-over — is eager.
   raft          BASELINE.json configs[2]: RAFT, 32 iterations, 4 synthetic 1280x720 pairs per GPU (fp32), pairs/s.
+  train         BASELINE.json configs[3] per-GPU share (fp32, 4 frames): forward + match + loss + alo_msda_backward + AdamW;
+                carries its own roofline entry for msda_bwd_tiled_kernel (HBM-bound, algorithmic bytes SURVEY 8d).
+  panoptic      BASELINE.json configs[4] per-GPU share (bf16, 8 frames, 16 kept queries per frame).
   cpu_baseline  rank 0, N = 1 only: the reference's CPU path (oracle/torch_ref.py, the torch restatement of
-                ms_deform_attn_core_pytorch) inside the same model graph on the host cores, on a bounded sample.
+                ms_deform_attn_core_pytorch / CorrBlock) on the host cores, on bounded samples: the detection model graph
+                (headline), the RAFT model graph (``raft.cpu_baseline``) and the two kernel-level units of SURVEY 8d
+                (``cpu_kernels``: one MSDA encoder call at B = 8; correlation build + 32 lookups at B = 4).
 """
 import argparse
 import json
@@ -42,6 +47,8 @@ from alonet.raft import RAFT  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak, same guide
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guide (AMD's 5 PF headline is 2:1 sparse)
+F32_MFMA_TAGS = ("corr_build", "corr_lookup_convc1")  # kernels whose contraction runs on the fp32 matrix instructions
 
 
 def parse():
@@ -51,20 +58,21 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU (detection)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--raft-steps", type=int, default=2)
+    ap.add_argument("--raft-steps", type=int, default=5)
+    ap.add_argument("--raft-warmup", type=int, default=2)
     ap.add_argument("--raft-batch", type=int, default=4, help="frame pairs per GPU (flow)")
     ap.add_argument("--no-raft", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the detector's forward eagerly instead of replaying its HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the bounded CPU sample (~13 s on 32 threads)")
-    ap.add_argument("--train-steps", type=int, default=0,
+    ap.add_argument("--train-steps", type=int, default=3,
                     help="also time K training steps of DeformableDETR-R50 (BASELINE configs[3]: fp32, 4 frames per GPU, "
-                         "DDP over RCCL when N > 1); off by default")
+                         "DDP over RCCL when N > 1); 0 = skip")
     ap.add_argument("--train-batch", type=int, default=4)
-    ap.add_argument("--panoptic-steps", type=int, default=0,
+    ap.add_argument("--panoptic-steps", type=int, default=5,
                     help="also time K steps of PanopticHead over DeformableDETR-R50 (BASELINE configs[4]: --batch frames "
-                         "per GPU, --panoptic-queries kept queries per frame)")
+                         "per GPU, --panoptic-queries kept queries per frame); 0 = skip")
     ap.add_argument("--panoptic-queries", type=int, default=16)
     ap.add_argument("--selftest", action="store_true",
                     help="CPU/gloo dry run of the launch, sharding, fencing and max-over-ranks logic (no GPU, no kernels)")
@@ -140,17 +148,22 @@ def flow_inputs(batch, rank, device):
     return mk(f1), mk(f2)
 
 
+def _cpu_threads():
+    # threads actually used: all of a small host, at most 32 of a big one (256 threads on the 256-core GPU host ran the
+    # detection graph ~15x SLOWER than 8 threads: torch's intra-op pools oversubscribe on these small tensors)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("ALO_CPU_THREADS", min(avail, 32)))
+    torch.set_num_threads(cores)
+    return cores, avail
+
+
 def cpu_baseline(cpu_frames):
     """The reference's CPU path of the same model graph on the host cores (bounded sample of the detection workload)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch_ref  # ORACLE: allowed here only as the timed CPU baseline
     import alonet.deformable_detr.ops.modules.ms_deform_attn as mod
 
-    # threads actually used: all of a small host, at most 32 of a big one (256 threads on the 256-core GPU host ran
-    # this graph ~15x SLOWER than 8 threads: torch's intra-op pools oversubscribe on these small tensors)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = int(os.environ.get("ALO_CPU_THREADS", min(avail, 32)))
-    torch.set_num_threads(cores)
+    cores, avail = _cpu_threads()
     torch.manual_seed(0)
     model = DeformableDetrR50(num_classes=91, aux_loss=False, device=None).eval()
     gen = torch.Generator().manual_seed(1234)
@@ -171,8 +184,82 @@ def cpu_baseline(cpu_frames):
         mod.ms_deform_attn_core_pytorch = saved
     return {"value": done / spent, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{done} frame(s) of 1333x800, one at a time, through the same DeformableDETR-R50 graph in fp32 on "
-                      f"{cores} host threads ({spent:.1f} s); multi-scale deformable attention = oracle/torch_ref.py (torch "
-                      "restatement of the reference's ms_deform_attn_core_pytorch CPU path), other layers stock PyTorch CPU ops"}
+                      f"{cores} of the host's {avail} hardware threads ({spent:.1f} s); multi-scale deformable attention = "
+                      "oracle/torch_ref.py (torch restatement of the reference's ms_deform_attn_core_pytorch CPU path), other "
+                      "layers stock PyTorch CPU ops"}
+
+
+def cpu_baseline_raft():
+    """RAFT's model graph on the host cores with the reference's CPU CorrBlock (oracle/torch_ref.CorrBlockRef): one
+    1280x720 pair, the full 32 iterations."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_ref  # ORACLE: timed CPU baseline only
+
+    cores, avail = _cpu_threads()
+    torch.manual_seed(0)
+    model = RAFT(corr_block=torch_ref.CorrBlockRef).eval()
+    f1, f2 = flow_inputs(1, 0, torch.device("cpu"))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        model.inference(model(f1, f2, iters=32, only_last=True), only_last=True)
+        spent = time.perf_counter() - t0
+    return {"value": 1.0 / spent, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 pair of 1280x720, 32 iterations, fp32 on {cores} of the host's {avail} hardware threads ({spent:.1f} s); "
+                      "correlation pyramid + lookups = oracle/torch_ref.CorrBlockRef (torch restatement of the reference's "
+                      "CorrBlock), encoders / update block stock PyTorch CPU ops"}
+
+
+def cpu_kernel_baselines():
+    """SURVEY.md 8(d) kernel-level units on the host cores, same shapes as the GPU kernels' roofline entries."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_ref  # ORACLE: timed CPU baseline only
+
+    cores, avail = _cpu_threads()
+    out = {}
+    gen = torch.Generator().manual_seed(7)
+    shapes = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes)
+    N, M, D, L, P = 8, 8, 32, 4, 4
+    value = torch.randn(N, S, M, D, generator=gen)
+    loc = torch.rand(N, S, M, L, P, 2, generator=gen)
+    attn = torch.softmax(torch.randn(N, S, M, L * P, generator=gen), -1).view(N, S, M, L, P)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        torch_ref.msda_core(value, torch.tensor(shapes), loc, attn)
+        spent = time.perf_counter() - t0
+    nbytes = alo_hip.msda_forward_bytes(N, S, M, D, L, S, P, 4, 4)
+    out["msda_fwd/Lq=22223"] = {"ms": round(spent * 1e3, 1), "alg_bytes": nbytes, "GBps": round(nbytes / spent / 1e9, 2), "cores": cores,
+                                "kind": "port", "sample": f"one encoder-size call, N = 8, S = Lq = {S}, fp32 (oracle/torch_ref.msda_core)"}
+    del value, loc, attn
+    B, C, H, W = 4, 256, 90, 160
+    f1, f2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    coords = torch.stack([xs, ys]).float()[None].repeat(B, 1, 1, 1) + torch.randn(B, 2, H, W, generator=gen) * 4.0
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        blk = torch_ref.CorrBlockRef(f1, f2)
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(4):          # 4 of the 32 lookups of a forward, scaled below
+            blk(coords)
+        t_look = (time.perf_counter() - t0) / 4
+    flops = 2.0 * B * (H * W) ** 2 * C
+    out["corr_build"] = {"ms": round(t_build * 1e3, 1), "alg_flops": flops, "TFLOPs": round(flops / t_build / 1e12, 3), "cores": cores,
+                         "kind": "port", "sample": "volume + 3 pooled levels, B = 4, 256 x 90 x 160 (oracle/torch_ref.CorrBlockRef)"}
+    lb = 4.0 * B * H * W * (324 + 400 + 2)
+    out["corr_lookup"] = {"ms": round(t_look * 1e3, 2), "alg_bytes": lb, "GBps": round(lb / t_look / 1e9, 2), "cores": cores, "kind": "port",
+                          "ms_per_forward_32_lookups": round(32 * t_look * 1e3, 1),
+                          "sample": "mean of 4 lookups, B = 4, radius 4, 4 levels (oracle/torch_ref.CorrBlockRef.__call__)"}
+    return out
+
+
+def offline_traffic(a):
+    """FETCH_SIZE + WRITE_SIZE per launch of the dominant kernel from the committed offline PMC collection (not this run)."""
+    path = os.path.join(ROOT, "profiles", "msda_fwd_traffic.json")
+    if a.dtype != "bf16" or a.batch != 8 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
 
 
 def kernel_report(summary):
@@ -184,7 +271,9 @@ def kernel_report(summary):
         if d["alg_flops_avg"]:
             item["alg_flops"] = d["alg_flops_avg"]
             item["TFLOPs"] = round(d["alg_flops_avg"] / sec / 1e12, 2)
-            item["mfma_frac"] = round(d["alg_flops_avg"] / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+            peak = MFMA_F32_PEAK_TFLOPS if tag.startswith(F32_MFMA_TAGS) else MFMA_BF16_PEAK_TFLOPS
+            item["mfma_peak_TFLOPs"] = peak   # dense peak of the instruction family the kernel uses (fp32 vs bf16 MFMA)
+            item["mfma_frac"] = round(d["alg_flops_avg"] / sec / 1e12 / peak, 4)
         rep[tag] = item
     return rep
 
@@ -300,7 +389,7 @@ def main():
                 raft_step = raft_eager
 
         with alo_hip.LaunchTimer(only="corr_build") as rtimer:  # one launch per forward; everything else un-instrumented
-            raft_seconds = timed_steps(raft_step, a.raft_steps, 1, world, device)
+            raft_seconds = timed_steps(raft_step, a.raft_steps, a.raft_warmup, world, device)
         rk = kernel_report(rtimer.summary())
         with alo_hip.LaunchTimer() as rfull:  # full kernel table from one extra, un-timed EAGER forward
             raft_eager()
@@ -308,7 +397,7 @@ def main():
         rk_all.update(rk)
         kernels.update(rk_all)
         raft = {"metric": "frame pairs/sec (whole node) RAFT 32-iter inference", "value": round(a.raft_batch * world * a.raft_steps / raft_seconds, 3),
-                "unit": "pairs/s", "steps": a.raft_steps, "warmup": 1, "ms_per_step": round(raft_seconds / a.raft_steps * 1e3, 2),
+                "unit": "pairs/s", "steps": a.raft_steps, "warmup": a.raft_warmup, "ms_per_step": round(raft_seconds / a.raft_steps * 1e3, 2),
                 "dtype": "f32", "config": {"workload": f"alonet.raft.RAFT 32 iters, batch {a.raft_batch} synthetic 1280x720 pairs per GPU",
                                            "launch": "eager" if raft_step is raft_eager else "HIP graph replay",
                                            "per_gpu_batch": a.raft_batch}}
@@ -350,6 +439,11 @@ def main():
                  "config": {"workload": f"forward + Hungarian match + set loss + backward (alo_msda_backward) + clip + AdamW, "
                                         f"{a.train_batch} synthetic 1333x800 frames x 10 boxes per GPU, global batch {a.train_batch * world}",
                             "parallelism": "DDP over RCCL" if world > 1 else "single GPU"}}
+        bk = tk.get("msda_bwd/Lq=22223")
+        if bk is not None:   # HIP events around the launch (memset of grad_value + the tiled kernel), encoder-size calls only
+            train["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_tiled_kernel (+ hipMemsetAsync of grad_value), encoder call N=%d, Lq=S=22223, fp32" % a.train_batch,
+                                 "achieved": bk["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": bk["hbm_frac"], "traffic": None,
+                                 "alg_bytes_per_launch": bk["alg_bytes"], "ms_per_launch": bk["ms_avg"], "launches": bk["launches"]}
         del tmodel, step_model, tframes, opt
         torch.cuda.empty_cache()
 
@@ -400,10 +494,10 @@ def main():
             "bound": "hbm", "kernel": "msda_fwd_bf16_mfma_kernel<4, fused, head-major> (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
             "achieved": round(enc["alg_bytes"] / ((enc_b2b_ms or enc["ms_avg"]) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(enc["alg_bytes"] / ((enc_b2b_ms or enc["ms_avg"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            # HBM-side bytes per launch from the PMC passes (profiles/r01_pmc_counters.md, third collection): FETCH_SIZE
-            # 389.2 MB (raw; gather pattern uncalibrated: lower bound) + WRITE_SIZE 108.2 MB; measured offline with
-            # tools/pmc.sh on the same kernel and shape, not in this run
-            "traffic": 497.4e6 if a.dtype == "bf16" and a.batch == 8 else None,
+            # PMC counters cannot be read from inside the timed process: `traffic` (in-run) stays null; the offline rocprofv3
+            # --pmc collection of the same kernel and shape (tools/pmc.sh, committed under profiles/) rides along, labelled
+            "traffic": None,
+            "traffic_offline": offline_traffic(a),
             "alg_bytes_per_launch": enc["alg_bytes"],
             # ms_per_launch: 20 back-to-back re-launches on the in-model buffers (what `achieved` uses; agrees with rocprofv3);
             # ms_per_launch_in_step: mean of the per-launch event pairs inside the timed steps (includes dispatch gaps)
@@ -418,6 +512,9 @@ def main():
         line["panoptic"] = panoptic
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.cpu_frames)
+        if raft is not None:
+            raft["cpu_baseline"] = cpu_baseline_raft()
+        line["cpu_kernels"] = cpu_kernel_baselines()
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
