@@ -3,12 +3,16 @@
 // Reference semantics: alonet/raft/corr.py:13-60 (volume = fmap1^T . fmap2 / sqrt(C); 3x avg_pool2d; 9x9 bilinear
 // window per level) and alonet/raft/utils/utils.py:5-19 (pixel -> [-1,1] -> grid_sample(align_corners=True)).
 //
-// Build: average pooling over the (h2, w2) axes of the volume is linear, so
-//        level_l[b,i,:] = <fmap1[b,:,i], pool^l(fmap2)[b,:,:]> / sqrt(C):
-// every pyramid level is the same dense contraction against a (tiny) pooled copy of fmap2.  One launch covers all
-// levels; the contraction runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, so the volume
-// keeps the reference's fp32 accuracy) and each level is written exactly once — the 3.3 GB level-0 volume is never
-// re-read to make the coarser levels, and the 1/sqrt(C) scale is folded into the epilogue.
+// Build: one dense contraction per pair, volume[b,i,j] = <fmap1[b,:,i], fmap2[b,:,j]> / sqrt(C), on the bf16 matrix cores at
+//        fp32 accuracy: a pre-pass splits every fp32 feature EXACTLY into three bf16 terms (x = hi + mid + lo, 8 + 8 + 8
+//        significant bits) and lays them out channel-contiguous per pixel; the GEMM accumulates the six largest of the nine
+//        cross products (hh, hm, mh, mm, hl, lh; the dropped ones are < 2^-23 relative) in fp32 with
+//        v_mfma_f32_32x32x16_bf16 — 6 instructions of 32 cycles per 16 channels where the exact-fp32 form
+//        (v_mfma_f32_32x32x2_f32) needs 8 of 64: 2.7x less matrix time, which turns the kernel from MFMA-bound into a
+//        stream of the 4.4 GB it writes.  A workgroup's column tile is a 4 x 32 PATCH of the (h2, w2) grid, so the 2x2 and 4x4
+//        averages of the pyramid's levels 1 and 2 are sums of accumulators the wave already holds (lane neighbours + its four
+//        row tiles): levels 0-2 leave in one launch and the level-0 volume is never re-read.  Levels >= 3 (1.6 % of the
+//        columns) are the same contraction against a 2x2-pooled copy of fmap2 (pooling commutes with the inner product).
 //
 // Lookup: one workgroup serves 32 consecutive query pixels.  Stage 1 reads each (query, level, window-row) strip of
 // 2r+3 taps once and interpolates it horizontally into LDS; stage 2 interpolates vertically and writes the
@@ -39,151 +43,225 @@ pool2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// all-levels correlation GEMM on fp32 MFMA
+// exact three-way bf16 split of a feature map: (B, C, n) fp32 -> [b][kc][term][pixel][16 channels] bf16, kc = ceil(C / 16)
+// (channels past C are zero).  One 16-channel slice of one pixel and one term is 32 contiguous bytes: a GEMM tile's rows of
+// a slice are one contiguous run.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int kSplitPx = 64;
 
-struct GemmLevel {
-    const float* b;  // (B, C, n) pooled fmap2 of this level
-    float* out;      // (B*HW, n)
-    int n;           // h_l * w_l
-    int tile0;       // first column-tile index of this level in the flat tile list
-};
-struct GemmArgs {
-    const float* a;  // fmap1 (B, C, HW)
-    int B, C, HW;
-    int tiles_m;     // ceil(HW / BM)
-    int tiles_n;     // sum over levels of ceil(n_l / BN)
-    int num_levels;
-    float scale;     // 1 / sqrt(C)
+__global__ void __launch_bounds__(256)
+corr_split_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int C, long n, int KC) {
+    __shared__ float tile[16][kSplitPx + 1];
+    const long px0 = (long)blockIdx.x * kSplitPx;
+    const int kc = blockIdx.y, b = blockIdx.z;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = (t >> 6) + 4 * e, px = t & 63;
+        const int c = kc * 16 + ch;
+        tile[ch][px] = (c < C && px0 + px < n) ? in[((long)b * C + c) * n + px0 + px] : 0.f;
+    }
+    __syncthreads();
+    const int px = t >> 2, q = t & 3;
+    if (px0 + px >= n) return;
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = tile[4 * q + e][px];
+        hi[e] = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(hi[e] & 0xffff0000u);   // exact: the low 16 mantissa bits
+        mid[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(mid[e] & 0xffff0000u); // exact: <= 8 significant bits left
+        lo[e] = __float_as_uint(r2);
+    }
+    // bf16 by truncation = the upper half; v_perm packs two upper halves
+    const long base = (((long)b * KC + kc) * 3) * n;
+    u32x2* o0 = reinterpret_cast<u32x2*>(out + ((base + px0 + px) * 16 + 4 * q));
+    u32x2* o1 = reinterpret_cast<u32x2*>(out + ((base + n + px0 + px) * 16 + 4 * q));
+    u32x2* o2 = reinterpret_cast<u32x2*>(out + ((base + 2 * n + px0 + px) * 16 + 4 * q));
+    *o0 = u32x2{__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u), __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u)};
+    *o1 = u32x2{__builtin_amdgcn_perm(mid[1], mid[0], 0x07060302u), __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302u)};
+    *o2 = u32x2{__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u), __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u)};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// correlation GEMM on split operands
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+__device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
+    union { u32x4 u; bf16x8_t b; } x;
+    x.u = v;
+    return x.b;
+}
+
+struct Gemm3Args {
+    const uint16_t* a;   // split fmap1  [B][KC][3][HW][16]
+    const uint16_t* b;   // split fmap2 (or a pooled copy of it) [B][KC][3][n][16]
+    float* out0;         // POOLED: level 0 (B*HW, H*W); plain: the level (B*HW, n)
+    float* out1;         // POOLED: level 1 or null
+    float* out2;         // POOLED: level 2 or null
+    int B, KC, HW;       // rows
+    int H, W, n;         // columns: POOLED: the (H, W) grid, n = H*W; plain: n columns
+    int h1, w1, h2, w2;  // POOLED: shapes of levels 1 and 2
+    int tiles_m, tiles_r, tiles_c;   // row tiles; column tiles: POOLED (4-row bands) x (32-column strips), plain: tiles_c of 128
+    float scale;
     unsigned nblocks;
-    GemmLevel lvl[kMaxPyr];
 };
 
-// Stage a BK x 128 panel (k-major, 128 contiguous columns) into registers: 4 x float4 per thread.
-template <bool ALIGNED>
-__device__ __forceinline__ void panel_load(const float* __restrict__ src, int ld, int rows_valid, int cols_valid,
-                                           int tid, f32x4 (&r)[4]) {
-    const int c4 = (tid & 31) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = (tid >> 5) + 8 * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < rows_valid) {
-            const float* p = src + (long)k * ld + c4;
-            if (ALIGNED) {
-                if (c4 < cols_valid) v = *reinterpret_cast<const f32x4*>(p);  // ld % 4 == 0: all four in or out
-            } else {
-                if (c4 + 0 < cols_valid) v.x = p[0];
-                if (c4 + 1 < cols_valid) v.y = p[1];
-                if (c4 + 2 < cols_valid) v.z = p[2];
-                if (c4 + 3 < cols_valid) v.w = p[3];
-            }
-        }
-        r[j] = v;
-    }
-}
-__device__ __forceinline__ void panel_store(float* __restrict__ dst, int tid, const f32x4 (&r)[4]) {
-    const int c4 = (tid & 31) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = (tid >> 5) + 8 * j;
-        *reinterpret_cast<f32x4*>(dst + k * BM + c4) = r[j];
-    }
+// Workgroup tile: 256 rows (pixels of fmap1) x 128 columns (POOLED: a 4 x 32 patch of fmap2's grid; plain: 128 consecutive
+// columns); 8 waves, each 32 rows x all 128 columns = 4 MFMA tiles of 32 x 32.  Per 16-channel slice the workgroup needs
+// 24 + 12 KiB of operands (three bf16 terms each); they go from memory STRAIGHT into LDS (global_load_lds_dwordx4, no
+// registers, no ds_write pass), one slice ahead, while the matrix pipe works on the current one.  2 workgroups = 16 waves
+// per CU: four waves per SIMD take turns on the matrix pipe, so one's epilogue / staging waits hide under the others' MFMAs.
+constexpr int kTM = 256, kTN = 128, kGemmThreads = 512;
+constexpr int kGranA = 3 * kTM * 2, kGranB = 3 * kTN * 2;          // 16-byte granules per stage
+constexpr int kGemmLds = 2 * (kGranA + kGranB) * 16;               // 72 KiB
+
+// LDS granule of (term, row, half) of an operand tile with ROWS rows.  The LDS-DMA writes lane-linearly, so the layout is
+// plain [term][row][half]; the half is flipped on every other group of 8 rows — on the SOURCE address of the DMA and on the
+// read address alike — so that the 16 lanes a ds_read_b128 serves together (rows 8 apart share banks) never collide.
+template <int ROWS>
+__device__ __forceinline__ int slot(int term, int row, int g) { return (term * ROWS + row) * 2 + (g ^ ((row >> 3) & 1)); }
+
+// 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of LDS starting at `lds_dst` (wave-uniform), asynchronously
+__device__ __forceinline__ void dma16(const uint16_t* src, u32x4* lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, lds_dst, 16, 0, 0);
+#endif
 }
 
-template <bool ALIGNED>
-__global__ void __launch_bounds__(256, 2)
-corr_gemm_kernel(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][BK * BM];  // [buffer][A|B][k][col]  64 KiB
+template <bool POOLED>
+__global__ void __launch_bounds__(kGemmThreads, 2)
+corr_gemm3_kernel(const Gemm3Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* const lds0 = reinterpret_cast<u32x4*>(smem_raw);
+    auto ldsA = [&](int stage) { return lds0 + stage * (kGranA + kGranB); };
+    auto ldsB = [&](int stage) { return lds0 + stage * (kGranA + kGranB) + kGranA; };
 
-    // flat block -> (batch, column tile, row tile); row tiles fastest so neighbours on an XCD reuse the B panel from L2
+    // flat block -> (batch, column tile, row tile); row tiles fastest so neighbours on an XCD reuse the B tile from L2
     const unsigned lb = xcd_contiguous_block(blockIdx.x, g.nblocks);
     const int tm = lb % g.tiles_m;
-    const int tn_flat = (lb / g.tiles_m) % g.tiles_n;
-    const int b = lb / (g.tiles_m * g.tiles_n);
-    int li = 0;
+    const int tn = (lb / g.tiles_m) % (g.tiles_r * g.tiles_c);
+    const int b = lb / (g.tiles_m * g.tiles_r * g.tiles_c);
+    const int tr = tn / g.tiles_c, tc = tn % g.tiles_c;
+    const int i0 = tm * kTM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // DMA plan: a wave instruction moves 64 granules = 32 rows x 2 halves of one term.  A: 3 terms x 8 row groups = 24
+    // instructions (3 per wave), B: 3 x 4 = 12 (waves 0-3: 2, waves 4-7: 1).  Rows past the edge re-read row 0 (their
+    // accumulators are never stored, and pooled outputs only combine columns that exist).
+    const int drow = lane >> 1, dhalf = lane & 1;
+    const uint16_t* asrc[3];
+    const uint16_t* bsrc[2];
 #pragma unroll
-    for (int l = 1; l < kMaxPyr; ++l)
-        if (l < g.num_levels && tn_flat >= g.lvl[l].tile0) li = l;
-    const GemmLevel L = g.lvl[li];
-    const int i0 = tm * BM;
-    const int j0 = (tn_flat - L.tile0) * BN;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const float* Ap = g.a + (long)b * g.C * g.HW + i0;
-    const float* Bp = L.b + (long)b * g.C * L.n + j0;
-    const int a_cols = g.HW - i0, b_cols = L.n - j0;
-
-    f32x16 acc[2][2];
+    for (int e = 0; e < 3; ++e) {
+        const int ins = wave + 8 * e, term = ins >> 3, row = 32 * (ins & 7) + drow;
+        const int half = dhalf ^ ((row >> 3) & 1);
+        asrc[e] = g.a + ((((long)b * g.KC) * 3 + term) * g.HW + (i0 + row < g.HW ? i0 + row : 0)) * 16 + half * 8;
+    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    f32x4 ra[4], rb[4];
-    const int nk = (g.C + BK - 1) / BK;
-    panel_load<ALIGNED>(Ap, g.HW, g.C, a_cols, tid, ra);
-    panel_load<ALIGNED>(Bp, L.n, g.C, b_cols, tid, rb);
-    panel_store(lds[0][0], tid, ra);
-    panel_store(lds[0][1], tid, rb);
-    __syncthreads();
-
-    // operand fetch: lane holds A[i = lane & 31][k = lane >> 5]; the wave's two 32-row tiles are interleaved
-    // (row 2r + t of the 64-row strip belongs to tile t) so ONE 8-byte LDS read feeds both tiles, conflict-free.
-    const int a_off = (lane >> 5) * BM + wm * 64 + 2 * (lane & 31);
-    const int b_off = (lane >> 5) * BM + wn * 64 + 2 * (lane & 31);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const int k0 = (kt + 1) * BK;
-            panel_load<ALIGNED>(Ap + (long)k0 * g.HW, g.HW, g.C - k0, a_cols, tid, ra);
-            panel_load<ALIGNED>(Bp + (long)k0 * L.n, L.n, g.C - k0, b_cols, tid, rb);
+    for (int e = 0; e < 2; ++e) {
+        const int ins = (wave + 8 * e) % 12, term = ins >> 2, row = 32 * (ins & 3) + drow;
+        const int half = dhalf ^ ((row >> 3) & 1);
+        long col;
+        bool ok;
+        if (POOLED) {
+            const int y = 4 * tr + (row >> 5), x = 32 * tc + (row & 31);
+            ok = y < g.H && x < g.W;
+            col = (long)y * g.W + x;
+        } else {
+            col = (long)tc * kTN + row;
+            ok = col < g.n;
         }
-        const float* As = lds[cur][0];
-        const float* Bs = lds[cur][1];
+        bsrc[e] = g.b + ((((long)b * g.KC) * 3 + term) * g.n + (ok ? col : 0)) * 16 + half * 8;
+    }
+    const long a_step = 3L * g.HW * 16, b_step = 3L * g.n * 16;   // one K slice further
+    auto stage_in = [&](int kc, int stage) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const float2 av = *reinterpret_cast<const float2*>(As + kk * 2 * BM + a_off);
-            const float2 bv = *reinterpret_cast<const float2*>(Bs + kk * 2 * BM + b_off);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            panel_store(lds[cur ^ 1][0], tid, ra);
-            panel_store(lds[cur ^ 1][1], tid, rb);
-        }
-        __syncthreads();
+        for (int e = 0; e < 3; ++e) dma16(asrc[e] + kc * a_step, ldsA(stage) + (wave + 8 * e) * 64);
+        dma16(bsrc[0] + kc * b_step, ldsB(stage) + wave * 64);
+        if (wave < 4) dma16(bsrc[1] + kc * b_step, ldsB(stage) + (wave + 8) * 64);   // wave-uniform
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    stage_in(0, 0);
+    __syncthreads();   // (hipcc drains the DMA queue in front of a barrier)
+
+    const int kg = lane >> 5, li = lane & 31;
+    for (int kc = 0; kc < g.KC; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < g.KC) stage_in(kc + 1, cur ^ 1);   // lands while this slice is multiplied
+        const u32x4* As = ldsA(cur);
+        const u32x4* Bs = ldsB(cur);
+        const int arow = 32 * wave + li;
+        const u32x4 ah = As[slot<kTM>(0, arow, kg)], am = As[slot<kTM>(1, arow, kg)], al = As[slot<kTM>(2, arow, kg)];
+        u32x4 bf[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int term = 0; term < 3; ++term) bf[t][term] = Bs[slot<kTN>(term, 32 * t + li, kg)];
+        // small cross terms first; the four column tiles rotate, so no MFMA waits on the one before it
+#define ALO_CORR_STEP(AT, BT)                                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                               \
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(AT), as_bf16x8(bf[t][BT]), acc[t], 0, 0, 0);
+        ALO_CORR_STEP(al, 0) ALO_CORR_STEP(ah, 2) ALO_CORR_STEP(am, 1) ALO_CORR_STEP(am, 0) ALO_CORR_STEP(ah, 1) ALO_CORR_STEP(ah, 0)
+#undef ALO_CORR_STEP
+        __syncthreads();   // the next slice has landed (DMA drained in front of the barrier) and this one is free to overwrite
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    float* outp = L.out + ((long)b * g.HW) * L.n;
-    const int jc = j0 + wn * 64 + 2 * (lane & 31);
-    const bool pair_ok = ((L.n & 1) == 0);  // even row length: (i*n + jc) is even -> 8-byte aligned float2 stores
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): every store
+    // instruction writes whole 128-byte lines (32 consecutive columns of two rows).
+    // The volume is written once and never read again by this kernel: non-temporal stores keep the stream out of the L2.
+    const long rowbase = (long)b * g.HW;
+    {
+        if (POOLED) {
+            const int x = 32 * tc + li;
+            const int yb = 4 * tr;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const bool iok = i < g.HW;
+                float s4 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int i = i0 + wm * 64 + 2 * row + ti;
-            if (i < g.HW) {
-                float* p = outp + (long)i * L.n + jc;
-                const float v0 = acc[ti][0][r] * g.scale, v1 = acc[ti][1][r] * g.scale;
-                // the volume is written once and not read again by this kernel: non-temporal stores keep the 4.4 GB stream
-                // from being read for ownership / parked in the L2
-                if (pair_ok && jc + 1 < L.n) {
-                    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-                    __builtin_nontemporal_store(f32x2_t{v0, v1}, reinterpret_cast<f32x2_t*>(p));
-                } else {
-                    if (jc < L.n) __builtin_nontemporal_store(v0, p);
-                    if (jc + 1 < L.n) __builtin_nontemporal_store(v1, p + 1);
+                for (int p = 0; p < 2; ++p) {
+                    const float v0 = acc[2 * p][r], v1 = acc[2 * p + 1][r];
+                    const int y = yb + 2 * p;
+                    if (iok && x < g.W) {
+                        float* o = g.out0 + (rowbase + i) * g.n + (long)y * g.W + x;
+                        if (y < g.H) __builtin_nontemporal_store(v0 * g.scale, o);
+                        if (y + 1 < g.H) __builtin_nontemporal_store(v1 * g.scale, o + g.W);
+                    }
+                    // level 1: 2 x 2 mean = this lane's two rows + the same of its x-neighbour (lane ^ 1)
+                    float s2 = v0 + v1;
+                    s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+                    s4 += s2;
+                    if (g.out1 && iok && !(lane & 1)) {
+                        const int y1 = (yb >> 1) + p, x1 = x >> 1;
+                        if (y1 < g.h1 && x1 < g.w1)
+                            __builtin_nontemporal_store(s2 * (0.25f * g.scale), g.out1 + (rowbase + i) * ((long)g.h1 * g.w1) + (long)y1 * g.w1 + x1);
+                    }
+                }
+                // level 2: 4 x 4 mean = both row pairs + the other half of the quad
+                s4 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s4), 0x4E, 0xf, 0xf, false));       // quad_perm [2,3,0,1]
+                if (g.out2 && iok && !(lane & 3)) {
+                    const int y2 = yb >> 2, x2 = x >> 2;
+                    if (y2 < g.h2 && x2 < g.w2)
+                        __builtin_nontemporal_store(s4 * (0.0625f * g.scale), g.out2 + (rowbase + i) * ((long)g.h2 * g.w2) + (long)y2 * g.w2 + x2);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const long col = (long)tc * kTN + 32 * t + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (i < g.HW && col < g.n) __builtin_nontemporal_store(acc[t][r] * g.scale, g.out0 + (rowbase + i) * g.n + col);
                 }
             }
         }
@@ -348,12 +426,20 @@ extern "C" void alo_corr_level_shape(int H, int W, int level, int* h_out, int* w
     if (w_out) *w_out = W;
 }
 
+namespace {
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline size_t split_bytes(int B, int C, long n) { return align256((size_t)B * ((C + 15) / 16) * 3 * n * 16 * sizeof(uint16_t)); }
+}  // namespace
+
+// Scratch: the split copies of fmap1 and fmap2; for pyramids deeper than 3 levels also the 2x2-average chain of fmap2 (fp32)
+// and the split copies of its levels >= 3.
 extern "C" size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels) {
-    size_t total = 0;
-    for (int l = 1; l < num_levels; ++l) {
+    size_t total = 2 * split_bytes(B, C, (long)H * W);
+    for (int l = 1; l < num_levels && num_levels > 3; ++l) {
         int h, w;
         alo_corr_level_shape(H, W, l, &h, &w);
-        total += (size_t)B * C * h * w * sizeof(float);
+        total += align256((size_t)B * C * h * w * sizeof(float));
+        if (l >= 3) total += split_bytes(B, C, (long)h * w);
     }
     return total;
 }
@@ -366,56 +452,86 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
     ALO_REQUIRE(num_levels >= 1 && num_levels <= kMaxPyr, ALO_ERR_INVALID_ARGUMENT,
                 "alo_corr_build: num_levels must be in [1,%d], got %d", kMaxPyr, num_levels);
     const size_t need = alo_corr_build_workspace_bytes(B, C, H, W, num_levels);
-    ALO_REQUIRE(workspace_bytes >= need && (need == 0 || workspace), ALO_ERR_INVALID_ARGUMENT,
-                "alo_corr_build: workspace of %zu bytes required, %zu given", need, workspace_bytes);
+    ALO_REQUIRE(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, ALO_ERR_INVALID_ARGUMENT,
+                "alo_corr_build: a 16-byte aligned workspace of %zu bytes is required, %zu given", need, workspace_bytes);
     ALO_REQUIRE((double)H * W * H * W < 2.0e9 * 64, ALO_ERR_UNSUPPORTED, "alo_corr_build: feature grid too large");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-
-    GemmArgs g;
-    g.a = fmap1;
-    g.B = B; g.C = C; g.HW = H * W;
-    g.tiles_m = (g.HW + BM - 1) / BM;
-    g.num_levels = num_levels;
-    g.scale = 1.0f / sqrtf((float)C);
-    int tiles = 0;
-    const float* prev = fmap2;
-    int ph = H, pw = W;
-    float* ws = static_cast<float*>(workspace);
-    bool aligned = (g.HW % 4 == 0) && (((uintptr_t)fmap1 | (uintptr_t)fmap2) & 15) == 0;
+    const long HW = (long)H * W;
+    const int KC = (C + 15) / 16;
     for (int l = 0; l < num_levels; ++l) {
         int h, w;
         alo_corr_level_shape(H, W, l, &h, &w);
         ALO_REQUIRE(h > 0 && w > 0, ALO_ERR_INVALID_ARGUMENT, "alo_corr_build: pyramid level %d is empty (%dx%d grid)", l, H, W);
         ALO_REQUIRE(levels[l], ALO_ERR_INVALID_ARGUMENT, "alo_corr_build: levels[%d] is null", l);
-        const float* bl = fmap2;
-        if (l > 0) {
-            const long planes = (long)B * C;
-            const long total = planes * h * w;
-            const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-            hipLaunchKernelGGL(pool2_kernel, dim3(blocks), dim3(256), 0, stream, prev, ws, planes, ph, pw);
-            if (int rc = check_launch("alo_corr_build(pool)")) return rc;
-            bl = ws;
-            ws += total;
-        }
-        g.lvl[l].b = bl;
-        g.lvl[l].out = levels[l];
-        g.lvl[l].n = h * w;
-        g.lvl[l].tile0 = tiles;
-        tiles += (h * w + BN - 1) / BN;
-        aligned = aligned && ((h * w) % 4 == 0) && (((uintptr_t)bl) & 15) == 0;
-        prev = bl;
-        ph = h; pw = w;
     }
-    for (int l = num_levels; l < kMaxPyr; ++l) g.lvl[l] = GemmLevel{nullptr, nullptr, 0, 0x7fffffff};
-    g.tiles_n = tiles;
-    const long nblocks = (long)g.tiles_m * tiles * B;
+
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    uint16_t* f1s = reinterpret_cast<uint16_t*>(ws);
+    ws += split_bytes(B, C, HW);
+    uint16_t* f2s = reinterpret_cast<uint16_t*>(ws);
+    ws += split_bytes(B, C, HW);
+    auto split = [&](const float* in, uint16_t* out, long n) -> int {
+        const dim3 grid((unsigned)((n + kSplitPx - 1) / kSplitPx), (unsigned)KC, (unsigned)B);
+        hipLaunchKernelGGL(corr_split_kernel, grid, dim3(256), 0, stream, in, out, C, n, KC);
+        return check_launch("alo_corr_build(split)");
+    };
+    if (int rc = split(fmap1, f1s, HW)) return rc;
+    if (int rc = split(fmap2, f2s, HW)) return rc;
+
+    Gemm3Args g;
+    g.a = f1s; g.b = f2s;
+    g.B = B; g.KC = KC; g.HW = (int)HW;
+    g.H = H; g.W = W; g.n = (int)HW;
+    g.tiles_m = (int)((HW + kTM - 1) / kTM);
+    g.tiles_r = (H + 3) / 4;
+    g.tiles_c = (W + 31) / 32;
+    g.scale = 1.0f / sqrtf((float)C);
+    g.out0 = levels[0];
+    g.out1 = num_levels > 1 ? levels[1] : nullptr;
+    g.out2 = num_levels > 2 ? levels[2] : nullptr;
+    alo_corr_level_shape(H, W, 1, &g.h1, &g.w1);
+    alo_corr_level_shape(H, W, 2, &g.h2, &g.w2);
+    long nblocks = (long)g.tiles_m * g.tiles_r * g.tiles_c * B;
     ALO_REQUIRE(nblocks < 0x7fffffffL, ALO_ERR_UNSUPPORTED, "alo_corr_build: grid too large");
     g.nblocks = (unsigned)nblocks;
-    if (aligned)
-        hipLaunchKernelGGL(corr_gemm_kernel<true>, dim3(g.nblocks), dim3(256), 0, stream, g);
-    else
-        hipLaunchKernelGGL(corr_gemm_kernel<false>, dim3(g.nblocks), dim3(256), 0, stream, g);
-    return check_launch("alo_corr_build(gemm)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_gemm3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_gemm3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_build: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(corr_gemm3_kernel<true>, dim3(g.nblocks), dim3(kGemmThreads), kGemmLds, stream, g);
+    if (int rc = check_launch("alo_corr_build(gemm)")) return rc;
+
+    // levels >= 3: the same contraction against the 2x2-average chain of fmap2
+    const float* prev = fmap2;
+    int ph = H, pw = W;
+    for (int l = 1; l < num_levels && num_levels > 3; ++l) {
+        int h, w;
+        alo_corr_level_shape(H, W, l, &h, &w);
+        float* pooled = reinterpret_cast<float*>(ws);
+        ws += align256((size_t)B * C * h * w * sizeof(float));
+        const long planes = (long)B * C, total = planes * h * w;
+        const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+        hipLaunchKernelGGL(pool2_kernel, dim3(blocks), dim3(256), 0, stream, prev, pooled, planes, ph, pw);
+        if (int rc = check_launch("alo_corr_build(pool)")) return rc;
+        prev = pooled; ph = h; pw = w;
+        if (l < 3) continue;
+        const long n = (long)h * w;
+        uint16_t* ps = reinterpret_cast<uint16_t*>(ws);
+        ws += split_bytes(B, C, n);
+        if (int rc = split(pooled, ps, n)) return rc;
+        Gemm3Args e = g;
+        e.b = ps; e.n = (int)n;
+        e.out0 = levels[l]; e.out1 = e.out2 = nullptr;
+        e.tiles_r = 1;
+        e.tiles_c = (int)((n + kTN - 1) / kTN);
+        e.nblocks = (unsigned)((long)e.tiles_m * e.tiles_c * B);
+        hipLaunchKernelGGL(corr_gemm3_kernel<false>, dim3(e.nblocks), dim3(kGemmThreads), kGemmLds, stream, e);
+        if (int rc = check_launch("alo_corr_build(gemm, coarse level)")) return rc;
+    }
+    return ALO_OK;
 }
 
 extern "C" int alo_corr_lookup(const float* const* levels, const float* coords, float* out, int B, int H, int W,

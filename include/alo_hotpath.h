@@ -167,7 +167,8 @@ int alo_msda_backward_hinted(const void* value, const int32_t* spatial_shapes, c
  * (F.avg_pool2d(2, stride=2), corr.py:25-27). */
 void alo_corr_level_shape(int H, int W, int level, int* h_out, int* w_out);
 
-/* Bytes of scratch alo_corr_build needs (the 2x2-average pyramid of fmap2 below level 0). */
+/* Bytes of scratch alo_corr_build needs (bf16-split copies of the feature maps; the 2x2-average chain of fmap2 for
+ * pyramids deeper than 3 levels). */
 size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels);
 
 /*
@@ -176,12 +177,15 @@ size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels
  *   level_0[b*HW + i, 0, y, x] = <fmap1[b,:,i], fmap2[b,:,y*W + x]> / sqrt(C)
  *   level_{l+1}                = avg_pool2d(level_l, 2, stride 2)        over the last two dims
  *
- * computed for every level as one fp32 MFMA contraction of fmap1 against the 2x2-average pyramid of fmap2 (average
- * pooling commutes with the inner product; results agree with pool-after-correlate to fp32 rounding).
+ * Level 0 is one dense contraction on the bf16 matrix cores at fp32 accuracy (every feature split exactly into three bf16
+ * terms, the six largest cross products accumulated in fp32: error < 2^-22 relative per product, fp32 accumulation);
+ * levels 1 and 2 are pooled from the accumulators in the same launch; deeper levels are the same contraction against the
+ * 2x2-average chain of fmap2 (average pooling commutes with the inner product).  Results agree with the reference's
+ * matmul + avg_pool2d chain to fp32 rounding.
  *
  *   fmap1, fmap2   (B, C, H, W) float32
  *   levels         HOST array of num_levels DEVICE pointers; levels[l] is (B*H*W, 1, h_l, w_l) float32, fully written
- *   workspace      device scratch of alo_corr_build_workspace_bytes(...) bytes (may be NULL when that is 0)
+ *   workspace      device scratch of alo_corr_build_workspace_bytes(...) bytes, 16-byte aligned (the split operands)
  *   1 <= num_levels <= 8.  Levels whose h_l or w_l is 0 are rejected (ALO_ERR_INVALID_ARGUMENT).
  */
 int alo_corr_build(const float* fmap1, const float* fmap2, float* const* levels, void* workspace,

@@ -96,9 +96,10 @@ def test_full_size_properties_720p():
     assert [tuple(p.shape) for p in blk.corr_pyramid] == [(14400, 1, 90, 160), (14400, 1, 45, 80),
                                                           (14400, 1, 22, 40), (14400, 1, 11, 20)]
     lvl0 = blk.corr_pyramid[0].view(H * W, H * W)
-    # (1) transpose symmetry: corr(f1, f2)[i, j] == corr(f2, f1)[j, i] (same products, same k order) -> bit equal
+    # (1) transpose symmetry: corr(f1, f2)[i, j] == corr(f2, f1)[j, i]: the same six split products per channel, the two mixed
+    # pairs accumulated in swapped order -> equal to fp32 rounding of the accumulation, not to the bit
     swapped = CorrBlock.corr(f2, f1).view(H * W, H * W)
-    assert torch.equal(lvl0, swapped.t())
+    assert (lvl0 - swapped.t()).abs().max().item() <= 2e-6
     # (2) a slab of rows against torch's own fp32 matmul
     rows = torch.arange(0, H * W, 97, device=DEV)
     ref = (f1.view(C, -1)[:, rows].t().double() @ f2.view(C, -1).double()) / 16.0
