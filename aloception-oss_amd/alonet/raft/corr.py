@@ -27,6 +27,14 @@ class CorrBlock:
         self.radius = radius
         self.corr_pyramid = alo_hip.corr_build(fmap1.float(), fmap2.float(), num_levels)
 
+    def lookup_conv1x1(self, coords, weight, bias, relu=True):
+        """``act(conv1x1(self(coords)))`` without materialising the window features (the motion encoder's ``convc1``);
+        None when the fused kernel does not cover the configuration (the caller then convolves ``self(coords)``)."""
+        _no_backward(coords, weight)
+        if not alo_hip.corr_lookup_conv1x1_supported(self.corr_pyramid, weight, self.radius):
+            return None
+        return alo_hip.corr_lookup_conv1x1(self.corr_pyramid, coords.float(), weight, bias, self.radius, relu)
+
     def __call__(self, coords):
         _no_backward(coords)
         return alo_hip.corr_lookup(self.corr_pyramid, coords.float(), self.radius)

@@ -289,27 +289,21 @@ __device__ __forceinline__ float round_trip(float p, int size) {
     return ((gnorm + 1.0f) / 2.0f) * s;
 }
 
+// Stage 1 of the lookup for ONE pyramid level and TQ consecutive queries: every (query, window-row) strip of 2r+3 taps is read
+// once and interpolated horizontally into `hbuf` [ROWS][WIN][TQ]; `tybuf` / `rowbuf` [WIN][TQ] receive the vertical fraction
+// and the upper staged row of each tap row.
 template <int R>
-__global__ void __launch_bounds__(256)
-corr_lookup_kernel(const LookupArgs a) {
+__device__ __forceinline__ void lookup_stage1(const LookupArgs& a, int l, int b, int q0, int tid, int nthreads, float* hbuf,
+                                              float* tybuf, int* rowbuf) {
     // A window of WIN x WIN taps spaced one pixel apart touches a (WIN+1)^2 footprint.  Every tap position goes through
     // the reference's fp32 round trip on its own, so floor(x_k) may come out as floor(x_0) + k - 1 or + k + 1 when x sits
     // within an ulp of an integer; one spare row and column (ROWS = COLS = WIN + 2) lets such taps shift by one.
     constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, COLS = WIN + 2;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* hbuf = sm;                                            // [L][ROWS][WIN][TQ] horizontally interpolated rows
-    float* tybuf = sm + a.num_levels * ROWS * WIN * TQ;          // [L][WIN][TQ]       vertical fraction per tap row
-    int* rowbuf = reinterpret_cast<int*>(tybuf + a.num_levels * WIN * TQ);  // [L][WIN][TQ] upper staged row per tap row
-
-    const int b = blockIdx.x / a.tiles_per_batch;
-    const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
-    const int tid = threadIdx.x;
-
-    const int items = a.num_levels * ROWS * TQ;
-    for (int item = tid; item < items; item += 256) {
+    const int h = a.h[l], w = a.w[l];
+    const float inv = 1.0f / (float)(1 << l);
+    for (int item = tid; item < ROWS * TQ; item += nthreads) {
         const int q = item % TQ;
-        const int row = (item / TQ) % ROWS;
-        const int l = item / (TQ * ROWS);
+        const int row = item / TQ;
         const int i = q0 + q;
         float hv[WIN];
 #pragma unroll
@@ -317,8 +311,6 @@ corr_lookup_kernel(const LookupArgs a) {
         float ty = 0.f;
         int trow = row < WIN ? row : 0;
         if (i < a.HW) {
-            const int h = a.h[l], w = a.w[l];
-            const float inv = 1.0f / (float)(1 << l);
             const float cx = a.coords[((long)b * 2 + 0) * a.HW + i] * inv;  // exact: power-of-two scale
             const float cy = a.coords[((long)b * 2 + 1) * a.HW + i] * inv;
             const float iy0 = round_trip(cy - (float)R, h);
@@ -374,45 +366,171 @@ corr_lookup_kernel(const LookupArgs a) {
                 }
             }
         }
-        float* dst = hbuf + ((l * ROWS + row) * WIN) * TQ + q;
+        float* dst = hbuf + (row * WIN) * TQ + q;
 #pragma unroll
         for (int k = 0; k < WIN; ++k) dst[k * TQ] = hv[k];
         if (row < WIN) {
-            tybuf[(l * WIN + row) * TQ + q] = ty;
-            rowbuf[(l * WIN + row) * TQ + q] = trow;
+            tybuf[row * TQ + q] = ty;
+            rowbuf[row * TQ + q] = trow;
         }
     }
-    __syncthreads();
+}
 
+// Plain lookup: a workgroup (128 threads) serves one (32-query tile, level): 15 KB of LDS, so many of them per CU hide the
+// latency of the strip reads.  Stage 2 interpolates vertically and writes the level's (2r+1)^2 output channels with
+// 128-byte contiguous segments per channel.
+template <int R>
+__global__ void __launch_bounds__(128)
+corr_lookup_kernel(const LookupArgs a) {
+    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2;
+    __shared__ float hbuf[ROWS * WIN * TQ];
+    __shared__ float tybuf[WIN * TQ];
+    __shared__ int rowbuf[WIN * TQ];
+    const int b = blockIdx.x / a.tiles_per_batch;
+    const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
+    const int l = blockIdx.y, tid = threadIdx.x;
+    lookup_stage1<R>(a, l, b, q0, tid, 128, hbuf, tybuf, rowbuf);
+    __syncthreads();
     const int CH = a.num_levels * WIN * WIN;
-    for (int o = tid; o < CH * TQ; o += 256) {
-        const int q = o % TQ, ch = o / TQ;
-        const int l = ch / (WIN * WIN), rem = ch % (WIN * WIN);
+    for (int o = tid; o < WIN * WIN * TQ; o += 128) {
+        const int q = o % TQ, rem = o / TQ;
         const int ax = rem / WIN, cy = rem % WIN;  // first window axis -> x offset, second -> y offset
         const int i = q0 + q;
         if (i < a.HW) {
-            const float ty = tybuf[(l * WIN + cy) * TQ + q];
-            const int r0 = rowbuf[(l * WIN + cy) * TQ + q];
-            const float top = hbuf[((l * ROWS + r0) * WIN + ax) * TQ + q];
-            const float bot = hbuf[((l * ROWS + r0 + 1) * WIN + ax) * TQ + q];
-            a.out[((long)b * CH + ch) * a.HW + i] = (1.0f - ty) * top + ty * bot;
+            const float ty = tybuf[cy * TQ + q];
+            const int r0 = rowbuf[cy * TQ + q];
+            const float top = hbuf[(r0 * WIN + ax) * TQ + q];
+            const float bot = hbuf[((r0 + 1) * WIN + ax) * TQ + q];
+            a.out[((long)b * CH + l * WIN * WIN + rem) * a.HW + i] = (1.0f - ty) * top + ty * bot;
+        }
+    }
+}
+
+// Lookup fused with the 1x1 convolution that consumes it: the window features never leave the chip.  RAFT's motion encoder
+// reads them in `convc1` (update.py:83-101: L*(2r+1)^2 -> Cout channels, + bias, ReLU); here that contraction runs level by
+// level on the bf16 matrix cores at fp32 accuracy, like the volume itself: out[b, n, query] = act(bias[n] + sum_l sum_k
+// W[n][l][k] * feature_l[k][query]) with every fp32 feature (and, once on the host side, every weight) split exactly into
+// three bf16 terms and the six largest cross products accumulated in fp32.
+// Per level: stage 1 as above; stage 2 writes the level's (2r+1)^2 features of the 32 queries to LDS as three bf16 planes in
+// operand order; then every wave multiplies them into the accumulators of its Cout / 4 output channels.  A store instruction
+// writes two whole 128-byte lines (32 consecutive queries of one output channel).
+struct ConvArgs {
+    const uint16_t* weight;   // [3 terms][Cout][L][KP] bf16: the convolution's weight regrouped per level, K zero-padded to KP
+    const float* bias;        // (Cout) or null
+    int cout, relu, kp;       // kp = round_up((2r+1)^2, 16)
+};
+
+template <int R>
+__global__ void __launch_bounds__(256)
+corr_lookup_conv_kernel(const LookupArgs a, const ConvArgs cv) {
+    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, KP = (WIN * WIN + 15) / 16 * 16;
+    __shared__ float hbuf[ROWS * WIN * TQ];
+    __shared__ float tybuf[WIN * TQ];
+    __shared__ int rowbuf[WIN * TQ];
+    __shared__ __attribute__((aligned(16))) uint16_t feat[3 * KP * TQ];   // [term][k / 8][query][k % 8]
+    const int b = blockIdx.x / a.tiles_per_batch;
+    const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, li = lane & 31;
+    const int per_wave = cv.cout / 4;   // output channels of this wave: per_wave / 32 tiles of 32
+    f32x16 acc[2];                      // cout <= 256
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int o = tid; o < 3 * KP * TQ / 2; o += 256) reinterpret_cast<unsigned*>(feat)[o] = 0u;   // the K padding stays zero
+    const long wterm = (long)cv.cout * a.num_levels * KP;   // elements between two terms of the packed weight
+    for (int l = 0; l < a.num_levels; ++l) {
+        lookup_stage1<R>(a, l, b, q0, tid, 256, hbuf, tybuf, rowbuf);
+        __syncthreads();
+        for (int o = tid; o < WIN * WIN * TQ; o += 256) {
+            const int q = o % TQ, rem = o / TQ;
+            const int ax = rem / WIN, cy = rem % WIN;
+            const float ty = tybuf[cy * TQ + q];
+            const int r0 = rowbuf[cy * TQ + q];
+            const float top = hbuf[(r0 * WIN + ax) * TQ + q];
+            const float bot = hbuf[((r0 + 1) * WIN + ax) * TQ + q];
+            const float x = (1.0f - ty) * top + ty * bot;
+            const unsigned hi = __float_as_uint(x);
+            const float r1 = x - __uint_as_float(hi & 0xffff0000u);
+            const unsigned mid = __float_as_uint(r1);
+            const float r2 = r1 - __uint_as_float(mid & 0xffff0000u);
+            const int at = ((rem >> 3) * TQ + q) * 8 + (rem & 7);
+            feat[at] = (uint16_t)(hi >> 16);
+            feat[KP * TQ + at] = (uint16_t)(mid >> 16);
+            feat[2 * KP * TQ + at] = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t * 32 >= per_wave) break;   // uniform
+            const uint16_t* wrow = cv.weight + ((long)(wave * per_wave + t * 32 + li) * a.num_levels + l) * KP + 8 * kg;
+#pragma unroll
+            for (int k0 = 0; k0 < KP; k0 += 16) {
+                const u32x4 wh = *reinterpret_cast<const u32x4*>(wrow + k0);
+                const u32x4 wm = *reinterpret_cast<const u32x4*>(wrow + wterm + k0);
+                const u32x4 wl = *reinterpret_cast<const u32x4*>(wrow + 2 * wterm + k0);
+                const uint16_t* fp = feat + (((k0 >> 3) + kg) * TQ + li) * 8;
+                const u32x4 fh = *reinterpret_cast<const u32x4*>(fp);
+                const u32x4 fm = *reinterpret_cast<const u32x4*>(fp + KP * TQ);
+                const u32x4 fl = *reinterpret_cast<const u32x4*>(fp + 2 * KP * TQ);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wl), as_bf16x8(fh), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fl), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fm), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fh), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fm), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fh), acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // hbuf / feat are rewritten by the next level
+    }
+    // C/D layout: col = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output channel)
+    const int i = q0 + li;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t * 32 >= per_wave) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = wave * per_wave + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            float v = acc[t][r] + (cv.bias ? cv.bias[n] : 0.f);
+            if (cv.relu) v = fmaxf(v, 0.f);
+            if (i < a.HW) a.out[((long)b * cv.cout + n) * a.HW + i] = v;
         }
     }
 }
 
 template <int R>
 int launch_lookup(const LookupArgs& a, hipStream_t stream) {
-    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2;
-    const size_t lds = (size_t)a.num_levels * (ROWS * WIN + 2 * WIN) * TQ * sizeof(float);
-    if (lds > 160 * 1024) return fail(ALO_ERR_UNSUPPORTED, "alo_corr_lookup: window too large for LDS");
-    auto kern = corr_lookup_kernel<R>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_lookup: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(kern, dim3(a.B * a.tiles_per_batch), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(corr_lookup_kernel<R>, dim3(a.B * a.tiles_per_batch, a.num_levels), dim3(128), 0, stream, a);
     return check_launch("alo_corr_lookup");
+}
+template <int R>
+int launch_lookup_conv(const LookupArgs& a, const ConvArgs& cv, hipStream_t stream) {
+    hipLaunchKernelGGL(corr_lookup_conv_kernel<R>, dim3(a.B * a.tiles_per_batch), dim3(256), 0, stream, a, cv);
+    return check_launch("alo_corr_lookup_conv1x1");
+}
+
+int fill_lookup_args(LookupArgs& a, const float* const* levels, const float* coords, float* out, int B, int H, int W, int radius,
+                     int num_levels, const char* what) {
+    ALO_REQUIRE(levels && coords && out, ALO_ERR_INVALID_ARGUMENT, "%s: null pointer argument", what);
+    ALO_REQUIRE(B > 0 && H > 0 && W > 0, ALO_ERR_INVALID_ARGUMENT, "%s: dimensions must be positive", what);
+    ALO_REQUIRE(radius >= 0 && radius <= 7, ALO_ERR_UNSUPPORTED, "%s: radius must be in [0,7], got %d", what, radius);
+    ALO_REQUIRE(num_levels >= 1 && num_levels <= kMaxPyr, ALO_ERR_INVALID_ARGUMENT,
+                "%s: num_levels must be in [1,%d], got %d", what, kMaxPyr, num_levels);
+    for (int l = 0; l < kMaxPyr; ++l) { a.lvl[l] = nullptr; a.h[l] = a.w[l] = 2; }
+    for (int l = 0; l < num_levels; ++l) {
+        ALO_REQUIRE(levels[l], ALO_ERR_INVALID_ARGUMENT, "%s: levels[%d] is null", what, l);
+        alo_corr_level_shape(H, W, l, &a.h[l], &a.w[l]);
+        ALO_REQUIRE(a.h[l] >= 2 && a.w[l] >= 2, ALO_ERR_INVALID_ARGUMENT,
+                    "%s: level %d is %dx%d; the reference divides by (size-1) and needs >= 2", what, l, a.h[l], a.w[l]);
+        a.lvl[l] = levels[l];
+    }
+    a.coords = coords;
+    a.out = out;
+    a.B = B;
+    a.HW = H * W;
+    a.num_levels = num_levels;
+    a.tiles_per_batch = (a.HW + TQ - 1) / TQ;
+    return ALO_OK;
 }
 
 }  // namespace
@@ -536,26 +654,8 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
 
 extern "C" int alo_corr_lookup(const float* const* levels, const float* coords, float* out, int B, int H, int W,
                                int radius, int num_levels, void* stream_) {
-    ALO_REQUIRE(levels && coords && out, ALO_ERR_INVALID_ARGUMENT, "alo_corr_lookup: null pointer argument");
-    ALO_REQUIRE(B > 0 && H > 0 && W > 0, ALO_ERR_INVALID_ARGUMENT, "alo_corr_lookup: dimensions must be positive");
-    ALO_REQUIRE(radius >= 0 && radius <= 7, ALO_ERR_UNSUPPORTED, "alo_corr_lookup: radius must be in [0,7], got %d", radius);
-    ALO_REQUIRE(num_levels >= 1 && num_levels <= kMaxPyr, ALO_ERR_INVALID_ARGUMENT,
-                "alo_corr_lookup: num_levels must be in [1,%d], got %d", kMaxPyr, num_levels);
     LookupArgs a;
-    for (int l = 0; l < kMaxPyr; ++l) { a.lvl[l] = nullptr; a.h[l] = a.w[l] = 2; }
-    for (int l = 0; l < num_levels; ++l) {
-        ALO_REQUIRE(levels[l], ALO_ERR_INVALID_ARGUMENT, "alo_corr_lookup: levels[%d] is null", l);
-        alo_corr_level_shape(H, W, l, &a.h[l], &a.w[l]);
-        ALO_REQUIRE(a.h[l] >= 2 && a.w[l] >= 2, ALO_ERR_INVALID_ARGUMENT,
-                    "alo_corr_lookup: level %d is %dx%d; the reference divides by (size-1) and needs >= 2", l, a.h[l], a.w[l]);
-        a.lvl[l] = levels[l];
-    }
-    a.coords = coords;
-    a.out = out;
-    a.B = B;
-    a.HW = H * W;
-    a.num_levels = num_levels;
-    a.tiles_per_batch = (a.HW + TQ - 1) / TQ;
+    if (int rc = fill_lookup_args(a, levels, coords, out, B, H, W, radius, num_levels, "alo_corr_lookup")) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     switch (radius) {
         case 0: return launch_lookup<0>(a, stream);
@@ -566,5 +666,26 @@ extern "C" int alo_corr_lookup(const float* const* levels, const float* coords, 
         case 5: return launch_lookup<5>(a, stream);
         case 6: return launch_lookup<6>(a, stream);
         default: return launch_lookup<7>(a, stream);
+    }
+}
+
+extern "C" int alo_corr_lookup_conv1x1_kpad(int radius) { return ((2 * radius + 1) * (2 * radius + 1) + 15) / 16 * 16; }
+
+extern "C" int alo_corr_lookup_conv1x1(const float* const* levels, const float* coords, const void* weight_packed, const float* bias,
+                                       float* out, int B, int H, int W, int radius, int num_levels, int cout, int relu,
+                                       void* stream_) {
+    const char* what = "alo_corr_lookup_conv1x1";
+    LookupArgs a;
+    if (int rc = fill_lookup_args(a, levels, coords, out, B, H, W, radius, num_levels, what)) return rc;
+    ALO_REQUIRE(weight_packed && ((uintptr_t)weight_packed & 15) == 0, ALO_ERR_INVALID_ARGUMENT, "%s: weight must be non-null and 16-byte aligned", what);
+    ALO_REQUIRE(cout > 0 && cout % 128 == 0 && cout <= 256, ALO_ERR_UNSUPPORTED, "%s: Cout must be 128 or 256, got %d", what, cout);
+    const ConvArgs cv{static_cast<const uint16_t*>(weight_packed), bias, cout, relu ? 1 : 0, alo_corr_lookup_conv1x1_kpad(radius)};
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    switch (radius) {
+        case 1: return launch_lookup_conv<1>(a, cv, stream);
+        case 2: return launch_lookup_conv<2>(a, cv, stream);
+        case 3: return launch_lookup_conv<3>(a, cv, stream);
+        case 4: return launch_lookup_conv<4>(a, cv, stream);
+        default: return fail(ALO_ERR_UNSUPPORTED, "%s: radius must be in [1,4], got %d", what, radius);
     }
 }

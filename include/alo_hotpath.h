@@ -209,6 +209,24 @@ int alo_corr_lookup(const float* const* levels, const float* coords, float* out,
                     int B, int H, int W, int radius, int num_levels, void* stream);
 
 /*
+ * The lookup above fused with the 1x1 convolution that consumes it in RAFT's motion encoder (update.py:83-101, `convc1`:
+ * L*(2r+1)^2 -> Cout channels, + bias, ReLU): the (B, L*(2r+1)^2, H, W) window features are never written.
+ *
+ *   out[b, n, y, x] = act( bias[n] + sum_k weight[n, k] * lookup[b, k, y, x] )
+ *
+ *   weight_packed  (3, Cout, L, KP) bf16: the convolution's (Cout, L*(2r+1)^2, 1, 1) fp32 weight regrouped per pyramid level (each
+ *                  level's (2r+1)^2 entries zero-padded to KP = alo_corr_lookup_conv1x1_kpad(radius)) and split exactly into three
+ *                  bf16 terms w = t0 + t1 + t2 (t0 = upper 16 bits of w, t1 = upper 16 bits of w - t0, t2 = the rest); 16-byte aligned
+ *   bias           (Cout) float32 or NULL;   relu != 0: act = max(., 0)
+ *   out            (B, Cout, H, W) float32, fully written
+ *   Cout in {128, 256}, 1 <= radius <= 4.  The contraction runs on the bf16 matrix cores at fp32 accuracy (features split the same
+ *   way on the fly, the six largest cross products accumulated in fp32).
+ */
+int alo_corr_lookup_conv1x1_kpad(int radius);
+int alo_corr_lookup_conv1x1(const float* const* levels, const float* coords, const void* weight_packed, const float* bias,
+                            float* out, int B, int H, int W, int radius, int num_levels, int cout, int relu, void* stream);
+
+/*
  * ---- Extensions: one-pass epilogues of the layers that call the attention op -------------------------------------------
  * The reference evaluates these as separate PyTorch ops; they have no counterpart in its native code.  Both read and
  * write every byte once; all pointers 16-byte aligned; dtype ALO_F32 or ALO_BF16 (arithmetic in fp32 either way).

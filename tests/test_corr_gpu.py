@@ -151,3 +151,33 @@ def test_batch_items_are_independent():
     for lvl in range(4):
         assert torch.equal(full.corr_pyramid[lvl][n:2 * n], solo.corr_pyramid[lvl])
     assert torch.equal(full(coords)[1], solo(coords[1:2])[0])
+
+
+@pytest.mark.parametrize("B,H,W,r,L,cout", [(2, 24, 32, 4, 4, 256), (1, 19, 23, 3, 4, 128), (1, 90, 160, 4, 4, 256)])
+def test_lookup_fused_with_the_1x1_convolution(B, H, W, r, L, cout):
+    """alo_corr_lookup_conv1x1 == relu(conv1x1(alo_corr_lookup)) (RAFT's motion encoder, update.py:83-101): the lookup is
+    pinned on the oracle above, the contraction here against a float64 product of the same features."""
+    gen = torch.Generator(device="cpu").manual_seed(H + cout)
+    f1 = torch.randn(B, 64, H, W, generator=gen).to(DEV)
+    f2 = torch.randn(B, 64, H, W, generator=gen).to(DEV)
+    levels = alo_hip.corr_build(f1, f2, L)
+    coords = coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 3.0
+    K = L * (2 * r + 1) ** 2
+    weight = (torch.randn(cout, K, 1, 1, generator=gen) / K ** 0.5).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    feats = alo_hip.corr_lookup(levels, coords, r)
+    want = torch.relu(torch.einsum("nk,bkhw->bnhw", weight.view(cout, K).double(), feats.double()) + bias.double()[None, :, None, None])
+    got = alo_hip.corr_lookup_conv1x1(levels, coords, weight, bias, r, relu=True)
+    assert got.shape == (B, cout, H, W) and got.dtype == torch.float32
+    assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    plain = alo_hip.corr_lookup_conv1x1(levels, coords, weight, None, r, relu=False)
+    want2 = torch.einsum("nk,bkhw->bnhw", weight.view(cout, K).double(), feats.double())
+    assert (plain.double() - want2).abs().max().item() <= 2e-5 * max(1.0, want2.abs().max().item())
+
+
+def test_corr_block_lookup_conv1x1_declines_what_the_kernel_does_not_cover():
+    f = torch.randn(1, 32, 16, 16, device=DEV)
+    blk = CorrBlock(f, f, radius=3)
+    conv = torch.nn.Conv2d(4 * 49, 96, 1).to(DEV)   # RAFT-small's convc1: 96 output channels
+    with torch.no_grad():
+        assert blk.lookup_conv1x1(coords_grid(1, 16, 16, device=DEV), conv.weight, conv.bias) is None

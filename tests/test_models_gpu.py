@@ -174,6 +174,25 @@ def test_graphed_forward_replays_the_eager_forward_bit_for_bit():
     assert len(graphed._graphs) == 1
 
 
+def test_raft_with_the_fused_lookup_convolution_matches_reference(golden):
+    """The motion encoder fed a deferred lookup (alo_corr_lookup_conv1x1: lookup + convc1 + ReLU in one kernel) reproduces
+    the reference's flow (G7) like the default path."""
+    g = golden("g7_raft.npz")
+    model = RAFT().eval()
+    model.load_state_dict(formula_state_dict(model.state_dict()))
+    model = model.to(DEV)
+    model.update_block.accepts_deferred_lookup = True
+    f1 = aloscene.Frame(t(g["img1"]).float(), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
+    f2 = aloscene.Frame(t(g["img2"]).float(), normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)
+    import alo_hip
+    with alo_hip.LaunchTimer() as timer, torch.no_grad():
+        outs = model(f1, f2, iters=4)
+    assert "corr_lookup_convc1" in timer.summary() and "corr_lookup" not in timer.summary()
+    flows = np.stack([o["flow"].cpu().numpy() for o in outs])
+    assert np.abs(flows - g["flow"]).max() <= 1e-3
+    assert np.abs(outs[-1]["hidden_state"].cpu().numpy() - g["hidden_last"]).max() <= 1e-3
+
+
 def test_graphed_forward_replays_raft(golden):
     """Two frame inputs + keyword options through one HIP graph: RAFT's iterations replay to the eager flow."""
     from alonet.common import GraphedForward
