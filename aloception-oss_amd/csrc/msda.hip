@@ -747,41 +747,39 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
 //
 // msda_bwd_kernel above scatters one 128-byte atomic row per (query, head, point, corner): 45.5 M rows per encoder-size
 // call, and the memory-side atomic units retire ~16 G rows/s — 2.9 of its 4.1 ms.  Queries that are neighbours in the image
-// sample overlapping pixels, so the sums can be formed on chip first.  Here a workgroup owns a SUPER-TILE of up to 64 queries
-// (an 8x8 block of one pyramid level when the queries are the pyramid's own pixels, Lq == S; 64 consecutive queries
-// otherwise) of ONE head; each of its 4 waves owns a sub-tile of 16 queries (a 4x4 quadrant):
+// sample overlapping pixels, so the sums can be formed on chip first.  Here ONE WAVE (a 64-thread workgroup, no block barrier
+// anywhere) owns a TILE of 16 queries of one head — a 4x4 block of one pyramid level when the queries are the pyramid's own
+// pixels (Lq == S: the encoder's self-attention), 16 consecutive queries otherwise:
 //   1. lane (query i, level l) turns its 4 sampling points into taps; the wave reduces the per-level bounding box of all its
 //      taps (the WINDOW) and writes the scalar weights w_corner * attn into a dense matrix A[window pixel][16 queries] in LDS:
 //      plain read-add-write, no LDS atomics — lane (i, l) is the only writer of column i of level l's rows.
-//   2. grad_value of the window is the dense product  dV[pixel][ch] = sum_q A[pixel][q] * grad_out[q][ch].  The windows of the
-//      4 sub-tiles overlap: the workgroup walks the rows of their common bounding box once, the 32-row blocks dealt round-robin
-//      to the waves, summing all four sub-tiles' contributions in the accumulators — ONE atomic row per touched pixel per
-//      super-tile (about 1/20 of the per-corner count).
+//   2. grad_value of the window is the dense product  dV[pixel][ch] = sum_q A[pixel][q] * grad_out[q][ch]  (32 window rows x
+//      32 channels per MFMA tile, K = the 16 queries): ONE atomic row per touched window pixel per tile instead of one per
+//      corner — about 1/5 of the per-corner count.
 //   3. the channel dot products every sample needs, d[pixel][q] = <value[pixel], grad_out[q]>, are the transposed dense
 //      product over the same window, the value rows going from memory straight into the matrix operand; D lands in the wave's
 //      LDS region in place of A and lane (i, l) picks its 16 corner values from there:
 //      grad_attn = sum_k w_k d_k,  grad_loc = attn * (W, H) * (...).
 // Both products run on the fp32 matrix instructions (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32 FMA chains).
-// Measured (profiles/r02_pmc_counters.md): the kernel is bound by VALU issue and load latency, the matrix pipe is < 10 % busy —
-// an exact three-way bf16 split of the operands (6 bf16 MFMAs instead of 8 fp32 ones, 2.7x less matrix time) was tried and
-// cost more in split arithmetic than it saved.
-// The wave's LDS region holds 310 window pixels; the levels are made resident in as many passes as it takes.  A level whose window does
-// not fit (queries of a coarse level looking at a fine one, decoder queries, arbitrary locations) takes the per-corner route of
-// msda_bwd_kernel for that level only: same results, old cost.
+// Tried and dropped (profiles/r02_msda_bwd.md): 4-wave workgroups that share a walk over the common bounding box of four tiles
+// (half the atomic rows, but two block barriers per pass: 0.89 against 0.78 ms); an exact three-way bf16 split of the operands
+// on the bf16 MFMAs (2.7x less matrix time, more split arithmetic than it saved: the kernel is bound by VALU issue and latency,
+// the matrix pipe is ~20 % busy); smaller LDS regions for 3-4 waves per SIMD (the register file spills first).
+// The wave's LDS region holds 310 window pixels; the levels are made resident in as many passes as it takes.  A level whose
+// window does not fit (queries of a coarse level looking at a fine one, decoder queries, arbitrary locations) takes the
+// per-corner route of msda_bwd_kernel for that level only: same results, old cost.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kTileWaves = 4;
-constexpr int kPxBudget = 310;                      // window pixels per wave resident in LDS at a time (64 B each): 2 workgroups / CU
+constexpr int kPxBudget = 310;                      // window pixels resident in LDS at a time (64 B each): 8 waves per CU
 constexpr int kWaveRegion = kPxBudget * 64;         // bytes
-constexpr int kBatch = 4;               // 16-row blocks of value rows in flight in stage 3
-constexpr int kTableEntry = 6;                      // {x0, y0, ww, wh, off, pass} per (wave, level)
-constexpr int kTileLds = kTileWaves * kWaveRegion + kTileWaves * 4 * kTableEntry * 4 + 16 + kTileWaves * 32 * 4;
+constexpr int kBatch = 4;                           // 16-row blocks of value rows in flight in stage 3
+constexpr int kTileLds = kWaveRegion + 32 * 4;      // + the pixel indices of one 32-row block
 
 struct TileDims {
     int S, M, Lq;
-    int pyramid;        // 1: Lq == S and the queries are tiled as 8x8 blocks of their level; 0: 64 consecutive queries
-    int n_super;        // super-tiles per batch item
-    int tile0[4];       // pyramid: first super-tile of each level
-    int tiles_w[4];     // pyramid: super-tiles per row of each level
+    int pyramid;        // 1: Lq == S and the queries are tiled as 4x4 blocks of their level; 0: 16 consecutive queries
+    int n_super;        // tiles per batch item
+    int tile0[4];       // pyramid: first tile of each level
+    int tiles_w[4];     // pyramid: tiles per row of each level
     unsigned nblocks;
 };
 
@@ -807,21 +805,19 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over each 32-
     return v;
 }
 
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64, 2)
 msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
                       const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
                       float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
                       const TileDims td) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float* region = reinterpret_cast<float*>(smem + wave * kWaveRegion);
-    int* table = reinterpret_cast<int*>(smem + kTileWaves * kWaveRegion);   // [wave][level]{x0, y0, ww, wh, off, pass}
-    int* npass_slot = table + kTileWaves * 4 * kTableEntry;                           // [wave] passes this wave needs
-    int* pixbuf = npass_slot + 4 + wave * 32;                               // [wave][32] pixel index of a block's rows
+    const int lane = threadIdx.x;
+    float* region = reinterpret_cast<float*>(smem);
+    int* pixbuf = reinterpret_cast<int*>(smem + kWaveRegion);               // [32] pixel index of a block's rows
 
     const unsigned lb = xcd_contiguous_block(blockIdx.x, td.nblocks);
     const int m = lb % td.M;
-    // super-tiles in reverse order: those of the coarse levels (whose queries look at wide windows of the fine levels and take
+    // tiles in reverse order: those of the coarse levels (whose queries look at wide windows of the fine levels and take
     // the per-corner route there) start first and overlap the many light ones instead of forming the tail
     const int st = td.n_super - 1 - (int)((lb / td.M) % td.n_super);
     const int b = lb / (td.M * td.n_super);
@@ -837,19 +833,19 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     const int trow = td.pyramid ? (st - td.tile0[lq]) / td.tiles_w[lq] : 0;
     const int tcol = td.pyramid ? (st - td.tile0[lq]) - trow * td.tiles_w[lq] : 0;
     const int Hq = shapes[2 * lq], Wq = shapes[2 * lq + 1], Sq = lstart[lq];
-    auto query_of = [&](int j, int i) -> int {   // sub-tile j, slot i -> query index, -1 past the edge
+    auto query_of = [&](int i) -> int {   // slot i of the tile -> query index, -1 past the edge
         if (td.pyramid) {
-            const int qy = trow * 8 + (j >> 1) * 4 + (i >> 2), qx = tcol * 8 + (j & 1) * 4 + (i & 3);
+            const int qy = trow * 4 + (i >> 2), qx = tcol * 4 + (i & 3);
             return (qy < Hq && qx < Wq) ? Sq + qy * Wq + qx : -1;
         }
-        const int q = st * 64 + j * 16 + i;
+        const int q = st * 16 + i;
         return q < Lq ? q : -1;
     };
     const long bq0 = (long)b * Lq;
 
     // ---- stage 1: taps and windows ------------------------------------------------------------------------------------------
     const int qi = lane >> 2, lev = lane & 3;
-    const int q_own = query_of(wave, qi);
+    const int q_own = query_of(qi);
     const bool live = q_own >= 0;
     const int Hl = shapes[2 * lev], Wl = shapes[2 * lev + 1];
     const long qm = (bq0 + (live ? q_own : 0)) * M + m;
@@ -861,16 +857,14 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     const f32x4 av = *reinterpret_cast<const f32x4*>(attn + (qm * 4 + lev) * 4);
     // grad_out rows of all four sub-tiles as B operands of the 32x32x2 product: lane (kg = lane >> 5, ch = lane & 31) holds
     // G_j[8 kg + s][ch], s = 0..7.  Issued behind the (smaller) location loads: their latency hides behind the tap arithmetic.
-    float G[4][8];
+    float G[8];
     {
         const float* gb = grad_out + (bq0 * M + m) * 32 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int q = query_of(j, 8 * (lane >> 5) + s);
-                G[j][s] = q >= 0 ? gb[(unsigned)(q * M) * 32u] : 0.f;
-            }
+        for (int s = 0; s < 8; ++s) {
+            const int q = query_of(8 * (lane >> 5) + s);
+            G[s] = q >= 0 ? gb[(unsigned)(q * M) * 32u] : 0.f;
+        }
     }
     {
         const float xs[4] = {l0[0], l0[2], l1[0], l1[2]}, ys[4] = {l0[1], l0[3], l1[1], l1[3]};
@@ -933,11 +927,6 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     const int my_pass = lev == 0 ? pass4[0] : (lev == 1 ? pass4[1] : (lev == 2 ? pass4[2] : pass4[3]));
     const int off = lev == 0 ? off4[0] : (lev == 1 ? off4[1] : (lev == 2 ? off4[2] : off4[3]));
     const bool any_corner_route = pass4[0] == 8 || pass4[1] == 8 || pass4[2] == 8 || pass4[3] == 8;
-    if (lane == 0) npass_slot[wave] = my_npass;
-    if (lane < 4) {
-        int* t = table + (wave * 4 + lane) * kTableEntry;
-        t[0] = x0; t[1] = y0; t[2] = ww; t[3] = wh; t[4] = off; t[5] = my_pass;
-    }
     int base[4];   // window row of the (h_low, w_low) corner; the others are +1, +ww, +ww+1
 #pragma unroll
     for (int p = 0; p < 4; ++p) base[p] = (h_low[p] - y0) * ww + (w_low[p] - x0);
@@ -946,7 +935,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     // the A operand uses the same (c, kg, s) -> channel map, so every channel meets itself
     f32x4 g4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     {
-        const int qb = query_of(wave, lane & 15);
+        const int qb = query_of(lane & 15);
         if (qb >= 0) {
             const float* gp = grad_out + ((bq0 + qb) * M + m) * 32 + 4 * (lane >> 4);
             g4[0] = *reinterpret_cast<const f32x4*>(gp);
@@ -956,8 +945,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
 
     float* gv_b = grad_value + (size_t)b * S * M * 32 + m * 32 + (lane & 31);
     const float* vb3 = value + (size_t)b * S * M * 32 + m * 32 + 4 * (lane >> 4);
-    int npass = 1;
-    for (int pass = 0; pass < npass; ++pass) {
+    for (int pass = 0; pass < my_npass; ++pass) {
         // ---- stage 1b: A of this pass's levels -------------------------------------------------------------------------------
         const bool mine = my_pass == pass;
         int used = 0;
@@ -975,8 +963,6 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                 const float w4[4] = {hh * hw * at[p], hh * lw[p] * at[p], lh[p] * hw * at[p], lh[p] * lw[p] * at[p]};
                 const int idx[4] = {base[p], base[p] + 1, base[p] + ww, base[p] + ww + 1};
                 float cur[4];
-                // the 4 corners of one point are 4 different pixels: independent read-add-writes; the next point of this lane may
-                // hit the same entries and is ordered behind these by the wave's in-order LDS queue
 #pragma unroll
                 for (int k = 0; k < 4; ++k) cur[k] = (flags[p] >> k) & 1u ? region[(off + idx[k]) * 16 + qi] : 0.f;
 #pragma unroll
@@ -984,80 +970,35 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                     if ((flags[p] >> k) & 1u) region[(off + idx[k]) * 16 + qi] = cur[k] + w4[k];
             }
         }
-        __syncthreads();
-        if (pass == 0) npass = max(max(npass_slot[0], npass_slot[1]), max(npass_slot[2], npass_slot[3]));
-        npass = __builtin_amdgcn_readfirstlane(npass);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- stage 2: grad_value over the windows -------------------------------------------------------------------------------
-        int deal = 0;   // 32-row blocks of merged walks are dealt round-robin to the waves across all levels
-#pragma unroll 1
-        for (int lv = 0; lv < 4; ++lv) {
-            int X0[4], Y0[4], WW[4], WH[4], OF[4];
-            int sx0 = 0x7fffffff, sy0 = 0x7fffffff, sx1 = -0x7fffffff, sy1 = -0x7fffffff, sum = 0;
+        // ---- stage 2: grad_value over the own windows ----------------------------------------------------------------------------
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int* t = table + (j * 4 + lv) * kTableEntry;
-                const bool on = __builtin_amdgcn_readfirstlane(t[5]) == pass;
-                WW[j] = on ? __builtin_amdgcn_readfirstlane(t[2]) : 0;
-                X0[j] = Y0[j] = WH[j] = OF[j] = 0;
-                if (WW[j]) {
-                    X0[j] = __builtin_amdgcn_readfirstlane(t[0]);
-                    Y0[j] = __builtin_amdgcn_readfirstlane(t[1]);
-                    WH[j] = __builtin_amdgcn_readfirstlane(t[3]);
-                    OF[j] = __builtin_amdgcn_readfirstlane(t[4]);
-                    sx0 = min(sx0, X0[j]); sy0 = min(sy0, Y0[j]);
-                    sx1 = max(sx1, X0[j] + WW[j] - 1); sy1 = max(sy1, Y0[j] + WH[j] - 1);
-                    sum += WW[j] * WH[j];
-                }
-            }
-            if (sum == 0) continue;
-            // windows that overlap or abut share one walk over their common bounding box (every sub-tile contributing to a block);
-            // windows far apart (no locality between the sub-tiles) are walked one per wave
-            const long sbox = (long)(sx1 - sx0 + 1) * (sy1 - sy0 + 1);
-            const bool merged = sbox <= 2L * sum;
-            const int own_w = wave == 0 ? WW[0] : (wave == 1 ? WW[1] : (wave == 2 ? WW[2] : WW[3]));
-            const int own_h = wave == 0 ? WH[0] : (wave == 1 ? WH[1] : (wave == 2 ? WH[2] : WH[3]));
-            const int own_x = wave == 0 ? X0[0] : (wave == 1 ? X0[1] : (wave == 2 ? X0[2] : X0[3]));
-            const int own_y = wave == 0 ? Y0[0] : (wave == 1 ? Y0[1] : (wave == 2 ? Y0[2] : Y0[3]));
-            const int rx0 = merged ? sx0 : own_x, ry0 = merged ? sy0 : own_y;
-            const int rw = merged ? sx1 - sx0 + 1 : own_w, rh = merged ? sy1 - sy0 + 1 : own_h;
-            const int nrows = __builtin_amdgcn_readfirstlane(rw * rh);
+        for (int lv = 0; lv < 4; ++lv) {
+            if (pass4[lv] != pass) continue;   // wave-uniform
+            const int wx0 = __builtin_amdgcn_readlane(x0, lv), wy0 = __builtin_amdgcn_readlane(y0, lv);
+            const int wwl = __builtin_amdgcn_readlane(ww, lv);
+            const int nrows = np4[lv], offl = off4[lv];
             const int nblk = (nrows + 31) >> 5;
-            const float inv_rw = 1.0f / (float)(rw > 0 ? rw : 1);
-            // merged: this wave takes the blocks whose deal number is its own
-            const int first = merged ? ((wave - deal) & 3) : 0, step = merged ? kTileWaves : 1;
-            if (merged) deal += nblk;
+            const float inv_ww = 1.0f / (float)wwl;
             const int Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
-            for (int blk = __builtin_amdgcn_readfirstlane(first); blk < nblk; blk += step) {
+            for (int blk = 0; blk < nblk; ++blk) {
                 const int r = blk * 32 + (lane & 31);
                 const bool rin = r < nrows;
-                // r / rw through the reciprocal: exact while rows * width < 2^20 ((r + 0.5) / rw is 0.5 / rw away from an integer)
-                const int ry = rin ? (int)(((float)r + 0.5f) * inv_rw) : 0, rx = rin ? r - ry * rw : 0;
-                const int gx = rx0 + rx, gy = ry0 + ry;
+                const int ry = rin ? (int)(((float)r + 0.5f) * inv_ww) : 0, rx = rin ? r - ry * wwl : 0;
+                const float* ap = region + (offl + r) * 16 + 8 * (lane >> 5);
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                if (rin) { a0 = *reinterpret_cast<const f32x4*>(ap); a1 = *reinterpret_cast<const f32x4*>(ap + 4); }
                 f32x16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                bool any = false;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!WW[j] || !(merged || j == wave)) continue;   // wave-uniform
-                    const int wx = gx - X0[j], wy = gy - Y0[j];
-                    const bool in = rin && wx >= 0 && wx < WW[j] && wy >= 0 && wy < WH[j];
-                    if (__ballot(in) == 0) continue;                  // wave-uniform
-                    any = true;
-                    const float* ap = reinterpret_cast<const float*>(smem + j * kWaveRegion) + (OF[j] + wy * WW[j] + wx) * 16 + 8 * (lane >> 5);
-                    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                    if (in) { a0 = *reinterpret_cast<const f32x4*>(ap); a1 = *reinterpret_cast<const f32x4*>(ap + 4); }
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], G[e], acc, 0, 0, 0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], G[j][e], acc, 0, 0, 0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], G[j][4 + e], acc, 0, 0, 0);
-                }
-                if (!any) continue;
-                // C/D layout: col = lane & 31 (channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): one atomic instruction =
-                // two whole 128-byte rows; rows nothing was scattered to hold exact zeros and are skipped.  The rows' pixel indices
-                // pass through 128 bytes of LDS (row -> the lanes of both halves)
-                const int pix = rin ? Slv + gy * Wlv + gx : -1;
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], G[4 + e], acc, 0, 0, 0);
+                const int pix = rin ? Slv + (wy0 + ry) * Wlv + wx0 + rx : -1;
                 if (lane < 32) pixbuf[lane] = pix;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1067,7 +1008,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                     const i32x4 pr4 = *reinterpret_cast<const i32x4*>(pixbuf + 8 * g + 4 * (lane >> 5));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float a = acc[4 * g + e];   // row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), reg = 4 g + e
+                        const float a = acc[4 * g + e];
                         if (pr4[e] >= 0 && a != 0.f)
                             unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gv_b) + (size_t)((unsigned)(pr4[e] * M) * 128u)), a);
                     }
@@ -1077,20 +1018,16 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
-        __syncthreads();   // every wave is done reading every A: the regions are re-used for D
 
         // ---- stage 3: d[pixel][q] = <value[pixel], grad_out[q]> over the own windows, then the per-sample gradients -----------------
-#pragma unroll 1
+#pragma unroll
         for (int lv = 0; lv < 4; ++lv) {
-            const int* t = table + (wave * 4 + lv) * kTableEntry;
-            if (__builtin_amdgcn_readfirstlane(t[5]) != pass) continue;   // wave-uniform
-            const int wx0 = __builtin_amdgcn_readfirstlane(t[0]), wy0 = __builtin_amdgcn_readfirstlane(t[1]);
-            const int wwl = __builtin_amdgcn_readfirstlane(t[2]), offl = __builtin_amdgcn_readfirstlane(t[4]);
-            const int nrows = wwl * __builtin_amdgcn_readfirstlane(t[3]);
+            if (pass4[lv] != pass) continue;   // wave-uniform
+            const int wx0 = __builtin_amdgcn_readlane(x0, lv), wy0 = __builtin_amdgcn_readlane(y0, lv);
+            const int wwl = __builtin_amdgcn_readlane(ww, lv);
+            const int nrows = np4[lv], offl = off4[lv];
             const int nblk = (nrows + 15) >> 4;
             const int Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
-            // value rows go from memory straight into the A operand: lane (row = lane & 15, kg = lane >> 4) takes channels
-            // 16 c + 4 kg .. + 3 of its row (two 16-byte loads); the rows of kBatch blocks are requested before the first product
             const float inv_ww = 1.0f / (float)wwl;
             for (int blk0 = 0; blk0 < nblk; blk0 += kBatch) {
                 f32x4 v[kBatch][2];
@@ -1112,7 +1049,6 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][c][e], g4[c][e], d, 0, 0, 0);
-                    // C/D layout: col = lane & 15 (query), row = 4 * (lane >> 4) + reg
                     const int row0 = (blk0 + u) * 16 + 4 * (lane >> 4);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg)
@@ -1447,10 +1383,11 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
         TileDims td;
         td.S = S; td.M = M; td.Lq = Lq;
         td.pyramid = 0;
-        td.n_super = (Lq + 63) / 64;
+        td.n_super = (Lq + 15) / 16;
         for (int l = 0; l < 4; ++l) { td.tile0[l] = 0; td.tiles_w[l] = 1; }
+        const int tile = 4;
         if (host_shapes && Lq == S) {
-            // queries = the pyramid's own pixels (encoder self-attention): 8x8 blocks of each level.  Only how queries are
+            // queries = the pyramid's own pixels (encoder self-attention): 4x4 blocks of each level.  Only how queries are
             // grouped depends on this; the kernel reads the geometry it computes with from the device copy.
             long total = 0;
             int tiles = 0;
@@ -1459,8 +1396,8 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
                 const int h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
                 ok = ok && h > 0 && w > 0;
                 td.tile0[l] = tiles;
-                td.tiles_w[l] = (w + 7) / 8;
-                tiles += ((h + 7) / 8) * ((w + 7) / 8);
+                td.tiles_w[l] = (w + tile - 1) / tile;
+                tiles += ((h + tile - 1) / tile) * ((w + tile - 1) / tile);
                 total += (long)h * w;
             }
             if (ok && total == S) { td.pyramid = 1; td.n_super = tiles; }
@@ -1477,7 +1414,7 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
         }
         void* targs[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &grad_out,
                          &grad_value, &grad_sampling_loc, &grad_attn_weight, &td};
-        hipError_t el = hipLaunchKernel(reinterpret_cast<const void*>(msda_bwd_tiled_kernel), dim3(td.nblocks), dim3(256),
+        hipError_t el = hipLaunchKernel(reinterpret_cast<const void*>(msda_bwd_tiled_kernel), dim3(td.nblocks), dim3(64),
                                         targs, kTileLds, stream);
         if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: %s", hipGetErrorString(el));
         return check_launch("alo_msda_backward");

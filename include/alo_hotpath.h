@@ -152,8 +152,8 @@ int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const in
 /*
  * The same operation with a scheduling hint: `host_spatial_shapes` is a HOST copy of spatial_shapes (L x 2 int32, may be NULL).
  * When the queries are the pyramid's own pixels (Lq == S, the encoder's self-attention) the fp32 D = 32, L = P = 4 kernel
- * then groups them as 8x8 blocks of their level instead of runs of 64 consecutive queries, so that the sampling windows of
- * a workgroup's queries overlap as much as possible (one atomic row per touched pixel per block).  Results do not depend on
+ * then groups them as 4x4 blocks of their level instead of runs of 16 consecutive queries, so that the sampling windows of
+ * a wave's 16 queries overlap as much as possible (one atomic row per touched pixel per tile).  Results do not depend on
  * the hint (up to the order of the floating-point additions, which atomics leave undefined anyway); alo_msda_backward is this
  * call with a NULL hint.
  */
