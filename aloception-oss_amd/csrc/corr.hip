@@ -376,12 +376,16 @@ __device__ __forceinline__ void lookup_stage1(const LookupArgs& a, int l, int b,
     }
 }
 
-// Plain lookup: a workgroup (128 threads) serves one (32-query tile, level): 15 KB of LDS, so many of them per CU hide the
-// latency of the strip reads.  Stage 2 interpolates vertically and writes the level's (2r+1)^2 output channels with
-// 128-byte contiguous segments per channel.
+// Plain lookup: a workgroup serves one (32-query tile, level) with one thread per (query, window-row) strip — every strip read
+// of the tile is in flight at once — and 15 KB of LDS, so several workgroups per CU overlap their memory latency.  Stage 2
+// interpolates vertically and writes the level's (2r+1)^2 output channels with 128-byte contiguous segments per channel.
 template <int R>
-__global__ void __launch_bounds__(128)
+constexpr int lookup_threads() { return ((2 * R + 3) * TQ + 63) / 64 * 64; }
+
+template <int R>
+__global__ void __launch_bounds__(lookup_threads<R>())
 corr_lookup_kernel(const LookupArgs a) {
+    constexpr int NT = lookup_threads<R>();
     constexpr int WIN = 2 * R + 1, ROWS = WIN + 2;
     __shared__ float hbuf[ROWS * WIN * TQ];
     __shared__ float tybuf[WIN * TQ];
@@ -389,10 +393,10 @@ corr_lookup_kernel(const LookupArgs a) {
     const int b = blockIdx.x / a.tiles_per_batch;
     const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
     const int l = blockIdx.y, tid = threadIdx.x;
-    lookup_stage1<R>(a, l, b, q0, tid, 128, hbuf, tybuf, rowbuf);
+    lookup_stage1<R>(a, l, b, q0, tid, NT, hbuf, tybuf, rowbuf);
     __syncthreads();
     const int CH = a.num_levels * WIN * WIN;
-    for (int o = tid; o < WIN * WIN * TQ; o += 128) {
+    for (int o = tid; o < WIN * WIN * TQ; o += NT) {
         const int q = o % TQ, rem = o / TQ;
         const int ax = rem / WIN, cy = rem % WIN;  // first window axis -> x offset, second -> y offset
         const int i = q0 + q;
@@ -500,7 +504,7 @@ corr_lookup_conv_kernel(const LookupArgs a, const ConvArgs cv) {
 
 template <int R>
 int launch_lookup(const LookupArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(corr_lookup_kernel<R>, dim3(a.B * a.tiles_per_batch, a.num_levels), dim3(128), 0, stream, a);
+    hipLaunchKernelGGL(corr_lookup_kernel<R>, dim3(a.B * a.tiles_per_batch, a.num_levels), dim3(lookup_threads<R>()), 0, stream, a);
     return check_launch("alo_corr_lookup");
 }
 template <int R>
