@@ -78,22 +78,25 @@ def parse():
                     help="also time K steps of PanopticHead over DeformableDETR-R50 (BASELINE configs[4]: --batch frames "
                          "per GPU, --panoptic-queries kept queries per frame); 0 = skip")
     ap.add_argument("--panoptic-queries", type=int, default=16)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 and the control collectives run on gloo — drives the N > 1 GPU branch "
+                         "(sharding, fences, max-over-ranks, DDP) on a one-GPU box; RCCL needs one device per rank")
     ap.add_argument("--selftest", action="store_true",
                     help="CPU/gloo dry run of the launch, sharding, fencing and max-over-ranks logic (no GPU, no kernels)")
     return ap.parse_args()
 
 
-def init_dist(n_gpus, on_gpu=True):
+def init_dist(n_gpus, on_gpu=True, share_gpu=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if n_gpus > 1 and world != n_gpus:
         raise SystemExit(f"--gpus {n_gpus} needs WORLD_SIZE={n_gpus} (launch with torch.distributed.run); got {world}")
     if on_gpu:
         torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_gpu:  # backend "nccl" is RCCL on ROCm; only the timing all-reduce and the barriers use it
+        if on_gpu and not share_gpu:  # backend "nccl" is RCCL on ROCm; only the timing all-reduce and the barriers use it
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -112,7 +115,7 @@ def fence(world):
 def max_over_ranks(seconds, world, device):
     if world == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -312,7 +315,7 @@ def main():
     a = parse()
     if a.selftest:
         return selftest(a)
-    rank, world, local = init_dist(a.gpus)
+    rank, world, local = init_dist(a.gpus, share_gpu=a.share_gpu)
     device = torch.device("cuda", local)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 

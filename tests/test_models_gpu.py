@@ -311,3 +311,27 @@ def test_config5_panoptic_at_per_gpu_size():
     assert out["pred_masks"].shape[:2] == (8, 16) and torch.isfinite(out["pred_masks"].float()).all()
     assert len(masks) == 8 and tuple(masks[0].shape) == (16, 800, 1333) and int(masks[0].as_tensor().sum(0).max()) <= 1
     assert boxes[0].shape == (16, 4)
+
+
+def test_bench_gpu_branch_with_two_ranks():
+    """The N > 1 branch of bench.py ON THE GPU (rank-seeded shards, barrier + synchronize fences, max over ranks, one JSON line
+    from rank 0): two ranks share the one GPU of this box (`--share-gpu`: control collectives on gloo, since RCCL wants one
+    device per rank).  The whole-job value must count both ranks' frames."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--raft-steps", "1", "--raft-warmup", "1", "--raft-batch", "1", "--train-steps", "0", "--panoptic-steps", "1",
+           "--no-cpu-baseline", "--share-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="4"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
+    assert abs(line["value"] - 2 * 2 * 3 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 1e-3
+    assert line["raft"]["value"] > 0 and line["panoptic"]["value"] > 0 and "cpu_baseline" not in line

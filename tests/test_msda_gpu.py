@@ -86,7 +86,8 @@ CASES = [  # (N, M, D, Lq, shapes, P)          which plan it exercises (fp32)
     (1, 2, 2, 2, [(6, 4), (3, 2)], 2),  # scalar path, group 8 (the reference test's D)
     (1, 2, 8, 13, [(7, 3)], 1),  # vec4 / group 4, L*P = 1
     (2, 8, 32, 454, [(16, 21), (8, 11), (4, 6), (2, 3)], 4),  # Lq == S: the tiled backward groups queries as 8x8 blocks
-    (1, 4, 32, 130, [(9, 13), (5, 7), (3, 4), (2, 2)], 4),  # tiled backward, 64-query runs with a ragged tail, 4 heads
+    (1, 4, 32, 130, [(9, 13), (5, 7), (3, 4), (2, 2)], 4),  # tiled backward, 16-query runs with a ragged tail, 4 heads
+    (1, 6, 32, 168, [(9, 13), (5, 7), (3, 4), (2, 2)], 4),  # tiled backward, Lq == S, a head count that is not a power of two
 ]
 
 
