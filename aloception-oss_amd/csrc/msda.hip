@@ -769,10 +769,12 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
 // window does not fit (queries of a coarse level looking at a fine one, decoder queries, arbitrary locations) takes the
 // per-corner route of msda_bwd_kernel for that level only: same results, old cost.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kPxBudget = 310;                      // window pixels resident in LDS at a time (64 B each): 8 waves per CU
+constexpr int kPxBudget = 300;                      // window pixels resident in LDS at a time (64 B each): 8 waves per CU
 constexpr int kWaveRegion = kPxBudget * 64;         // bytes
 constexpr int kBatch = 4;                           // 16-row blocks of value rows in flight in stage 3
-constexpr int kTileLds = kWaveRegion + 32 * 4;      // + the pixel indices of one 32-row block
+constexpr unsigned kDropped = 0xffffff00u;             // a byte offset past any frame slab: the buffer range check drops the lane
+constexpr int kRowTable = (kPxBudget + 31) / 32 * 32;   // byte offset (inside the frame's slab) of every resident window row
+constexpr int kTileLds = kWaveRegion + kRowTable * 4;   // 20480 bytes: 8 waves per CU
 
 struct TileDims {
     int S, M, Lq;
@@ -813,7 +815,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     float* region = reinterpret_cast<float*>(smem);
-    int* pixbuf = reinterpret_cast<int*>(smem + kWaveRegion);               // [32] pixel index of a block's rows
+    unsigned* rowoff = reinterpret_cast<unsigned*>(smem + kWaveRegion);               // [kRowTable]
 
     const unsigned lb = xcd_contiguous_block(blockIdx.x, td.nblocks);
     const int m = lb % td.M;
@@ -943,16 +945,53 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
         }
     }
 
-    float* gv_b = grad_value + (size_t)b * S * M * 32 + m * 32 + (lane & 31);
-    const float* vb3 = value + (size_t)b * S * M * 32 + m * 32 + 4 * (lane >> 4);
+    // wave-uniform slab bases + 32-bit per-lane byte offsets: the address arithmetic of every gather / atomic is one v_mad
+    char* gv_b = reinterpret_cast<char*>(grad_value + (size_t)b * S * M * 32 + m * 32);
+    const char* vb3 = reinterpret_cast<const char*>(value + (size_t)b * S * M * 32 + m * 32);
+    const __amdgpu_buffer_rsrc_t gv_rsrc = __builtin_amdgcn_make_buffer_rsrc(gv_b, 0, (int)((unsigned)(S * M - m) * 128u), 0x00020000);
+    const unsigned gv_lane = (unsigned)(lane & 31) * 4u, v_lane = (unsigned)(lane >> 4) * 16u, row_b = (unsigned)M * 128u;
+    // window geometry of the four levels as wave-uniform scalars
+    int sx0[4], sy0[4], sww[4], sW[4], sS[4];
+    float sinv[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        sx0[l] = __builtin_amdgcn_readlane(x0, l);
+        sy0[l] = __builtin_amdgcn_readlane(y0, l);
+        sww[l] = __builtin_amdgcn_readlane(ww, l);
+        sW[l] = shapes[2 * l + 1];
+        sS[l] = lstart[l];
+        // (r + 0.5) * sinv is at least 0.5 / ww away from an integer (ww <= kPxBudget): the rounding of rcp cannot move its floor
+        sinv[l] = __builtin_amdgcn_rcpf((float)max(sww[l], 1));
+    }
     for (int pass = 0; pass < my_npass; ++pass) {
-        // ---- stage 1b: A of this pass's levels -------------------------------------------------------------------------------
+        // ---- stage 1b: A of this pass's levels; the levels' windows are stacked in the region, rows [off4[l], off4[l] + np4[l]) -----
         const bool mine = my_pass == pass;
         int used = 0;
 #pragma unroll
         for (int l = 0; l < 4; ++l)
             if (pass4[l] == pass) used = off4[l] + np4[l];
+        const int used32 = (used + 31) & ~31;
         for (int o = lane * 4; o < used * 16; o += 256) *reinterpret_cast<f32x4*>(region + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+        // where every stacked row lives in the frame (a byte offset inside the (b, head) slab); the tail of the last 32-row block
+        // gets an offset the buffer range check drops
+        for (int r = lane; r < used32; r += 64) {
+            int lo = 0, wx = 0, wy = 0, wwl = 1, Wv = 0, Sv = 0;
+            float inv = 1.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in_k = pass4[k] == pass && r >= off4[k];   // levels are stacked in order: the last match owns the row
+                lo = in_k ? off4[k] : lo;
+                wx = in_k ? sx0[k] : wx;
+                wy = in_k ? sy0[k] : wy;
+                wwl = in_k ? sww[k] : wwl;
+                Wv = in_k ? sW[k] : Wv;
+                Sv = in_k ? sS[k] : Sv;
+                inv = in_k ? sinv[k] : inv;
+            }
+            const int rl = r - lo;
+            const int ry = (int)(((float)rl + 0.5f) * inv), rx = rl - ry * wwl;
+            rowoff[r] = r < used ? (unsigned)(Sv + (wy + ry) * Wv + wx + rx) * row_b : kDropped;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -974,86 +1013,59 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- stage 2: grad_value over the own windows ----------------------------------------------------------------------------
+        // ---- stage 2: grad_value of the stacked rows, 32 at a time -----------------------------------------------------------------
+        // (rows of the last block past `used` multiply whatever the region holds there: each output row depends on its own A row
+        // only, and theirs are dropped)
+        for (int blk = 0; blk < (used32 >> 5); ++blk) {
+            const float* ap = region + (blk * 32 + (lane & 31)) * 16 + 8 * (lane >> 5);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+            u32x4 po[4];
 #pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            if (pass4[lv] != pass) continue;   // wave-uniform
-            const int wx0 = __builtin_amdgcn_readlane(x0, lv), wy0 = __builtin_amdgcn_readlane(y0, lv);
-            const int wwl = __builtin_amdgcn_readlane(ww, lv);
-            const int nrows = np4[lv], offl = off4[lv];
-            const int nblk = (nrows + 31) >> 5;
-            const float inv_ww = 1.0f / (float)wwl;
-            const int Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
-            for (int blk = 0; blk < nblk; ++blk) {
-                const int r = blk * 32 + (lane & 31);
-                const bool rin = r < nrows;
-                const int ry = rin ? (int)(((float)r + 0.5f) * inv_ww) : 0, rx = rin ? r - ry * wwl : 0;
-                const float* ap = region + (offl + r) * 16 + 8 * (lane >> 5);
-                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                if (rin) { a0 = *reinterpret_cast<const f32x4*>(ap); a1 = *reinterpret_cast<const f32x4*>(ap + 4); }
-                f32x16 acc;
+            for (int g = 0; g < 4; ++g) po[g] = *reinterpret_cast<const u32x4*>(rowoff + blk * 32 + 8 * g + 4 * (lane >> 5));
+            f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], G[e], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], G[e], acc, 0, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], G[4 + e], acc, 0, 0, 0);
-                const int pix = rin ? Slv + (wy0 + ry) * Wlv + wx0 + rx : -1;
-                if (lane < 32) pixbuf[lane] = pix;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], G[4 + e], acc, 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const i32x4 pr4 = *reinterpret_cast<const i32x4*>(pixbuf + 8 * g + 4 * (lane >> 5));
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = acc[4 * g + e];
-                        if (pr4[e] >= 0 && a != 0.f)
-                            unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(gv_b) + (size_t)((unsigned)(pr4[e] * M) * 128u)), a);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    // no exec juggling: lanes with nothing to add (untouched rows hold exact zeros) aim past the slab
+                    const float a = acc[4 * g + e];
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(a, gv_rsrc, a != 0.f ? (po[g][e] | gv_lane) : kDropped, 0, 0);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
         }
 
-        // ---- stage 3: d[pixel][q] = <value[pixel], grad_out[q]> over the own windows, then the per-sample gradients -----------------
+        // ---- stage 3: d[row][q] = <value[row], grad_out[q]> over the stacked rows, then the per-sample gradients -------------------
+        for (int blk0 = 0; blk0 < ((used + 15) >> 4); blk0 += kBatch) {
+            f32x4 v[kBatch][2];
 #pragma unroll
-        for (int lv = 0; lv < 4; ++lv) {
-            if (pass4[lv] != pass) continue;   // wave-uniform
-            const int wx0 = __builtin_amdgcn_readlane(x0, lv), wy0 = __builtin_amdgcn_readlane(y0, lv);
-            const int wwl = __builtin_amdgcn_readlane(ww, lv);
-            const int nrows = np4[lv], offl = off4[lv];
-            const int nblk = (nrows + 15) >> 4;
-            const int Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
-            const float inv_ww = 1.0f / (float)wwl;
-            for (int blk0 = 0; blk0 < nblk; blk0 += kBatch) {
-                f32x4 v[kBatch][2];
-#pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const int r = (blk0 + u) * 16 + (lane & 15);
-                    const bool rin = r < nrows;
-                    const int ry = rin ? (int)(((float)r + 0.5f) * inv_ww) : 0, rx = rin ? r - ry * wwl : 0;
-                    const float* vp = vb3 + (size_t)(unsigned)((Slv + (wy0 + ry) * Wlv + wx0 + rx) * M) * 32u;
-                    v[u][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    v[u][1] = v[u][0];
-                    if (rin) { v[u][0] = *reinterpret_cast<const f32x4*>(vp); v[u][1] = *reinterpret_cast<const f32x4*>(vp + 16); }
+            for (int u = 0; u < kBatch; ++u) {
+                const int r = (blk0 + u) * 16 + (lane & 15);
+                v[u][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                v[u][1] = v[u][0];
+                if (r < used) {
+                    const float* vp = reinterpret_cast<const float*>(vb3 + (rowoff[r] + v_lane));
+                    v[u][0] = *reinterpret_cast<const f32x4*>(vp);
+                    v[u][1] = *reinterpret_cast<const f32x4*>(vp + 16);
                 }
+            }
+            // (stage 2 has read every A row before the first D row lands: one wave, LDS in order)
 #pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    if ((blk0 + u) * 16 >= nrows) break;   // wave-uniform
-                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < kBatch; ++u) {
+                if ((blk0 + u) * 16 >= used) break;   // wave-uniform
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][c][e], g4[c][e], d, 0, 0, 0);
-                    const int row0 = (blk0 + u) * 16 + 4 * (lane >> 4);
+                    for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][c][e], g4[c][e], d, 0, 0, 0);
+                const int row0 = (blk0 + u) * 16 + 4 * (lane >> 4);
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (row0 + reg < nrows) region[(offl + row0 + reg) * 16 + (lane & 15)] = d[reg];
-                }
+                for (int reg = 0; reg < 4; ++reg)
+                    if (row0 + reg < used) region[(row0 + reg) * 16 + (lane & 15)] = d[reg];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1378,7 +1390,7 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
     const bool aligned = (((uintptr_t)value | (uintptr_t)grad_out) & 15) == 0;
     const bool all_aligned = aligned && (((uintptr_t)sampling_loc | (uintptr_t)attn_weight | (uintptr_t)grad_value |
                                           (uintptr_t)grad_sampling_loc | (uintptr_t)grad_attn_weight) & 15) == 0;
-    if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && all_aligned && (double)S * M * 32 < 2.0e9) {
+    if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && all_aligned && (double)S * M * 128 < 4.0e9 && (double)Lq * M * 32 < 2.0e9) {   // 32-bit byte offsets inside one frame
         // the DETR-family shape: tiled, window-dense backward on the fp32 matrix cores (msda_bwd_tiled_kernel)
         TileDims td;
         td.S = S; td.M = M; td.Lq = Lq;
