@@ -535,7 +535,8 @@ def corr_lookup_conv1x1(levels, coords, weight, bias=None, radius=4, relu=True):
             top = (rest.view(torch.int32) & -65536).view(torch.float32)
             terms.append((top.view(torch.int32) >> 16).to(torch.int16))
             rest = rest - top
-        w2 = torch.stack(terms).contiguous()
+        # matrix-operand order (include/alo_hotpath.h): (term, level, k-step, 32-channel tile, kg, channel in tile, 8 entries)
+        w2 = torch.stack(terms).reshape(3, cout // 32, 32, L, kp // 16, 2, 8).permute(0, 3, 4, 1, 5, 2, 6).contiguous()
         hit = (tag, w2)
         weight._alo_packed = hit
     w2 = hit[1]

@@ -289,90 +289,118 @@ __device__ __forceinline__ float round_trip(float p, int size) {
     return ((gnorm + 1.0f) / 2.0f) * s;
 }
 
-// Stage 1 of the lookup for ONE pyramid level and TQ consecutive queries: every (query, window-row) strip of 2r+3 taps is read
-// once and interpolated horizontally into `hbuf` [ROWS][WIN][TQ]; `tybuf` / `rowbuf` [WIN][TQ] receive the vertical fraction
-// and the upper staged row of each tap row.
+// Stage 1 of the lookup, split in two so that a thread can have several strips in flight: `strip_request` turns one (query,
+// level, window row) into the strip's position and ISSUES its loads; `strip_finish` interpolates the strip horizontally into
+// `hbuf` [ROWS][WIN][TQ] and leaves the vertical fraction / upper staged row of the tap row in `tybuf` / `rowbuf` [WIN][TQ].
+//
+// A window of WIN x WIN taps spaced one pixel apart touches a (WIN+1)^2 footprint.  Every tap position goes through the
+// reference's fp32 round trip on its own, so floor(x_k) may come out as floor(x_0) + k - 1 or + k + 1 when x sits within an ulp
+// of an integer; one spare row and column (ROWS = COLS = WIN + 2) lets such taps shift by one.
 template <int R>
-__device__ __forceinline__ void lookup_stage1(const LookupArgs& a, int l, int b, int q0, int tid, int nthreads, float* hbuf,
-                                              float* tybuf, int* rowbuf) {
-    // A window of WIN x WIN taps spaced one pixel apart touches a (WIN+1)^2 footprint.  Every tap position goes through
-    // the reference's fp32 round trip on its own, so floor(x_k) may come out as floor(x_0) + k - 1 or + k + 1 when x sits
-    // within an ulp of an integer; one spare row and column (ROWS = COLS = WIN + 2) lets such taps shift by one.
-    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, COLS = WIN + 2;
+struct Strip {
+    static constexpr int COLS = 2 * R + 3, NV = (COLS + 3) / 4;
+    f32x4 raw[NV];      // the strip's taps when mode == 1
+    float cx, cy;       // the query's coordinates on this level
+    int xb, yb;         // floor of the window's first tap
+    int mode;           // 0: nothing to read (all zero), 1: taps are in raw, 2: scalar path (edge strips), -1: query past the end
+    const float* src;   // mode 2: the map row the strip lies in
+};
+
+template <int R>
+__device__ __forceinline__ void strip_request(const LookupArgs& a, int l, int b, int i, int row, Strip<R>& s) {
+    constexpr int COLS = Strip<R>::COLS, NV = Strip<R>::NV;
     const int h = a.h[l], w = a.w[l];
     const float inv = 1.0f / (float)(1 << l);
-    for (int item = tid; item < ROWS * TQ; item += nthreads) {
-        const int q = item % TQ;
-        const int row = item / TQ;
-        const int i = q0 + q;
-        float hv[WIN];
 #pragma unroll
-        for (int k = 0; k < WIN; ++k) hv[k] = 0.f;
-        float ty = 0.f;
-        int trow = row < WIN ? row : 0;
-        if (i < a.HW) {
-            const float cx = a.coords[((long)b * 2 + 0) * a.HW + i] * inv;  // exact: power-of-two scale
-            const float cy = a.coords[((long)b * 2 + 1) * a.HW + i] * inv;
-            const float iy0 = round_trip(cy - (float)R, h);
-            const float ix0 = round_trip(cx - (float)R, w);
-            if (fabsf(iy0) < 1e6f && fabsf(ix0) < 1e6f) {  // false for NaN too: such queries read as all-zero
-                const int yb = (int)floorf(iy0), xb = (int)floorf(ix0);
-                const int ry = yb + row;
-                if (row < WIN) {
-                    const float iy = round_trip(cy + (float)(row - R), h);
-                    const float fy = floorf(iy);
-                    int d = (int)fy - (yb + row);
-                    d = d < -1 ? -1 : (d > 1 ? 1 : d);
-                    if (row == 0) d = 0;
-                    trow = row + d;
-                    ty = iy - (float)(yb + trow);
-                }
-                if (ry >= 0 && ry < h && xb + COLS > 0 && xb < w) {
-                    // the strip's COLS taps as 16-byte loads from an arbitrary 4-byte aligned start instead of COLS scalar
-                    // loads: every load instruction of a wave touches 64 different lines here (one strip per lane, strips
-                    // 4*h*w bytes apart), so the instruction count is what the L1 is charged for.  Strips that hang off the
-                    // left edge of the map or would read past the batch item's slab take the scalar path (rare).
-                    const long e0 = (long)i * h * w + (long)ry * w + xb;  // element offset of tap 0 inside the slab
-                    float v[COLS];
-                    constexpr int NV = (COLS + 3) / 4;
-                    if (xb >= 0 && e0 + 4 * NV <= (long)a.HW * h * w) {
-                        const float* src = a.lvl[l] + (long)b * a.HW * ((long)h * w) + e0;
-                        f32x4 raw[NV];
+    for (int j = 0; j < NV; ++j) s.raw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s.cx = s.cy = 0.f;
+    s.xb = s.yb = 0;
+    s.src = nullptr;
+    s.mode = -1;
+    if (i >= a.HW) return;
+    s.mode = 0;
+    s.cx = a.coords[((long)b * 2 + 0) * a.HW + i] * inv;  // exact: power-of-two scale
+    s.cy = a.coords[((long)b * 2 + 1) * a.HW + i] * inv;
+    const float iy0 = round_trip(s.cy - (float)R, h);
+    const float ix0 = round_trip(s.cx - (float)R, w);
+    if (!(fabsf(iy0) < 1e6f && fabsf(ix0) < 1e6f)) {  // NaN too: such queries read as all-zero
+        s.mode = -1;
+        return;
+    }
+    s.yb = (int)floorf(iy0);
+    s.xb = (int)floorf(ix0);
+    const int ry = s.yb + row;
+    if (ry >= 0 && ry < h && s.xb + COLS > 0 && s.xb < w) {
+        // the strip's COLS taps as 16-byte loads from an arbitrary 4-byte aligned start instead of COLS scalar loads: every
+        // load instruction of a wave touches 64 different lines here (one strip per lane, strips 4*h*w bytes apart), so the
+        // instruction count is what the L1 is charged for.  Strips that hang off the left edge of the map or would read past
+        // the batch item's slab take the scalar path (rare).
+        const long e0 = (long)i * h * w + (long)ry * w + s.xb;  // element offset of tap 0 inside the slab
+        if (s.xb >= 0 && e0 + 4 * NV <= (long)a.HW * h * w) {
+            const float* src = a.lvl[l] + (long)b * a.HW * ((long)h * w) + e0;
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) {
-                            typedef f32x4 __attribute__((aligned(4))) f32x4_u;  // 4-byte aligned vector load
-                            raw[j] = *reinterpret_cast<const f32x4_u*>(src + 4 * j);
-                        }
+            for (int j = 0; j < NV; ++j) {
+                typedef f32x4 __attribute__((aligned(4))) f32x4_u;  // 4-byte aligned vector load
+                s.raw[j] = *reinterpret_cast<const f32x4_u*>(src + 4 * j);
+            }
+            s.mode = 1;
+        } else {
+            s.src = a.lvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
+            s.mode = 2;
+        }
+    }
+}
+
+template <int R>
+__device__ __forceinline__ void strip_finish(const LookupArgs& a, int l, int row, int q, const Strip<R>& s, float* hbuf, float* tybuf,
+                                             int* rowbuf) {
+    constexpr int WIN = 2 * R + 1, COLS = Strip<R>::COLS;
+    const int h = a.h[l], w = a.w[l];
+    float hv[WIN];
 #pragma unroll
-                        for (int k = 0; k < COLS; ++k) v[k] = (xb + k < w) ? raw[k / 4][k % 4] : 0.f;
-                    } else {
-                        const float* src = a.lvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
+    for (int k = 0; k < WIN; ++k) hv[k] = 0.f;
+    float ty = 0.f;
+    int trow = row < WIN ? row : 0;
+    if (s.mode >= 0) {
+        if (row < WIN) {
+            const float iy = round_trip(s.cy + (float)(row - R), h);
+            const float fy = floorf(iy);
+            int d = (int)fy - (s.yb + row);
+            d = d < -1 ? -1 : (d > 1 ? 1 : d);
+            if (row == 0) d = 0;
+            trow = row + d;
+            ty = iy - (float)(s.yb + trow);
+        }
+        if (s.mode > 0) {
+            float v[COLS];
+            if (s.mode == 1) {
 #pragma unroll
-                        for (int k = 0; k < COLS; ++k) {
-                            const int x = xb + k;
-                            v[k] = (x >= 0 && x < w) ? src[x] : 0.f;
-                        }
-                    }
+                for (int k = 0; k < COLS; ++k) v[k] = (s.xb + k < w) ? s.raw[k / 4][k % 4] : 0.f;
+            } else {
 #pragma unroll
-                    for (int k = 0; k < WIN; ++k) {
-                        const float ix = round_trip(cx + (float)(k - R), w);
-                        int d = (int)floorf(ix) - (xb + k);
-                        d = (k == 0) ? 0 : (d < -1 ? -1 : (d > 1 ? 1 : d));
-                        const float lo = d == 0 ? v[k] : (d > 0 ? v[k + 1] : v[k > 0 ? k - 1 : 0]);
-                        const float hi = d == 0 ? v[k + 1] : (d > 0 ? v[k + 2] : v[k]);
-                        const float tx = ix - (float)(xb + k + d);
-                        hv[k] = (1.0f - tx) * lo + tx * hi;
-                    }
+                for (int k = 0; k < COLS; ++k) {
+                    const int x = s.xb + k;
+                    v[k] = (x >= 0 && x < w) ? s.src[x] : 0.f;
                 }
             }
-        }
-        float* dst = hbuf + (row * WIN) * TQ + q;
 #pragma unroll
-        for (int k = 0; k < WIN; ++k) dst[k * TQ] = hv[k];
-        if (row < WIN) {
-            tybuf[row * TQ + q] = ty;
-            rowbuf[row * TQ + q] = trow;
+            for (int k = 0; k < WIN; ++k) {
+                const float ix = round_trip(s.cx + (float)(k - R), w);
+                int d = (int)floorf(ix) - (s.xb + k);
+                d = (k == 0) ? 0 : (d < -1 ? -1 : (d > 1 ? 1 : d));
+                const float lo = d == 0 ? v[k] : (d > 0 ? v[k + 1] : v[k > 0 ? k - 1 : 0]);
+                const float hi = d == 0 ? v[k + 1] : (d > 0 ? v[k + 2] : v[k]);
+                const float tx = ix - (float)(s.xb + k + d);
+                hv[k] = (1.0f - tx) * lo + tx * hi;
+            }
         }
+    }
+    float* dst = hbuf + (row * WIN) * TQ + q;
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) dst[k * TQ] = hv[k];
+    if (row < WIN) {
+        tybuf[row * TQ + q] = ty;
+        rowbuf[row * TQ + q] = trow;
     }
 }
 
@@ -393,7 +421,11 @@ corr_lookup_kernel(const LookupArgs a) {
     const int b = blockIdx.x / a.tiles_per_batch;
     const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
     const int l = blockIdx.y, tid = threadIdx.x;
-    lookup_stage1<R>(a, l, b, q0, tid, NT, hbuf, tybuf, rowbuf);
+    if (tid < ROWS * TQ) {
+        Strip<R> s;
+        strip_request<R>(a, l, b, q0 + tid % TQ, tid / TQ, s);
+        strip_finish<R>(a, l, tid / TQ, tid % TQ, s, hbuf, tybuf, rowbuf);
+    }
     __syncthreads();
     const int CH = a.num_levels * WIN * WIN;
     for (int o = tid; o < WIN * WIN * TQ; o += NT) {
@@ -419,83 +451,129 @@ corr_lookup_kernel(const LookupArgs a) {
 // operand order; then every wave multiplies them into the accumulators of its Cout / 4 output channels.  A store instruction
 // writes two whole 128-byte lines (32 consecutive queries of one output channel).
 struct ConvArgs {
-    const uint16_t* weight;   // [3 terms][Cout][L][KP] bf16: the convolution's weight regrouped per level, K zero-padded to KP
+    const uint16_t* weight;   // [3 terms][L][KP / 16][Cout / 32][64 lanes][8] bf16: the convolution's weight regrouped per level
+                              // (K zero-padded to KP) in the order the matrix operand is loaded: lane = 32 * kg + i holds
+                              // W[32 * tile + i][level][16 * kstep + 8 * kg + 0..7]
     const float* bias;        // (Cout) or null
     int cout, relu, kp;       // kp = round_up((2r+1)^2, 16)
 };
 
+// a workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+constexpr int kConvThreads = 512;
+constexpr int kConvLevels = 4;   // pyramid levels whose strips are in flight together
+
 template <int R>
-__global__ void __launch_bounds__(256)
+struct ConvLds {
+    static constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, KP = (WIN * WIN + 15) / 16 * 16;
+    static constexpr int hbuf_floats = ROWS * WIN * TQ, meta = WIN * TQ;
+    static constexpr size_t bytes = (size_t)kConvLevels * (hbuf_floats * 4 + meta * 8) + (size_t)3 * KP * TQ * 2;
+};
+
+template <int R>
+__global__ void __launch_bounds__(kConvThreads, 4)
 corr_lookup_conv_kernel(const LookupArgs a, const ConvArgs cv) {
-    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, KP = (WIN * WIN + 15) / 16 * 16;
-    __shared__ float hbuf[ROWS * WIN * TQ];
-    __shared__ float tybuf[WIN * TQ];
-    __shared__ int rowbuf[WIN * TQ];
-    __shared__ __attribute__((aligned(16))) uint16_t feat[3 * KP * TQ];   // [term][k / 8][query][k % 8]
+    using Lds = ConvLds<R>;
+    constexpr int WIN = Lds::WIN, ROWS = Lds::ROWS, KP = Lds::KP, NT = kConvThreads;
+    constexpr int ITEMS = ROWS * TQ;                                  // strips of one level
+    constexpr int SLOTS = (kConvLevels * ITEMS + NT - 1) / NT;       // strips a thread has in flight
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* hbuf = reinterpret_cast<float*>(smem);                                   // [kConvLevels][ROWS][WIN][TQ]
+    float* tybuf = hbuf + kConvLevels * Lds::hbuf_floats;                           // [kConvLevels][WIN][TQ]
+    int* rowbuf = reinterpret_cast<int*>(tybuf + kConvLevels * Lds::meta);
+    uint16_t* feat = reinterpret_cast<uint16_t*>(rowbuf + kConvLevels * Lds::meta);   // [term][k / 8][query][k % 8]
     const int b = blockIdx.x / a.tiles_per_batch;
     const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, li = lane & 31;
-    const int per_wave = cv.cout / 4;   // output channels of this wave: per_wave / 32 tiles of 32
-    f32x16 acc[2];                      // cout <= 256
+    const bool multiplies = wave * 32 < cv.cout;   // one 32-channel tile per wave: 8 waves for Cout = 256, 4 for 128
+    f32x16 acc;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int o = tid; o < 3 * KP * TQ / 2; o += 256) reinterpret_cast<unsigned*>(feat)[o] = 0u;   // the K padding stays zero
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int o = tid; o < 3 * KP * TQ / 2; o += NT) reinterpret_cast<unsigned*>(feat)[o] = 0u;   // the K padding stays zero
     const long wterm = (long)cv.cout * a.num_levels * KP;   // elements between two terms of the packed weight
-    for (int l = 0; l < a.num_levels; ++l) {
-        lookup_stage1<R>(a, l, b, q0, tid, 256, hbuf, tybuf, rowbuf);
-        __syncthreads();
-        for (int o = tid; o < WIN * WIN * TQ; o += 256) {
-            const int q = o % TQ, rem = o / TQ;
-            const int ax = rem / WIN, cy = rem % WIN;
-            const float ty = tybuf[cy * TQ + q];
-            const int r0 = rowbuf[cy * TQ + q];
-            const float top = hbuf[(r0 * WIN + ax) * TQ + q];
-            const float bot = hbuf[((r0 + 1) * WIN + ax) * TQ + q];
-            const float x = (1.0f - ty) * top + ty * bot;
-            const unsigned hi = __float_as_uint(x);
-            const float r1 = x - __uint_as_float(hi & 0xffff0000u);
-            const unsigned mid = __float_as_uint(r1);
-            const float r2 = r1 - __uint_as_float(mid & 0xffff0000u);
-            const int at = ((rem >> 3) * TQ + q) * 8 + (rem & 7);
-            feat[at] = (uint16_t)(hi >> 16);
-            feat[KP * TQ + at] = (uint16_t)(mid >> 16);
-            feat[2 * KP * TQ + at] = (uint16_t)(__float_as_uint(r2) >> 16);
+    for (int l0 = 0; l0 < a.num_levels; l0 += kConvLevels) {
+        const int nl = min(kConvLevels, a.num_levels - l0);
+        // every strip of these levels is requested before the first one is consumed: what a level-by-level walk pays four times
+        // in a row (coordinates -> strip reads with a DRAM page miss each) is paid once
+        Strip<R> st[SLOTS];
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int item = j * NT + tid;
+            const int lv = item / ITEMS, rem = item % ITEMS;
+            if (lv < nl) strip_request<R>(a, l0 + lv, b, q0 + rem % TQ, rem / TQ, st[j]);
         }
-        __syncthreads();
+        // ... and consumed slot by slot (items are ordered by level): the levels a slot completes are multiplied while the
+        // strips of the later slots are still on their way.  The barriers in between order LDS traffic only.
+        int done = 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t * 32 >= per_wave) break;   // uniform
-            const uint16_t* wrow = cv.weight + ((long)(wave * per_wave + t * 32 + li) * a.num_levels + l) * KP + 8 * kg;
-#pragma unroll
-            for (int k0 = 0; k0 < KP; k0 += 16) {
-                const u32x4 wh = *reinterpret_cast<const u32x4*>(wrow + k0);
-                const u32x4 wm = *reinterpret_cast<const u32x4*>(wrow + wterm + k0);
-                const u32x4 wl = *reinterpret_cast<const u32x4*>(wrow + 2 * wterm + k0);
-                const uint16_t* fp = feat + (((k0 >> 3) + kg) * TQ + li) * 8;
-                const u32x4 fh = *reinterpret_cast<const u32x4*>(fp);
-                const u32x4 fm = *reinterpret_cast<const u32x4*>(fp + KP * TQ);
-                const u32x4 fl = *reinterpret_cast<const u32x4*>(fp + 2 * KP * TQ);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wl), as_bf16x8(fh), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fl), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fm), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fh), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fm), acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fh), acc[t], 0, 0, 0);
+        for (int j = 0; j < SLOTS; ++j) {
+            {
+                const int item = j * NT + tid;
+                const int lv = item / ITEMS, rem = item % ITEMS;
+                if (lv < nl)
+                    strip_finish<R>(a, l0 + lv, rem / TQ, rem % TQ, st[j], hbuf + lv * Lds::hbuf_floats, tybuf + lv * Lds::meta,
+                                    rowbuf + lv * Lds::meta);
             }
+            lds_barrier();
+            const int ready = j == SLOTS - 1 ? nl : min(nl, ((j + 1) * NT) / ITEMS);
+            for (int lv = done; lv < ready; ++lv) {
+                const float* hb = hbuf + lv * Lds::hbuf_floats;
+                for (int o = tid; o < WIN * WIN * TQ; o += NT) {
+                    const int q = o % TQ, rem = o / TQ;
+                    const int ax = rem / WIN, cy = rem % WIN;
+                    const float ty = tybuf[lv * Lds::meta + cy * TQ + q];
+                    const int r0 = rowbuf[lv * Lds::meta + cy * TQ + q];
+                    const float top = hb[(r0 * WIN + ax) * TQ + q];
+                    const float bot = hb[((r0 + 1) * WIN + ax) * TQ + q];
+                    const float x = (1.0f - ty) * top + ty * bot;
+                    const unsigned hi = __float_as_uint(x);
+                    const float r1 = x - __uint_as_float(hi & 0xffff0000u);
+                    const unsigned mid = __float_as_uint(r1);
+                    const float r2 = r1 - __uint_as_float(mid & 0xffff0000u);
+                    const int at = ((rem >> 3) * TQ + q) * 8 + (rem & 7);
+                    feat[at] = (uint16_t)(hi >> 16);
+                    feat[KP * TQ + at] = (uint16_t)(mid >> 16);
+                    feat[2 * KP * TQ + at] = (uint16_t)(__float_as_uint(r2) >> 16);
+                }
+                lds_barrier();
+                if (multiplies) {
+                    // operand order: a wave's load instruction reads 1 KB of consecutive bytes
+                    const uint16_t* wrow = cv.weight + (((long)(l0 + lv) * (KP / 16) * (cv.cout / 32) + wave) * 64 + lane) * 8;
+#pragma unroll
+                    for (int k0 = 0; k0 < KP; k0 += 16) {
+                        const uint16_t* wk = wrow + (long)(k0 / 16) * (cv.cout / 32) * 512;
+                        const u32x4 wh = *reinterpret_cast<const u32x4*>(wk);
+                        const u32x4 wm = *reinterpret_cast<const u32x4*>(wk + wterm);
+                        const u32x4 wl = *reinterpret_cast<const u32x4*>(wk + 2 * wterm);
+                        const uint16_t* fp = feat + (((k0 >> 3) + kg) * TQ + li) * 8;
+                        const u32x4 fh = *reinterpret_cast<const u32x4*>(fp);
+                        const u32x4 fm = *reinterpret_cast<const u32x4*>(fp + KP * TQ);
+                        const u32x4 fl = *reinterpret_cast<const u32x4*>(fp + 2 * KP * TQ);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wl), as_bf16x8(fh), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fl), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fm), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fh), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fm), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fh), acc, 0, 0, 0);
+                    }
+                }
+                lds_barrier();   // feat is rewritten by the next level (hbuf by the next group of levels)
+            }
+            done = ready;
         }
-        __syncthreads();   // hbuf / feat are rewritten by the next level
     }
     // C/D layout: col = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output channel)
     const int i = q0 + li;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (t * 32 >= per_wave) break;
+    if (multiplies) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int n = wave * per_wave + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            float v = acc[t][r] + (cv.bias ? cv.bias[n] : 0.f);
+            const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            float v = acc[r] + (cv.bias ? cv.bias[n] : 0.f);
             if (cv.relu) v = fmaxf(v, 0.f);
             if (i < a.HW) a.out[((long)b * cv.cout + n) * a.HW + i] = v;
         }
@@ -509,7 +587,14 @@ int launch_lookup(const LookupArgs& a, hipStream_t stream) {
 }
 template <int R>
 int launch_lookup_conv(const LookupArgs& a, const ConvArgs& cv, hipStream_t stream) {
-    hipLaunchKernelGGL(corr_lookup_conv_kernel<R>, dim3(a.B * a.tiles_per_batch), dim3(256), 0, stream, a, cv);
+    static bool attr_set = false;   // per template instance
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_lookup_conv_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvLds<R>::bytes);
+        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_lookup_conv1x1: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(corr_lookup_conv_kernel<R>, dim3(a.B * a.tiles_per_batch), dim3(kConvThreads), ConvLds<R>::bytes, stream, a, cv);
     return check_launch("alo_corr_lookup_conv1x1");
 }
 

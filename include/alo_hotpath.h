@@ -214,9 +214,11 @@ int alo_corr_lookup(const float* const* levels, const float* coords, float* out,
  *
  *   out[b, n, y, x] = act( bias[n] + sum_k weight[n, k] * lookup[b, k, y, x] )
  *
- *   weight_packed  (3, Cout, L, KP) bf16: the convolution's (Cout, L*(2r+1)^2, 1, 1) fp32 weight regrouped per pyramid level (each
- *                  level's (2r+1)^2 entries zero-padded to KP = alo_corr_lookup_conv1x1_kpad(radius)) and split exactly into three
- *                  bf16 terms w = t0 + t1 + t2 (t0 = upper 16 bits of w, t1 = upper 16 bits of w - t0, t2 = the rest); 16-byte aligned
+ *   weight_packed  (3, L, KP/16, Cout/32, 64, 8) bf16: the convolution's (Cout, L*(2r+1)^2, 1, 1) fp32 weight regrouped per pyramid
+ *                  level (each level's (2r+1)^2 entries zero-padded to KP = alo_corr_lookup_conv1x1_kpad(radius)), split exactly into
+ *                  three bf16 terms w = t0 + t1 + t2 (t0 = upper 16 bits of w, t1 = upper 16 bits of w - t0, t2 = the rest) and
+ *                  laid out in the order the matrix operand is loaded: entry [t][l][s][c][32*g + i][e] = term t of
+ *                  W[32*c + i][l][16*s + 8*g + e]; 16-byte aligned
  *   bias           (Cout) float32 or NULL;   relu != 0: act = max(., 0)
  *   out            (B, Cout, H, W) float32, fully written
  *   Cout in {128, 256}, 1 <= radius <= 4.  The contraction runs on the bf16 matrix cores at fp32 accuracy (features split the same
