@@ -3,13 +3,15 @@
 // Reference semantics: alonet/raft/corr.py:13-60 (volume = fmap1^T . fmap2 / sqrt(C); 3x avg_pool2d; 9x9 bilinear
 // window per level) and alonet/raft/utils/utils.py:5-19 (pixel -> [-1,1] -> grid_sample(align_corners=True)).
 //
-// Build: one dense contraction per pair, volume[b,i,j] = <fmap1[b,:,i], fmap2[b,:,j]> / sqrt(C), on the bf16 matrix cores at
-//        fp32 accuracy: a pre-pass splits every fp32 feature EXACTLY into three bf16 terms (x = hi + mid + lo, 8 + 8 + 8
-//        significant bits) and lays them out channel-contiguous per pixel; the GEMM accumulates the six largest of the nine
-//        cross products (hh, hm, mh, mm, hl, lh; the dropped ones are < 2^-23 relative) in fp32 with
-//        v_mfma_f32_32x32x16_bf16 — 6 instructions of 32 cycles per 16 channels where the exact-fp32 form
-//        (v_mfma_f32_32x32x2_f32) needs 8 of 64: 2.7x less matrix time, which turns the kernel from MFMA-bound into a
-//        stream of the 4.4 GB it writes.  A workgroup's column tile is a 4 x 32 PATCH of the (h2, w2) grid, so the 2x2 and 4x4
+// Build: one dense contraction per pair, volume[b,i,j] = <fmap1[b,:,i], fmap2[b,:,j]> / sqrt(C), on the fp16 matrix cores at
+//        fp32 accuracy: a pre-pass scales every feature map by a power of two (per batch item, from its largest magnitude, so
+//        that nothing overflows or sinks into fp16's subnormals), splits every value into TWO fp16 terms (x = hi + lo, 11 + 11
+//        significant bits, round-to-nearest: |x - hi - lo| <= 2^-23 |x|) and lays them out channel-contiguous per pixel; the GEMM
+//        accumulates the three cross products hi*hi, hi*lo, lo*hi in fp32 (the dropped lo*lo is <= 2^-22 relative) with
+//        v_mfma_f32_32x32x16_f16 - 3 instructions of 32 cycles per 16 channels where the exact-fp32 form
+//        (v_mfma_f32_32x32x2_f32) needs 8 of 64, and half of what a three-term bf16 split needs.  The chip runs this kernel at
+//        its power limit (1.3 kW measured), so matrix instructions and operand bytes not spent are time not spent.
+//        A workgroup's column tile is a 4 x 32 PATCH of the (h2, w2) grid, so the 2x2 and 4x4
 //        averages of the pyramid's levels 1 and 2 are sums of accumulators the wave already holds (lane neighbours + its four
 //        row tiles): levels 0-2 leave in one launch and the level-0 volume is never re-read.  Levels >= 3 (1.6 % of the
 //        columns) are the same contraction against a 2x2-pooled copy of fmap2 (pooling commutes with the inner product).
@@ -43,45 +45,71 @@ pool2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// exact three-way bf16 split of a feature map: (B, C, n) fp32 -> [b][kc][term][pixel][16 channels] bf16, kc = ceil(C / 16)
-// (channels past C are zero).  One 16-channel slice of one pixel and one term is 32 contiguous bytes: a GEMM tile's rows of
-// a slice are one contiguous run.
+// largest magnitude of each batch item of a (B, per_batch) fp32 tensor, as the bit pattern of a non-negative float (they order
+// like unsigned integers; a NaN ends up on top).  `bits` must be zero on entry.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+corr_absmax_kernel(const float* __restrict__ in, unsigned* __restrict__ bits, long per_batch) {
+    const int b = blockIdx.y;
+    const float* p = in + (long)b * per_batch;
+    unsigned m = 0u;
+    const long n4 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? per_batch / 4 : 0;   // 16-byte loads where the slab allows them
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        const u32x4 v = reinterpret_cast<const u32x4*>(p)[i];
+        m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    }
+    for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < per_batch; i += (long)gridDim.x * 256L)
+        m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(bits + b, m);
+}
+
+// The power of two a batch item is divided by before it is split: its largest magnitude lands in [2^14, 2^15) (fp16 holds up to
+// 65504), so the low terms of all but the very smallest values stay normal fp16 numbers.  0 for an all-zero, infinite or NaN item.
+__device__ __forceinline__ int split_exponent(unsigned absmax_bits) {
+    const int e = (int)(absmax_bits >> 23);
+    if (e == 0 || e == 255) return 0;
+    const int k = e - 127 - 14;
+    return k < -110 ? -110 : (k > 110 ? 110 : k);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// two-term fp16 split of a feature map: (B, C, n) fp32 -> [b][kc][term][pixel][16 channels] fp16, kc = ceil(C / 16) (channels
+// past C are zero): hi = fp16(x'), lo = fp16(x' - hi) with x' = x * 2^-k (exact), both round-to-nearest; x' - hi is exact in
+// fp32.  One 16-channel slice of one pixel and one term is 32 contiguous bytes: a GEMM tile's rows of a slice are one
+// contiguous run.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kSplitPx = 64;
+typedef _Float16 __attribute__((ext_vector_type(4))) f16x4_t;
 
 __global__ void __launch_bounds__(256)
-corr_split_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int C, long n, int KC) {
+corr_split_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, const unsigned* __restrict__ absmax_bits, int C,
+                  long n, int KC) {
     __shared__ float tile[16][kSplitPx + 1];
     const long px0 = (long)blockIdx.x * kSplitPx;
     const int kc = blockIdx.y, b = blockIdx.z;
     const int t = threadIdx.x;
+    const float down = ldexpf(1.0f, -split_exponent(absmax_bits[b]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int ch = (t >> 6) + 4 * e, px = t & 63;
         const int c = kc * 16 + ch;
-        tile[ch][px] = (c < C && px0 + px < n) ? in[((long)b * C + c) * n + px0 + px] : 0.f;
+        tile[ch][px] = (c < C && px0 + px < n) ? in[((long)b * C + c) * n + px0 + px] * down : 0.f;
     }
     __syncthreads();
     const int px = t >> 2, q = t & 3;
     if (px0 + px >= n) return;
-    unsigned hi[4], mid[4], lo[4];
+    f16x4_t hi, lo;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float x = tile[4 * q + e][px];
-        hi[e] = __float_as_uint(x);
-        const float r1 = x - __uint_as_float(hi[e] & 0xffff0000u);   // exact: the low 16 mantissa bits
-        mid[e] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(mid[e] & 0xffff0000u); // exact: <= 8 significant bits left
-        lo[e] = __float_as_uint(r2);
+        hi[e] = (_Float16)x;
+        lo[e] = (_Float16)(x - (float)hi[e]);
     }
-    // bf16 by truncation = the upper half; v_perm packs two upper halves
-    const long base = (((long)b * KC + kc) * 3) * n;
-    u32x2* o0 = reinterpret_cast<u32x2*>(out + ((base + px0 + px) * 16 + 4 * q));
-    u32x2* o1 = reinterpret_cast<u32x2*>(out + ((base + n + px0 + px) * 16 + 4 * q));
-    u32x2* o2 = reinterpret_cast<u32x2*>(out + ((base + 2 * n + px0 + px) * 16 + 4 * q));
-    *o0 = u32x2{__builtin_amdgcn_perm(hi[1], hi[0], 0x07060302u), __builtin_amdgcn_perm(hi[3], hi[2], 0x07060302u)};
-    *o1 = u32x2{__builtin_amdgcn_perm(mid[1], mid[0], 0x07060302u), __builtin_amdgcn_perm(mid[3], mid[2], 0x07060302u)};
-    *o2 = u32x2{__builtin_amdgcn_perm(lo[1], lo[0], 0x07060302u), __builtin_amdgcn_perm(lo[3], lo[2], 0x07060302u)};
+    const long base = (((long)b * KC + kc) * 2) * n;
+    *reinterpret_cast<f16x4_t*>(out + ((base + px0 + px) * 16 + 4 * q)) = hi;
+    *reinterpret_cast<f16x4_t*>(out + ((base + n + px0 + px) * 16 + 4 * q)) = lo;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -93,10 +121,18 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(const u32x4& v) {
     x.u = v;
     return x.b;
 }
+typedef _Float16 __attribute__((ext_vector_type(8))) f16x8_t;
+__device__ __forceinline__ f16x8_t as_f16x8(const u32x4& v) {
+    union { u32x4 u; f16x8_t h; } x;
+    x.u = v;
+    return x.h;
+}
 
 struct Gemm3Args {
-    const uint16_t* a;   // split fmap1  [B][KC][3][HW][16]
-    const uint16_t* b;   // split fmap2 (or a pooled copy of it) [B][KC][3][n][16]
+    const uint16_t* a;   // split fmap1  [B][KC][2][HW][16]
+    const uint16_t* b;   // split fmap2 (or a pooled copy of it) [B][KC][2][n][16]
+    const unsigned* amax_a;   // per batch item: bit pattern of the largest magnitude of fmap1 / fmap2 (-> the powers of two the
+    const unsigned* amax_b;   // split copies were divided by)
     float* out0;         // POOLED: level 0 (B*HW, H*W); plain: the level (B*HW, n)
     float* out1;         // POOLED: level 1 or null
     float* out2;         // POOLED: level 2 or null
@@ -109,13 +145,14 @@ struct Gemm3Args {
 };
 
 // Workgroup tile: 256 rows (pixels of fmap1) x 128 columns (POOLED: a 4 x 32 patch of fmap2's grid; plain: 128 consecutive
-// columns); 8 waves, each 32 rows x all 128 columns = 4 MFMA tiles of 32 x 32.  Per 16-channel slice the workgroup needs
-// 24 + 12 KiB of operands (three bf16 terms each); they go from memory STRAIGHT into LDS (global_load_lds_dwordx4, no
-// registers, no ds_write pass), one slice ahead, while the matrix pipe works on the current one.  2 workgroups = 16 waves
-// per CU: four waves per SIMD take turns on the matrix pipe, so one's epilogue / staging waits hide under the others' MFMAs.
-constexpr int kTM = 256, kTN = 128, kGemmThreads = 512;
-constexpr int kGranA = 3 * kTM * 2, kGranB = 3 * kTN * 2;          // 16-byte granules per stage
-constexpr int kGemmLds = 2 * (kGranA + kGranB) * 16;               // 72 KiB
+// columns); 4 waves, each 64 rows x all 128 columns = 8 MFMA tiles of 32 x 32 (12 operand reads feed 24 MFMAs).  Per
+// 16-channel slice the workgroup needs 16 + 8 KiB of operands (two fp16 terms each); they go from memory STRAIGHT into LDS
+// (global_load_lds_dwordx4, no registers, no ds_write pass), one slice ahead, while the matrix pipe works on the current one.
+// 2 workgroups = 8 waves per CU (the accumulators take 128 of a wave's registers).
+constexpr int kTM = 256, kTN = 128, kGemmThreads = 256;
+constexpr int kRowGroup = 4;
+constexpr int kGranA = 2 * kTM * 2, kGranB = 2 * kTN * 2;          // 16-byte granules per stage
+constexpr int kGemmLds = 2 * (kGranA + kGranB) * 16;               // 48 KiB
 
 // LDS granule of (term, row, half) of an operand tile with ROWS rows.  The LDS-DMA writes lane-linearly, so the layout is
 // plain [term][row][half]; the half is flipped on every other group of 8 rows — on the SOURCE address of the DMA and on the
@@ -140,28 +177,32 @@ corr_gemm3_kernel(const Gemm3Args g) {
 
     // flat block -> (batch, column tile, row tile); row tiles fastest so neighbours on an XCD reuse the B tile from L2
     const unsigned lb = xcd_contiguous_block(blockIdx.x, g.nblocks);
-    const int tm = lb % g.tiles_m;
-    const int tn = (lb / g.tiles_m) % (g.tiles_r * g.tiles_c);
-    const int b = lb / (g.tiles_m * g.tiles_r * g.tiles_c);
+    // row tiles in groups of kRowGroup: the workgroups resident on an XCD together share kRowGroup A tiles (they stay in its L2
+    // for the whole sweep over the column tiles) and stream the B tiles past them
+    const int tiles_n = g.tiles_r * g.tiles_c, row_groups = (g.tiles_m + kRowGroup - 1) / kRowGroup;
+    const int tm = ((lb / (kRowGroup * tiles_n)) % row_groups) * kRowGroup + lb % kRowGroup;
+    const int tn = (lb / kRowGroup) % tiles_n;
+    const int b = lb / (kRowGroup * tiles_n * row_groups);
+    if (tm >= g.tiles_m) return;   // the last group's padding (workgroup-uniform)
     const int tr = tn / g.tiles_c, tc = tn % g.tiles_c;
     const int i0 = tm * kTM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // DMA plan: a wave instruction moves 64 granules = 32 rows x 2 halves of one term.  A: 3 terms x 8 row groups = 24
-    // instructions (3 per wave), B: 3 x 4 = 12 (waves 0-3: 2, waves 4-7: 1).  Rows past the edge re-read row 0 (their
-    // accumulators are never stored, and pooled outputs only combine columns that exist).
+    // DMA plan: a wave instruction moves 64 granules = 32 rows x 2 halves of one term.  A: 2 terms x 8 row groups = 16
+    // instructions (4 per wave), B: 2 x 4 = 8 (2 per wave).  Rows past the edge re-read row 0 (their accumulators are never
+    // stored, and pooled outputs only combine columns that exist).
     const int drow = lane >> 1, dhalf = lane & 1;
-    const uint16_t* asrc[3];
+    const uint16_t* asrc[4];
     const uint16_t* bsrc[2];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        const int ins = wave + 8 * e, term = ins >> 3, row = 32 * (ins & 7) + drow;
+    for (int e = 0; e < 4; ++e) {
+        const int ins = wave + 4 * e, term = ins >> 3, row = 32 * (ins & 7) + drow;
         const int half = dhalf ^ ((row >> 3) & 1);
-        asrc[e] = g.a + ((((long)b * g.KC) * 3 + term) * g.HW + (i0 + row < g.HW ? i0 + row : 0)) * 16 + half * 8;
+        asrc[e] = g.a + ((((long)b * g.KC) * 2 + term) * g.HW + (i0 + row < g.HW ? i0 + row : 0)) * 16 + half * 8;
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int ins = (wave + 8 * e) % 12, term = ins >> 2, row = 32 * (ins & 3) + drow;
+        const int ins = wave + 4 * e, term = ins >> 2, row = 32 * (ins & 3) + drow;
         const int half = dhalf ^ ((row >> 3) & 1);
         long col;
         bool ok;
@@ -173,21 +214,23 @@ corr_gemm3_kernel(const Gemm3Args g) {
             col = (long)tc * kTN + row;
             ok = col < g.n;
         }
-        bsrc[e] = g.b + ((((long)b * g.KC) * 3 + term) * g.n + (ok ? col : 0)) * 16 + half * 8;
+        bsrc[e] = g.b + ((((long)b * g.KC) * 2 + term) * g.n + (ok ? col : 0)) * 16 + half * 8;
     }
-    const long a_step = 3L * g.HW * 16, b_step = 3L * g.n * 16;   // one K slice further
+    const long a_step = 2L * g.HW * 16, b_step = 2L * g.n * 16;   // one K slice further
     auto stage_in = [&](int kc, int stage) {
 #pragma unroll
-        for (int e = 0; e < 3; ++e) dma16(asrc[e] + kc * a_step, ldsA(stage) + (wave + 8 * e) * 64);
-        dma16(bsrc[0] + kc * b_step, ldsB(stage) + wave * 64);
-        if (wave < 4) dma16(bsrc[1] + kc * b_step, ldsB(stage) + (wave + 8) * 64);   // wave-uniform
+        for (int e = 0; e < 4; ++e) dma16(asrc[e] + kc * a_step, ldsA(stage) + (wave + 4 * e) * 64);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) dma16(bsrc[e] + kc * b_step, ldsB(stage) + (wave + 4 * e) * 64);
     };
 
-    f32x16 acc[4];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.f;
 
     stage_in(0, 0);
     __syncthreads();   // (hipcc drains the DMA queue in front of a barrier)
@@ -198,19 +241,26 @@ corr_gemm3_kernel(const Gemm3Args g) {
         if (kc + 1 < g.KC) stage_in(kc + 1, cur ^ 1);   // lands while this slice is multiplied
         const u32x4* As = ldsA(cur);
         const u32x4* Bs = ldsB(cur);
-        const int arow = 32 * wave + li;
-        const u32x4 ah = As[slot<kTM>(0, arow, kg)], am = As[slot<kTM>(1, arow, kg)], al = As[slot<kTM>(2, arow, kg)];
-        u32x4 bf[4][3];
+        u32x4 af[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int term = 0; term < 2; ++term) af[h][term] = As[slot<kTM>(term, 64 * wave + 32 * h + li, kg)];
+        u32x4 bf[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int term = 0; term < 3; ++term) bf[t][term] = Bs[slot<kTN>(term, 32 * t + li, kg)];
-        // small cross terms first; the four column tiles rotate, so no MFMA waits on the one before it
+            for (int term = 0; term < 2; ++term) bf[t][term] = Bs[slot<kTN>(term, 32 * t + li, kg)];
+        // small cross terms first; the eight tiles rotate, so no MFMA waits on the one before it
 #define ALO_CORR_STEP(AT, BT)                                                                                                       \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                               \
         _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                               \
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(AT), as_bf16x8(bf[t][BT]), acc[t], 0, 0, 0);
-        ALO_CORR_STEP(al, 0) ALO_CORR_STEP(ah, 2) ALO_CORR_STEP(am, 1) ALO_CORR_STEP(am, 0) ALO_CORR_STEP(ah, 1) ALO_CORR_STEP(ah, 0)
+            acc[h][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(af[h][AT]), as_f16x8(bf[t][BT]), acc[h][t], 0, 0, 0);
+        ALO_CORR_STEP(1, 0) ALO_CORR_STEP(0, 1) ALO_CORR_STEP(0, 0)
 #undef ALO_CORR_STEP
+        // keep every MFMA of the slice in front of the barrier: the scheduler otherwise sinks two thirds of them below it, where
+        // no DMA is in flight (the next one is issued at the top of the loop), and the staging latency and the matrix work add up
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();   // the next slice has landed (DMA drained in front of the barrier) and this one is free to overwrite
     }
 
@@ -218,23 +268,30 @@ corr_gemm3_kernel(const Gemm3Args g) {
     // instruction writes whole 128-byte lines (32 consecutive columns of two rows).
     // The volume is written once and never read again by this kernel: non-temporal stores keep the stream out of the L2.
     const long rowbase = (long)b * g.HW;
-    {
+    // undo the operands' power-of-two scaling (exact) together with the 1/sqrt(C): 2^(ka + kb) applied in two halves, so that no
+    // factor leaves the float range unless the result does
+    const int kt = split_exponent(g.amax_a[b]) + split_exponent(g.amax_b[b]);
+    const float up1 = ldexpf(1.0f, kt / 2), up2 = ldexpf(g.scale, kt - kt / 2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x16 (&acc_h)[4] = acc[h];
+        const int wrow0 = i0 + 64 * wave + 32 * h;
         if (POOLED) {
             const int x = 32 * tc + li;
             const int yb = 4 * tr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = i0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int i = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 const bool iok = i < g.HW;
                 float s4 = 0.f;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const float v0 = acc[2 * p][r], v1 = acc[2 * p + 1][r];
+                    const float v0 = acc_h[2 * p][r], v1 = acc_h[2 * p + 1][r];
                     const int y = yb + 2 * p;
                     if (iok && x < g.W) {
                         float* o = g.out0 + (rowbase + i) * g.n + (long)y * g.W + x;
-                        if (y < g.H) __builtin_nontemporal_store(v0 * g.scale, o);
-                        if (y + 1 < g.H) __builtin_nontemporal_store(v1 * g.scale, o + g.W);
+                        if (y < g.H) __builtin_nontemporal_store(v0 * up1 * up2, o);
+                        if (y + 1 < g.H) __builtin_nontemporal_store(v1 * up1 * up2, o + g.W);
                     }
                     // level 1: 2 x 2 mean = this lane's two rows + the same of its x-neighbour (lane ^ 1)
                     float s2 = v0 + v1;
@@ -243,7 +300,7 @@ corr_gemm3_kernel(const Gemm3Args g) {
                     if (g.out1 && iok && !(lane & 1)) {
                         const int y1 = (yb >> 1) + p, x1 = x >> 1;
                         if (y1 < g.h1 && x1 < g.w1)
-                            __builtin_nontemporal_store(s2 * (0.25f * g.scale), g.out1 + (rowbase + i) * ((long)g.h1 * g.w1) + (long)y1 * g.w1 + x1);
+                            __builtin_nontemporal_store(s2 * up1 * (0.25f * up2), g.out1 + (rowbase + i) * ((long)g.h1 * g.w1) + (long)y1 * g.w1 + x1);
                     }
                 }
                 // level 2: 4 x 4 mean = both row pairs + the other half of the quad
@@ -251,7 +308,7 @@ corr_gemm3_kernel(const Gemm3Args g) {
                 if (g.out2 && iok && !(lane & 3)) {
                     const int y2 = yb >> 2, x2 = x >> 2;
                     if (y2 < g.h2 && x2 < g.w2)
-                        __builtin_nontemporal_store(s4 * (0.0625f * g.scale), g.out2 + (rowbase + i) * ((long)g.h2 * g.w2) + (long)y2 * g.w2 + x2);
+                        __builtin_nontemporal_store(s4 * up1 * (0.0625f * up2), g.out2 + (rowbase + i) * ((long)g.h2 * g.w2) + (long)y2 * g.w2 + x2);
                 }
             }
         } else {
@@ -260,8 +317,8 @@ corr_gemm3_kernel(const Gemm3Args g) {
                 const long col = (long)tc * kTN + 32 * t + li;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = i0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    if (i < g.HW && col < g.n) __builtin_nontemporal_store(acc[t][r] * g.scale, g.out0 + (rowbase + i) * g.n + col);
+                    const int i = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (i < g.HW && col < g.n) __builtin_nontemporal_store(acc_h[t][r] * up1 * up2, g.out0 + (rowbase + i) * g.n + col);
                 }
             }
         }
@@ -635,13 +692,14 @@ extern "C" void alo_corr_level_shape(int H, int W, int level, int* h_out, int* w
 
 namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-inline size_t split_bytes(int B, int C, long n) { return align256((size_t)B * ((C + 15) / 16) * 3 * n * 16 * sizeof(uint16_t)); }
+inline size_t split_bytes(int B, int C, long n) { return align256((size_t)B * ((C + 15) / 16) * 2 * n * 16 * sizeof(uint16_t)); }
+inline size_t absmax_bytes(int B) { return align256((size_t)2 * B * sizeof(unsigned)); }
 }  // namespace
 
-// Scratch: the split copies of fmap1 and fmap2; for pyramids deeper than 3 levels also the 2x2-average chain of fmap2 (fp32)
-// and the split copies of its levels >= 3.
+// Scratch: the split copies of fmap1 and fmap2 and the two per-batch-item magnitudes; for pyramids deeper than 3 levels also the
+// 2x2-average chain of fmap2 (fp32) and the split copies of its levels >= 3.
 extern "C" size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels) {
-    size_t total = 2 * split_bytes(B, C, (long)H * W);
+    size_t total = 2 * split_bytes(B, C, (long)H * W) + absmax_bytes(B);
     for (int l = 1; l < num_levels && num_levels > 3; ++l) {
         int h, w;
         alo_corr_level_shape(H, W, l, &h, &w);
@@ -677,16 +735,29 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
     ws += split_bytes(B, C, HW);
     uint16_t* f2s = reinterpret_cast<uint16_t*>(ws);
     ws += split_bytes(B, C, HW);
-    auto split = [&](const float* in, uint16_t* out, long n) -> int {
+    unsigned* amax = reinterpret_cast<unsigned*>(ws);   // [2][B]
+    ws += absmax_bytes(B);
+    hipError_t em = hipMemsetAsync(amax, 0, (size_t)2 * B * sizeof(unsigned), stream);
+    if (em != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_build: memset: %s", hipGetErrorString(em));
+    auto absmax = [&](const float* in, unsigned* bits) -> int {
+        const long per_batch = (long)C * HW;
+        const unsigned blocks = (unsigned)((per_batch / 4 + 1023) / 1024 > 256 ? 256 : (per_batch / 4 + 1023) / 1024);
+        hipLaunchKernelGGL(corr_absmax_kernel, dim3(blocks ? blocks : 1, (unsigned)B), dim3(256), 0, stream, in, bits, per_batch);
+        return check_launch("alo_corr_build(absmax)");
+    };
+    if (int rc = absmax(fmap1, amax)) return rc;
+    if (int rc = absmax(fmap2, amax + B)) return rc;
+    auto split = [&](const float* in, uint16_t* out, const unsigned* bits, long n) -> int {
         const dim3 grid((unsigned)((n + kSplitPx - 1) / kSplitPx), (unsigned)KC, (unsigned)B);
-        hipLaunchKernelGGL(corr_split_kernel, grid, dim3(256), 0, stream, in, out, C, n, KC);
+        hipLaunchKernelGGL(corr_split_kernel, grid, dim3(256), 0, stream, in, out, bits, C, n, KC);
         return check_launch("alo_corr_build(split)");
     };
-    if (int rc = split(fmap1, f1s, HW)) return rc;
-    if (int rc = split(fmap2, f2s, HW)) return rc;
+    if (int rc = split(fmap1, f1s, amax, HW)) return rc;
+    if (int rc = split(fmap2, f2s, amax + B, HW)) return rc;
 
     Gemm3Args g;
     g.a = f1s; g.b = f2s;
+    g.amax_a = amax; g.amax_b = amax + B;
     g.B = B; g.KC = KC; g.HW = (int)HW;
     g.H = H; g.W = W; g.n = (int)HW;
     g.tiles_m = (int)((HW + kTM - 1) / kTM);
@@ -698,7 +769,7 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
     g.out2 = num_levels > 2 ? levels[2] : nullptr;
     alo_corr_level_shape(H, W, 1, &g.h1, &g.w1);
     alo_corr_level_shape(H, W, 2, &g.h2, &g.w2);
-    long nblocks = (long)g.tiles_m * g.tiles_r * g.tiles_c * B;
+    long nblocks = (long)((g.tiles_m + kRowGroup - 1) / kRowGroup) * kRowGroup * g.tiles_r * g.tiles_c * B;
     ALO_REQUIRE(nblocks < 0x7fffffffL, ALO_ERR_UNSUPPORTED, "alo_corr_build: grid too large");
     g.nblocks = (unsigned)nblocks;
     static bool attr_set = false;
@@ -728,13 +799,13 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
         const long n = (long)h * w;
         uint16_t* ps = reinterpret_cast<uint16_t*>(ws);
         ws += split_bytes(B, C, n);
-        if (int rc = split(pooled, ps, n)) return rc;
+        if (int rc = split(pooled, ps, amax + B, n)) return rc;   // a 2x2 mean is no larger than fmap2's largest entry
         Gemm3Args e = g;
         e.b = ps; e.n = (int)n;
         e.out0 = levels[l]; e.out1 = e.out2 = nullptr;
         e.tiles_r = 1;
         e.tiles_c = (int)((n + kTN - 1) / kTN);
-        e.nblocks = (unsigned)((long)e.tiles_m * e.tiles_c * B);
+        e.nblocks = (unsigned)((long)((e.tiles_m + kRowGroup - 1) / kRowGroup) * kRowGroup * e.tiles_c * B);
         hipLaunchKernelGGL(corr_gemm3_kernel<false>, dim3(e.nblocks), dim3(kGemmThreads), kGemmLds, stream, e);
         if (int rc = check_launch("alo_corr_build(gemm, coarse level)")) return rc;
     }

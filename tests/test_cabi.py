@@ -46,12 +46,12 @@ def test_pyramid_shape_helpers():
     assert alo_hip.corr_level_shapes(90, 160, 4) == [(90, 160), (45, 80), (22, 40), (11, 20)]
     assert alo_hip.corr_level_shapes(17, 18, 4) == [(17, 18), (8, 9), (4, 4), (2, 2)]
     lib = alo_hip.lib()
-    # bf16-split copies of both feature maps (3 terms x 2 bytes per channel, 16-channel slices) + the fp32 pooled chain and the
-    # split copy of level 3 for a 4-level pyramid; every piece rounded up to 256 bytes
-    split0 = 4 * 16 * 3 * 14400 * 16 * 2
-    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 3) == 2 * split0
-    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 4) == 2 * split0 + 4 * 256 * (3600 + 880 + 220) * 4 + 4 * 16 * 3 * 220 * 16 * 2
-    assert lib.alo_corr_build_workspace_bytes(1, 8, 16, 16, 1) == 2 * 1 * 1 * 3 * 256 * 16 * 2
+    # fp16-split copies of both feature maps (2 terms x 2 bytes per channel, 16-channel slices) + the per-item magnitudes (256 bytes)
+    # + the fp32 pooled chain and the split copy of level 3 for a 4-level pyramid; every piece rounded up to 256 bytes
+    split0 = 4 * 16 * 2 * 14400 * 16 * 2
+    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 3) == 2 * split0 + 256
+    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 4) == 2 * split0 + 256 + 4 * 256 * (3600 + 880 + 220) * 4 + 4 * 16 * 2 * 220 * 16 * 2
+    assert lib.alo_corr_build_workspace_bytes(1, 8, 16, 16, 1) == 2 * 1 * 1 * 2 * 256 * 16 * 2 + 256
 
 
 def test_argument_errors_are_reported_before_any_launch():

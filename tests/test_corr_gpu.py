@@ -140,6 +140,55 @@ def test_full_size_properties_720p():
     np.testing.assert_allclose(out2.reshape(324, -1)[:, sel], o.reshape(324, n), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("sa,sb", [(1e-3, 1e-3), (3e4, 7e5), (1e-20, 1e-12), (1e12, 1e-15), (5e18, 3e17)])
+def test_build_is_accurate_at_any_magnitude(sa, sb):
+    """The operands travel as two fp16 terms after a per-item power-of-two scaling: the volume must keep fp32-class relative accuracy
+    from 1e-20 to 1e+18, with batch items of very different magnitude side by side, small entries next to large ones, and an
+    all-zero item."""
+    rng = np.random.default_rng(77)
+    B, C, H, W = 3, 96, 12, 20
+    f1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    f2 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    f1[0] *= sa; f2[0] *= sb
+    f1[1] *= sa * 1e-3; f2[1] *= sb * 4e2          # another magnitude in the same launch
+    f1[1, :, :3] *= 1e-6                           # tiny rows next to ordinary ones: they only need accuracy relative to the item
+    f1[2] = 0.0                                    # an all-zero item
+    a64, b64 = f1.astype(np.float64).reshape(B, C, -1), f2.astype(np.float64).reshape(B, C, -1)
+    vol = (np.einsum("bci,bcj->bij", a64, b64) / np.sqrt(C)).reshape(B * H * W, 1, H, W)   # corr.py:52-60 in float64
+    ref = [vol]
+    for _ in range(3):                                                                        # corr.py:20-27
+        p = ref[-1]
+        h, w = p.shape[2] // 2, p.shape[3] // 2
+        ref.append(p[:, :, :2 * h, :2 * w].reshape(-1, 1, h, 2, w, 2).mean(axis=(3, 5)))
+    levels = alo_hip.corr_build(dev(f1), dev(f2), 4)
+    n = H * W
+    for lvl in range(4):
+        got = levels[lvl].cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all()
+        for b in range(B):
+            r = ref[lvl][b * n:(b + 1) * n]
+            scale = max(np.abs(r).max(), 1e-300)
+            if b == 2:
+                assert not got[b * n:(b + 1) * n].any()
+            else:   # 3e-6 of the item's largest entry: fp32 accumulation of 96 products, nothing worse
+                assert np.abs(got[b * n:(b + 1) * n] - r).max() <= 3e-6 * scale, (lvl, b)
+
+
+def test_build_propagates_non_finite_features_like_the_reference():
+    rng = np.random.default_rng(78)
+    f1 = rng.standard_normal((2, 32, 8, 12)).astype(np.float32)
+    f2 = rng.standard_normal((2, 32, 8, 12)).astype(np.float32)
+    f1[0, 3, 2, 5] = np.inf
+    f2[0, 7, 1, 1] = np.nan
+    levels = alo_hip.corr_build(dev(f1), dev(f2), 2)
+    n = 8 * 12
+    got = levels[0].cpu().numpy().reshape(2, n, n)
+    assert not np.isfinite(got[0, 2 * 12 + 5]).any()      # the row of the infinite feature
+    assert np.isnan(got[0, :, 1 * 12 + 1]).all()           # the column of the NaN feature
+    ref1 = O.corr_pyramid(f1[1:], f2[1:], 2)[0]
+    np.testing.assert_allclose(got[1].reshape(n, 1, 8, 12), ref1, rtol=0, atol=3e-5)   # the other item is untouched
+
+
 def test_batch_items_are_independent():
     rng = np.random.default_rng(21)
     f1 = dev(rng.standard_normal((3, 64, 16, 24)).astype(np.float32))
