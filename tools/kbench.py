@@ -171,7 +171,7 @@ def bench_corr_build(B, reps, H=90, W=160, C=256):
     ncols = sum(h * w for h, w in shapes)
     flops_l0 = 2.0 * B * HW * HW * C  # 2*HW^2*C per pair (level 0, what the reference's matmul does)
     n3 = sum(h * w for h, w in shapes[3:])
-    flops_all = 6 * 2.0 * B * HW * (HW + n3) * C  # executed on the bf16 pipe: six split products; levels >= 3 as extra columns
+    flops_all = 3 * 2.0 * B * HW * (HW + n3) * C  # executed on the fp16 pipe: three split products; levels >= 3 as extra columns
     nbytes = 4 * (2 * B * C * HW + B * HW * ncols)
     return dict(kernel="corr_build", B=B, ms=t * 1e3, alg_flops=flops_l0, exec_flops=flops_all,
                 TFLOPs_alg=flops_l0 / t / 1e12, TFLOPs_exec=flops_all / t / 1e12, alg_bytes=nbytes,
