@@ -54,6 +54,7 @@ corr_absmax_kernel(const float* __restrict__ in, unsigned* __restrict__ bits, lo
     const float* p = in + (long)b * per_batch;
     unsigned m = 0u;
     const long n4 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? per_batch / 4 : 0;   // 16-byte loads where the slab allows them
+#pragma unroll 8   // eight independent 16-byte loads in flight per thread
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
         const u32x4 v = reinterpret_cast<const u32x4*>(p)[i];
         m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
@@ -62,7 +63,14 @@ corr_absmax_kernel(const float* __restrict__ in, unsigned* __restrict__ bits, lo
         m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(bits + b, m);
+    // one atomic per workgroup: they all aim at the item's one word and serialize there
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m) atomicMax(bits + b, m);
+    }
 }
 
 // The power of two a batch item is divided by before it is split: its largest magnitude lands in [2^14, 2^15) (fp16 holds up to
@@ -741,7 +749,9 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
     if (em != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_build: memset: %s", hipGetErrorString(em));
     auto absmax = [&](const float* in, unsigned* bits) -> int {
         const long per_batch = (long)C * HW;
-        const unsigned blocks = (unsigned)((per_batch / 4 + 1023) / 1024 > 256 ? 256 : (per_batch / 4 + 1023) / 1024);
+        // few workgroups with many loads in flight each: the atomics of an item all aim at one word and cost ~12 ns apiece
+        const long want = (per_batch / 4 + 2047) / 2048;
+        const unsigned blocks = (unsigned)(want > 96 ? 96 : want);
         hipLaunchKernelGGL(corr_absmax_kernel, dim3(blocks ? blocks : 1, (unsigned)B), dim3(256), 0, stream, in, bits, per_batch);
         return check_launch("alo_corr_build(absmax)");
     };
