@@ -374,125 +374,140 @@ def main():
     # ---- flow -------------------------------------------------------------------------------------------------------
     raft = None
     if not a.no_raft:
-        torch.manual_seed(0)
-        rmodel = RAFT().eval().to(device)
-        f1, f2 = flow_inputs(a.raft_batch, rank, device)
+        try:   # a secondary leg must never cost the headline line
+            torch.manual_seed(0)
+            rmodel = RAFT().eval().to(device)
+            f1, f2 = flow_inputs(a.raft_batch, rank, device)
 
-        def raft_eager():
-            with torch.no_grad():
-                outs = rmodel(f1, f2, iters=32, only_last=True)
-                return rmodel.inference(outs, only_last=True)
-
-        raft_step = raft_eager
-        if not a.no_graph:  # ~1500 launches per forward (32 update iterations): replayed as one HIP graph, as the detector's
-            from alonet.common import GraphedForward
-
-            rgraphed = GraphedForward(rmodel, adopt_inputs=True)
-
-            def raft_step():
+            def raft_eager():
                 with torch.no_grad():
-                    return rmodel.inference(rgraphed(f1, f2, iters=32, only_last=True), only_last=True)
+                    outs = rmodel(f1, f2, iters=32, only_last=True)
+                    return rmodel.inference(outs, only_last=True)
 
-            try:
-                rgraphed(f1, f2, iters=32, only_last=True)
-            except Exception as exc:
-                print(f"[bench] HIP graph capture of RAFT failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr, flush=True)
-                raft_step = raft_eager
+            raft_step = raft_eager
+            if not a.no_graph:  # ~1500 launches per forward (32 update iterations): replayed as one HIP graph, as the detector's
+                from alonet.common import GraphedForward
 
-        with alo_hip.LaunchTimer(only="corr_build") as rtimer:  # one launch per forward; everything else un-instrumented
-            raft_seconds = timed_steps(raft_step, a.raft_steps, a.raft_warmup, world, device)
-        rk = kernel_report(rtimer.summary())
-        with alo_hip.LaunchTimer() as rfull:  # full kernel table from one extra, un-timed EAGER forward
-            raft_eager()
-        rk_all = kernel_report(rfull.summary())
-        rk_all.update(rk)
-        kernels.update(rk_all)
-        raft = {"metric": "frame pairs/sec (whole node) RAFT 32-iter inference", "value": round(a.raft_batch * world * a.raft_steps / raft_seconds, 3),
-                "unit": "pairs/s", "steps": a.raft_steps, "warmup": a.raft_warmup, "ms_per_step": round(raft_seconds / a.raft_steps * 1e3, 2),
-                "dtype": "f32", "config": {"workload": f"alonet.raft.RAFT 32 iters, batch {a.raft_batch} synthetic 1280x720 pairs per GPU",
-                                           "launch": "eager" if raft_step is raft_eager else "HIP graph replay",
-                                           "per_gpu_batch": a.raft_batch}}
-        cb = rk.get("corr_build") or rk_all.get("corr_build")  # graph replay runs no host wrapper: take the eager pass's events
-        if cb is not None:
-            # With three fp16 products the contraction needs 0.52 ms of matrix time at peak and the 4.5 GB it writes need 0.56 ms of
-            # HBM time: the write stream is the larger of the two (SURVEY 8(d) predicted the cross-over), so that is the roofline
-            # reported; the matrix-pipe view rides along.
-            raft["roofline"] = {"bound": "hbm", "kernel": "corr_gemm3_kernel + magnitude / split / coarse-level passes (all-pairs volume + "
-                                                           "pyramid on the fp16 matrix pipe at fp32 accuracy: power-of-two scaling, two-term "
-                                                           "operand split, 3 products)",
-                                "achieved": cb["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": cb["hbm_frac"], "traffic": None,
-                                "alg_bytes_per_launch": cb["alg_bytes"], "ms_per_launch": cb["ms_avg"],
-                                "matrix_pipe": {"algorithmic_TFLOPs": cb["TFLOPs"], "executed_TFLOPs": cb["TFLOPs_executed_16bit"],
-                                                "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "frac": cb["mfma_frac"],
-                                                "algorithmic_vs_fp32_matrix_peak": round(cb["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 3)}}
-        del rmodel, f1, f2
-        torch.cuda.empty_cache()
+                rgraphed = GraphedForward(rmodel, adopt_inputs=True)
+
+                def raft_step():
+                    with torch.no_grad():
+                        return rmodel.inference(rgraphed(f1, f2, iters=32, only_last=True), only_last=True)
+
+                try:
+                    rgraphed(f1, f2, iters=32, only_last=True)
+                except Exception as exc:
+                    print(f"[bench] HIP graph capture of RAFT failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr, flush=True)
+                    raft_step = raft_eager
+
+            with alo_hip.LaunchTimer(only="corr_build") as rtimer:  # one launch per forward; everything else un-instrumented
+                raft_seconds = timed_steps(raft_step, a.raft_steps, a.raft_warmup, world, device)
+            rk = kernel_report(rtimer.summary())
+            with alo_hip.LaunchTimer() as rfull:  # full kernel table from one extra, un-timed EAGER forward
+                raft_eager()
+            rk_all = kernel_report(rfull.summary())
+            rk_all.update(rk)
+            kernels.update(rk_all)
+            raft = {"metric": "frame pairs/sec (whole node) RAFT 32-iter inference", "value": round(a.raft_batch * world * a.raft_steps / raft_seconds, 3),
+                    "unit": "pairs/s", "steps": a.raft_steps, "warmup": a.raft_warmup, "ms_per_step": round(raft_seconds / a.raft_steps * 1e3, 2),
+                    "dtype": "f32", "config": {"workload": f"alonet.raft.RAFT 32 iters, batch {a.raft_batch} synthetic 1280x720 pairs per GPU",
+                                               "launch": "eager" if raft_step is raft_eager else "HIP graph replay",
+                                               "per_gpu_batch": a.raft_batch}}
+            cb = rk.get("corr_build") or rk_all.get("corr_build")  # graph replay runs no host wrapper: take the eager pass's events
+            if cb is not None:
+                # With three fp16 products the contraction needs 0.52 ms of matrix time at peak and the 4.5 GB it writes need 0.56 ms of
+                # HBM time: the write stream is the larger of the two (SURVEY 8(d) predicted the cross-over), so that is the roofline
+                # reported; the matrix-pipe view rides along.
+                raft["roofline"] = {"bound": "hbm", "kernel": "corr_gemm3_kernel + magnitude / split / coarse-level passes (all-pairs volume + "
+                                                               "pyramid on the fp16 matrix pipe at fp32 accuracy: power-of-two scaling, two-term "
+                                                               "operand split, 3 products)",
+                                    "achieved": cb["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": cb["hbm_frac"], "traffic": None,
+                                    "alg_bytes_per_launch": cb["alg_bytes"], "ms_per_launch": cb["ms_avg"],
+                                    "matrix_pipe": {"algorithmic_TFLOPs": cb["TFLOPs"], "executed_TFLOPs": cb["TFLOPs_executed_16bit"],
+                                                    "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS, "frac": cb["mfma_frac"],
+                                                    "algorithmic_vs_fp32_matrix_peak": round(cb["TFLOPs"] / MFMA_F32_PEAK_TFLOPS, 3)}}
+            del rmodel, f1, f2
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            print(f"[bench] raft leg failed ({type(exc).__name__}: {exc}); omitted from the line", file=sys.stderr, flush=True)
+            raft = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.empty_cache()
 
     # ---- training step (opt-in) ---------------------------------------------------------------------------------------
     train = None
     if a.train_steps > 0:
-        from alonet.deformable_detr.training import build_criterion, configure_optimizers, training_step, wrap_ddp
+        try:   # a secondary leg must never cost the headline line
+            from alonet.deformable_detr.training import build_criterion, configure_optimizers, training_step, wrap_ddp
 
-        torch.manual_seed(0)
-        tmodel = DeformableDetrR50(num_classes=91, aux_loss=True, device=device).train()
-        step_model = wrap_ddp(tmodel, local) if world > 1 else tmodel
-        gen = torch.Generator().manual_seed(777 + rank)
-        names = [f"class_{i}" for i in range(91)]
-        tframes = []
-        for _ in range(a.train_batch):
-            lab = aloscene.Labels(torch.randint(0, 91, (10,), generator=gen).float(), encoding="id", labels_names=names)
-            cxcy = torch.rand(10, 2, generator=gen) * 0.6 + 0.2
-            wh = torch.rand(10, 2, generator=gen) * 0.3 + 0.05
-            bx = aloscene.BoundingBoxes2D(torch.cat([cxcy, wh], 1), "xcyc", False, labels=lab)
-            tframes.append(aloscene.Frame(torch.rand(3, 800, 1333, generator=gen) * 255, normalization="255",
-                                          boxes2d=bx).norm_resnet())
-        tframes = aloscene.Frame.batch_list(tframes).to(device)
-        crit, opt = build_criterion(), configure_optimizers(tmodel)
-        with alo_hip.LaunchTimer() as ttimer:
-            tsec = timed_steps(lambda: training_step(step_model, crit, opt, tframes)[0].item(), a.train_steps, 1, world, device)
-        tk = kernel_report(ttimer.summary())
-        kernels.update({k + "[train]": v for k, v in tk.items()})
-        train = {"metric": "frames/sec (whole node) DeformableDETR-R50 training step", "unit": "frames/s",
-                 "value": round(a.train_batch * world * a.train_steps / tsec, 3), "steps": a.train_steps, "warmup": 1,
-                 "ms_per_step": round(tsec / a.train_steps * 1e3, 2), "dtype": "f32",
-                 "config": {"workload": f"forward + Hungarian match + set loss + backward (alo_msda_backward) + clip + AdamW, "
-                                        f"{a.train_batch} synthetic 1333x800 frames x 10 boxes per GPU, global batch {a.train_batch * world}",
-                            "parallelism": "DDP over RCCL" if world > 1 else "single GPU"}}
-        bk = tk.get("msda_bwd/Lq=22223")
-        if bk is not None:   # HIP events around the launch (memset of grad_value + the tiled kernel), encoder-size calls only
-            train["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_tiled_kernel (+ hipMemsetAsync of grad_value), encoder call N=%d, Lq=S=22223, fp32" % a.train_batch,
-                                 "achieved": bk["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": bk["hbm_frac"], "traffic": None,
-                                 "alg_bytes_per_launch": bk["alg_bytes"], "ms_per_launch": bk["ms_avg"], "launches": bk["launches"]}
-        del tmodel, step_model, tframes, opt
-        torch.cuda.empty_cache()
+            torch.manual_seed(0)
+            tmodel = DeformableDetrR50(num_classes=91, aux_loss=True, device=device).train()
+            step_model = wrap_ddp(tmodel, local) if world > 1 else tmodel
+            gen = torch.Generator().manual_seed(777 + rank)
+            names = [f"class_{i}" for i in range(91)]
+            tframes = []
+            for _ in range(a.train_batch):
+                lab = aloscene.Labels(torch.randint(0, 91, (10,), generator=gen).float(), encoding="id", labels_names=names)
+                cxcy = torch.rand(10, 2, generator=gen) * 0.6 + 0.2
+                wh = torch.rand(10, 2, generator=gen) * 0.3 + 0.05
+                bx = aloscene.BoundingBoxes2D(torch.cat([cxcy, wh], 1), "xcyc", False, labels=lab)
+                tframes.append(aloscene.Frame(torch.rand(3, 800, 1333, generator=gen) * 255, normalization="255",
+                                              boxes2d=bx).norm_resnet())
+            tframes = aloscene.Frame.batch_list(tframes).to(device)
+            crit, opt = build_criterion(), configure_optimizers(tmodel)
+            with alo_hip.LaunchTimer() as ttimer:
+                tsec = timed_steps(lambda: training_step(step_model, crit, opt, tframes)[0].item(), a.train_steps, 1, world, device)
+            tk = kernel_report(ttimer.summary())
+            kernels.update({k + "[train]": v for k, v in tk.items()})
+            train = {"metric": "frames/sec (whole node) DeformableDETR-R50 training step", "unit": "frames/s",
+                     "value": round(a.train_batch * world * a.train_steps / tsec, 3), "steps": a.train_steps, "warmup": 1,
+                     "ms_per_step": round(tsec / a.train_steps * 1e3, 2), "dtype": "f32",
+                     "config": {"workload": f"forward + Hungarian match + set loss + backward (alo_msda_backward) + clip + AdamW, "
+                                            f"{a.train_batch} synthetic 1333x800 frames x 10 boxes per GPU, global batch {a.train_batch * world}",
+                                "parallelism": "DDP over RCCL" if world > 1 else "single GPU"}}
+            bk = tk.get("msda_bwd/Lq=22223")
+            if bk is not None:   # HIP events around the launch (memset of grad_value + the tiled kernel), encoder-size calls only
+                train["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_tiled_kernel (+ hipMemsetAsync of grad_value), encoder call N=%d, Lq=S=22223, fp32" % a.train_batch,
+                                     "achieved": bk["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": bk["hbm_frac"], "traffic": None,
+                                     "alg_bytes_per_launch": bk["alg_bytes"], "ms_per_launch": bk["ms_avg"], "launches": bk["launches"]}
+            del tmodel, step_model, tframes, opt
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            print(f"[bench] train leg failed ({type(exc).__name__}: {exc}); omitted from the line", file=sys.stderr, flush=True)
+            train = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.empty_cache()
 
     # ---- panoptic head (opt-in) ---------------------------------------------------------------------------------------
     panoptic = None
     if a.panoptic_steps > 0:
-        from alonet.deformable_detr_panoptic import DeformableDetrR50Panoptic
+        try:   # a secondary leg must never cost the headline line
+            from alonet.deformable_detr_panoptic import DeformableDetrR50Panoptic
 
-        torch.manual_seed(0)
-        pmodel = DeformableDetrR50Panoptic(num_classes=250, device=device).eval().to(dtype).to(memory_format=torch.channels_last)
-        pframes = detection_inputs(a.batch, rank, device, dtype)
-        keep = [torch.zeros(300, dtype=torch.bool, device=device) for _ in range(a.batch)]
-        for k in keep:  # random-init scores never pass the detector's threshold: keep a fixed, realistic query count
-            k[torch.arange(a.panoptic_queries, device=device) * (300 // a.panoptic_queries)] = True
+            torch.manual_seed(0)
+            pmodel = DeformableDetrR50Panoptic(num_classes=250, device=device).eval().to(dtype).to(memory_format=torch.channels_last)
+            pframes = detection_inputs(a.batch, rank, device, dtype)
+            keep = [torch.zeros(300, dtype=torch.bool, device=device) for _ in range(a.batch)]
+            for k in keep:  # random-init scores never pass the detector's threshold: keep a fixed, realistic query count
+                k[torch.arange(a.panoptic_queries, device=device) * (300 // a.panoptic_queries)] = True
 
-        def pan_step():
-            with torch.no_grad():
-                out = pmodel(pframes, filters=keep)
-                return pmodel.inference(out, filters=keep)
+            def pan_step():
+                with torch.no_grad():
+                    out = pmodel(pframes, filters=keep)
+                    return pmodel.inference(out, filters=keep)
 
-        psec = timed_steps(pan_step, a.panoptic_steps, 1, world, device)
-        panoptic = {"metric": "frames/sec (whole node) PanopticHead on DeformableDETR-R50", "unit": "frames/s",
-                    "value": round(a.batch * world * a.panoptic_steps / psec, 3), "steps": a.panoptic_steps, "warmup": 1,
-                    "ms_per_step": round(psec / a.panoptic_steps * 1e3, 2), "dtype": a.dtype if a.dtype != "fp32" else "f32",
-                    "config": {"workload": f"PanopticHead (MHAttentionMap + FPNstyleCNN) over DeformableDETR-R50, forward + "
-                                           f"inference() to aloscene.Mask, batch {a.batch} synthetic 1333x800 frames per GPU, "
-                                           f"{a.panoptic_queries} kept queries per frame",
-                               "per_gpu_batch": a.batch}}
-        del pmodel, pframes
-        torch.cuda.empty_cache()
+            psec = timed_steps(pan_step, a.panoptic_steps, 1, world, device)
+            panoptic = {"metric": "frames/sec (whole node) PanopticHead on DeformableDETR-R50", "unit": "frames/s",
+                        "value": round(a.batch * world * a.panoptic_steps / psec, 3), "steps": a.panoptic_steps, "warmup": 1,
+                        "ms_per_step": round(psec / a.panoptic_steps * 1e3, 2), "dtype": a.dtype if a.dtype != "fp32" else "f32",
+                        "config": {"workload": f"PanopticHead (MHAttentionMap + FPNstyleCNN) over DeformableDETR-R50, forward + "
+                                               f"inference() to aloscene.Mask, batch {a.batch} synthetic 1333x800 frames per GPU, "
+                                               f"{a.panoptic_queries} kept queries per frame",
+                                   "per_gpu_batch": a.batch}}
+            del pmodel, pframes
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            print(f"[bench] panoptic leg failed ({type(exc).__name__}: {exc}); omitted from the line", file=sys.stderr, flush=True)
+            panoptic = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.empty_cache()
 
     if rank != 0:
         if world > 1:

@@ -1,4 +1,4 @@
-"""The training step under DistributedDataParallel with world_size 2 on gloo (CPU): gradient all-reduce, the
+"""Two training steps under DistributedDataParallel with world_size 2 on gloo (CPU): gradient all-reduce, the
 criterion's all_reduce(num_boxes); the DDP-averaged gradients must equal the single-process gradients of the CONCATENATED
 batch (both ranks' frames in one forward), and both ranks must hold identical parameters after the step.  The attention runs through the
 reference's differentiable pure-torch branch (``is_tracing``) because the HIP op has no CPU implementation."""
@@ -59,6 +59,12 @@ WORKER = textwrap.dedent('''
             continue
         scale = max(1e-6, float(p.grad.abs().max()))
         worst = max(worst, float((ddp_grads[n] - p.grad).abs().max()) / scale)
+    opt.step()
+    # a SECOND step through the same DDP wrapper: with find_unused_parameters=False the reducer raises at this forward if any
+    # trainable parameter went without a gradient in the first one
+    opt.zero_grad()
+    total2, _ = crit(ddp(frames, is_tracing=None), frames)
+    total2.backward()
     opt.step()
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(2)]
