@@ -34,6 +34,9 @@ import os
 import sys
 import time
 
+# RCCL / device-tensor sharing between the ranks of one node needs dmabuf IPC on this driver (already exported on the GPU boxes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 
@@ -318,6 +321,8 @@ def main():
         return selftest(a)
     rank, world, local = init_dist(a.gpus, share_gpu=a.share_gpu)
     device = torch.device("cuda", local)
+    if world > 1:   # N processes share the host: keep each one's CPU pools (Hungarian matching, launch glue) to its share of the cores
+        torch.set_num_threads(max(1, min(32, (os.cpu_count() or 32) // world)))
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
     # ---- detection: the headline workload ---------------------------------------------------------------------------
