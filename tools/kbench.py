@@ -70,6 +70,12 @@ def msda_inputs(N, Lq, kind, dtype, seed=0):
     if kind == "encoder":
         assert Lq == S
         loc = encoder_like_locations(N, seed=seed)
+    elif kind == "survey":   # SURVEY 8(d)'s own micro-bench inputs: loc = own pixel centre + U(-0.05, 0.05) in normalised units
+        assert Lq == S
+        ref = torch.cat([torch.stack([(xs.reshape(-1) + 0.5) / w, (ys.reshape(-1) + 0.5) / h], -1)
+                         for (h, w) in DETR_SHAPES
+                         for ys, xs in [torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w, device=DEV), indexing="ij")]], 0)
+        loc = ref[None, :, None, None, None, :] + (torch.rand(N, S, 8, 4, 4, 2, generator=gen, device=DEV) - 0.5) * 0.1
     else:
         loc = torch.rand(N, Lq, 8, 4, 4, 2, generator=gen, device=DEV)
     attn = torch.softmax(torch.randn(N, Lq, 8, 16, generator=gen, device=DEV), -1).view(N, Lq, 8, 4, 4)
@@ -243,6 +249,10 @@ def main():
             res = [bench_msda_fwd(a.N, 300, "uniform", dt, a.reps) for dt in dts]
         elif w == "msda_bwd":
             res = [bench_msda_bwd(4, S, "encoder", torch.float32, max(3, a.reps // 4))]
+        elif w == "msda_survey":   # forward (fp32 / bf16 values) and backward on SURVEY 8(d)'s U(-0.05, 0.05) locations
+            res = [bench_msda_fwd(a.N, S, "survey", dt, a.reps) for dt in dts] + [bench_msda_bwd(4, S, "survey", torch.float32, max(3, a.reps // 4))]
+        elif w == "msda_bwd_rand":
+            res = [bench_msda_bwd(4, S, "uniform", torch.float32, max(3, a.reps // 4))]
         elif w == "corr_build":
             res = [bench_corr_build(a.B, max(3, a.reps // 4))]
         elif w == "corr_lookup":
