@@ -82,6 +82,10 @@ def parse():
                     help="also time K steps of PanopticHead over DeformableDETR-R50 (BASELINE configs[4]: --batch frames "
                          "per GPU, --panoptic-queries kept queries per frame); 0 = skip")
     ap.add_argument("--panoptic-queries", type=int, default=16)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="test only: create the RCCL process group (and wrap the training model in DDP) even with ONE rank, so the "
+                         "N > 1 code path (nccl init on the device, GPU barriers, the timing all-reduce, DDP's bucketed all-reduce) "
+                         "runs on a single-GPU box")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 and the control collectives run on gloo — drives the N > 1 GPU branch "
                          "(sharding, fences, max-over-ranks, DDP) on a one-GPU box; RCCL needs one device per rank")
@@ -90,7 +94,7 @@ def parse():
     return ap.parse_args()
 
 
-def init_dist(n_gpus, on_gpu=True, share_gpu=False):
+def init_dist(n_gpus, on_gpu=True, share_gpu=False, force=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
@@ -98,8 +102,9 @@ def init_dist(n_gpus, on_gpu=True, share_gpu=False):
         raise SystemExit(f"--gpus {n_gpus} needs WORLD_SIZE={n_gpus} (launch with torch.distributed.run); got {world}")
     if on_gpu:
         torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
         if on_gpu and not share_gpu:  # backend "nccl" is RCCL on ROCm; only the timing all-reduce and the barriers use it
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -110,14 +115,14 @@ def init_dist(n_gpus, on_gpu=True, share_gpu=False):
 def fence(world):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.barrier()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
 
 
 def max_over_ranks(seconds, world, device):
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -319,7 +324,7 @@ def main():
     a = parse()
     if a.selftest:
         return selftest(a)
-    rank, world, local = init_dist(a.gpus, share_gpu=a.share_gpu)
+    rank, world, local = init_dist(a.gpus, share_gpu=a.share_gpu, force=a.force_dist)
     device = torch.device("cuda", local)
     if world > 1:   # N processes share the host: keep each one's CPU pools (Hungarian matching, launch glue) to its share of the cores
         torch.set_num_threads(max(1, min(32, (os.cpu_count() or 32) // world)))
@@ -446,7 +451,7 @@ def main():
 
             torch.manual_seed(0)
             tmodel = DeformableDetrR50(num_classes=91, aux_loss=True, device=device).train()
-            step_model = wrap_ddp(tmodel, local) if world > 1 else tmodel
+            step_model = wrap_ddp(tmodel, local) if (world > 1 or a.force_dist) else tmodel
             gen = torch.Generator().manual_seed(777 + rank)
             names = [f"class_{i}" for i in range(91)]
             tframes = []
@@ -468,7 +473,7 @@ def main():
                      "ms_per_step": round(tsec / a.train_steps * 1e3, 2), "dtype": "f32",
                      "config": {"workload": f"forward + Hungarian match + set loss + backward (alo_msda_backward) + clip + AdamW, "
                                             f"{a.train_batch} synthetic 1333x800 frames x 10 boxes per GPU, global batch {a.train_batch * world}",
-                                "parallelism": "DDP over RCCL" if world > 1 else "single GPU"}}
+                                "parallelism": "DDP over RCCL" if (world > 1 or a.force_dist) else "single GPU"}}
             bk = tk.get("msda_bwd/Lq=22223")
             if bk is not None:   # HIP events around the launch (memset of grad_value + the tiled kernel), encoder-size calls only
                 train["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_tiled_kernel (+ hipMemsetAsync of grad_value), encoder call N=%d, Lq=S=22223, fp32" % a.train_batch,
@@ -515,7 +520,7 @@ def main():
             torch.cuda.empty_cache()
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -555,7 +560,7 @@ def main():
             raft["cpu_baseline"] = cpu_baseline_raft()
         line["cpu_kernels"] = cpu_kernel_baselines()
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

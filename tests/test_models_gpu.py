@@ -335,3 +335,27 @@ def test_bench_gpu_branch_with_two_ranks():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
     assert abs(line["value"] - 2 * 2 * 3 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 1e-3
     assert line["raft"]["value"] > 0 and line["panoptic"]["value"] > 0 and "cpu_baseline" not in line
+
+
+def test_bench_rccl_code_path_on_one_rank():
+    """What a multi-GPU run adds to bench.py, exercised on the one GPU of this box with a ONE-rank RCCL group (`--force-dist`):
+    `init_process_group("nccl", device_id=...)`, barriers and the timing all-reduce on device tensors, HIP-graph capture of the
+    forward while the communicator exists, and the training step under DistributedDataParallel with RCCL buckets."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2",
+           "--no-raft", "--train-steps", "2", "--train-batch", "1", "--panoptic-steps", "0", "--no-cpu-baseline", "--force-dist"]
+    env = dict(os.environ, OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert "error" not in line["train"], line["train"]
+    assert line["train"]["config"]["parallelism"] == "DDP over RCCL" and line["train"]["value"] > 0
+    assert "HIP graph" in line["config"]["launch"], line["config"]["launch"]   # capture worked beside the communicator
