@@ -51,7 +51,8 @@ def test_lookup_alone_on_the_reference_pyramid(golden):
 
 
 @pytest.mark.parametrize("B,C,H,W,r,L", [(2, 256, 24, 32, 4, 4), (1, 64, 19, 23, 4, 3), (3, 37, 16, 18, 2, 4),
-                                         (1, 128, 33, 47, 1, 2), (1, 16, 40, 40, 7, 4), (2, 8, 16, 16, 0, 1)])
+                                         (1, 128, 33, 47, 1, 2), (1, 16, 40, 40, 7, 4), (2, 8, 16, 16, 0, 1),
+                                         (3, 3, 5, 7, 1, 2)])   # last: C*H*W odd, so batch items 1.. are not 16-byte aligned
 def test_build_and_lookup_vs_oracle(B, C, H, W, r, L):
     rng = np.random.default_rng(B * 1000 + C + H)
     f1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
