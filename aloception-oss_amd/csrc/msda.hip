@@ -751,21 +751,22 @@ msda_bwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
 // anywhere) owns a TILE of 16 queries of one head — a 4x4 block of one pyramid level when the queries are the pyramid's own
 // pixels (Lq == S: the encoder's self-attention), 16 consecutive queries otherwise:
 //   1. lane (query i, level l) turns its 4 sampling points into taps; the wave reduces the per-level bounding box of all its
-//      taps (the WINDOW) and writes the scalar weights w_corner * attn into a dense matrix A[window pixel][16 queries] in LDS:
-//      plain read-add-write, no LDS atomics — lane (i, l) is the only writer of column i of level l's rows.
-//   2. grad_value of the window is the dense product  dV[pixel][ch] = sum_q A[pixel][q] * grad_out[q][ch]  (32 window rows x
-//      32 channels per MFMA tile, K = the 16 queries): ONE atomic row per touched window pixel per tile instead of one per
-//      corner — about 1/5 of the per-corner count.
+//      taps (the WINDOW), stacks the windows of the levels that fit together into one range of rows of its LDS region (with a
+//      table of where every row lives in the frame) and writes the scalar weights w_corner * attn into a dense matrix
+//      A[row][16 queries]: plain read-add-write, no LDS atomics — lane (i, l) is the only writer of column i of level l's rows.
+//   2. grad_value of the stacked rows is the dense product  dV[row][ch] = sum_q A[row][q] * grad_out[q][ch]  (32 rows x 32
+//      channels per MFMA tile, K = the 16 queries): ONE atomic row per touched window pixel per tile instead of one per corner —
+//      about 1/7 of the per-corner count; buffer atomics whose lanes aim past the slab where there is nothing to add.
 //   3. the channel dot products every sample needs, d[pixel][q] = <value[pixel], grad_out[q]>, are the transposed dense
 //      product over the same window, the value rows going from memory straight into the matrix operand; D lands in the wave's
 //      LDS region in place of A and lane (i, l) picks its 16 corner values from there:
 //      grad_attn = sum_k w_k d_k,  grad_loc = attn * (W, H) * (...).
 // Both products run on the fp32 matrix instructions (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32 FMA chains).
-// Tried and dropped (profiles/r02_msda_bwd.md): 4-wave workgroups that share a walk over the common bounding box of four tiles
-// (half the atomic rows, but two block barriers per pass: 0.89 against 0.78 ms); an exact three-way bf16 split of the operands
-// on the bf16 MFMAs (2.7x less matrix time, more split arithmetic than it saved: the kernel is bound by VALU issue and latency,
-// the matrix pipe is ~20 % busy); smaller LDS regions for 3-4 waves per SIMD (the register file spills first).
-// The wave's LDS region holds 310 window pixels; the levels are made resident in as many passes as it takes.  A level whose
+// Tried and dropped (DESIGN.md 4.2 has the table): 4-wave workgroups that share a walk over the common bounding box of four tiles
+// (half the atomic rows, but two block barriers per pass); three-term bf16 and two-term fp16 splits of the operands on the 16-bit
+// MFMAs (the matrix chain is not on the critical path); smaller LDS regions for 3-4 waves per SIMD (the register file spills
+// first); persistent waves, statically strided or fed from a queue (slower than one tile per hardware-dispatched workgroup).
+// The wave's LDS region holds 300 window pixels; the levels are made resident in as many passes as it takes.  A level whose
 // window does not fit (queries of a coarse level looking at a fine one, decoder queries, arbitrary locations) takes the
 // per-corner route of msda_bwd_kernel for that level only: same results, old cost.
 // ------------------------------------------------------------------------------------------------------------------
