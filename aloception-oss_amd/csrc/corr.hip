@@ -509,11 +509,12 @@ corr_lookup_kernel(const LookupArgs a) {
 
 // Lookup fused with the 1x1 convolution that consumes it: the window features never leave the chip.  RAFT's motion encoder
 // reads them in `convc1` (update.py:83-101: L*(2r+1)^2 -> Cout channels, + bias, ReLU); here that contraction runs level by
-// level on the bf16 matrix cores at fp32 accuracy, like the volume itself: out[b, n, query] = act(bias[n] + sum_l sum_k
+// level on the bf16 matrix cores at fp32 accuracy (the volume itself uses the two-term fp16 form; here its per-query scaling pass
+// costs more than it saves): out[b, n, query] = act(bias[n] + sum_l sum_k
 // W[n][l][k] * feature_l[k][query]) with every fp32 feature (and, once on the host side, every weight) split exactly into
 // three bf16 terms and the six largest cross products accumulated in fp32.
 // Per level: stage 1 as above; stage 2 writes the level's (2r+1)^2 features of the 32 queries to LDS as three bf16 planes in
-// operand order; then every wave multiplies them into the accumulators of its Cout / 4 output channels.  A store instruction
+// operand order; then every wave multiplies them into the accumulators of its 32 output channels.  A store instruction
 // writes two whole 128-byte lines (32 consecutive queries of one output channel).
 struct ConvArgs {
     const uint16_t* weight;   // [3 terms][L][KP / 16][Cout / 32][64 lanes][8] bf16: the convolution's weight regrouped per level
