@@ -399,22 +399,27 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     return out
 
 
-_HOST_SHAPES = {}
-
-
 def _host_spatial_shapes(spatial_shapes):
-    """Host copy of a device ``spatial_shapes`` tensor: the ``_alo_shapes`` attribute DeformableTransformer attaches, else one
-    device-to-host read per distinct tensor (cached on storage pointer + version; the geometry tensors live as long as the
-    model does)."""
-    host = getattr(spatial_shapes, "_alo_shapes", None)
+    """Host copy of a device ``spatial_shapes`` tensor.  It rides on the tensor OBJECT (``_alo_shapes``, tagged with the version
+    counter it was read at; DeformableTransformer attaches its own list when it builds the tensor), so it dies with the tensor: a cache
+    keyed on the storage pointer would hand a stale copy to the next 32-byte tensor the caching allocator places at that address.
+    Without the attribute: one device-to-host read, then cached on the object."""
+    host = getattr(spatial_shapes, "_alo_shapes", None)   # attached by the model that built the tensor
     if host is not None:
         return host
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(spatial_shapes.shape))
-    if key not in _HOST_SHAPES:
-        if len(_HOST_SHAPES) > 64:
-            _HOST_SHAPES.clear()
-        _HOST_SHAPES[key] = [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
-    return _HOST_SHAPES[key]
+    hit = getattr(spatial_shapes, "_alo_shapes_read", None)
+    if hit is not None and hit[0] == spatial_shapes._version:
+        return hit[1]
+    host = [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
+    spatial_shapes._alo_shapes_read = (spatial_shapes._version, host)
+    return host
+
+
+def _tiled_backward_eligible(value, dims, ldt):
+    """The shapes msda_bwd_tiled_kernel covers (csrc/msda.hip, backward_impl): fp32, D = 32, L = P = 4, queries = the pyramid's
+    own pixels.  Only then is the host copy of the shapes worth a device-to-host read."""
+    N, S, M, D, L, Lq, P = dims
+    return value.dtype == torch.float32 and ldt == ALO_F32 and D == 32 and L == 4 and P == 4 and Lq == S
 
 
 def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
@@ -429,7 +434,8 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
     grad_loc = torch.empty(loc.shape, dtype=gdt, device=value.device)
     grad_attn = torch.empty(attn.shape, dtype=gdt, device=value.device)
     nbytes = msda_backward_bytes(N, S, M, D, L, Lq, P, value.element_size(), loc.element_size())
-    host = _host_spatial_shapes(spatial_shapes) if Lq == S else None   # only the encoder's self-attention can use the hint
+    # only the encoder's self-attention on the DETR-family shape can use the hint (it sizes the grid of 4x4 query tiles)
+    host = _host_spatial_shapes(spatial_shapes) if _tiled_backward_eligible(value, dims, ldt) else None
     hint = None if host is None else (ctypes.c_int32 * (2 * L))(*[int(v) for hw in host for v in hw])
 
     def launch():
@@ -572,6 +578,7 @@ def invalidate_caches(module):
     weights, folded batch-norm convolutions, merged projections).  The caches are keyed on ``(tensor._version, data_ptr)``;
     in-place writes through ``.data`` (``p.data.copy_``, EMA updates, ``nn.init.*_(w.data)``) do not bump the version
     counter, so call this after such weight surgery — ``alonet.common.load_weights`` and ``GraphedForward`` do."""
+    module.__dict__["_cache_epoch_alo"] = module.__dict__.get("_cache_epoch_alo", 0) + 1   # GraphedForward re-captures on a new epoch
     for p in list(module.parameters()) + list(module.buffers()):
         for key in ("_alo_packed", "_alo_2d"):
             if key in getattr(p, "__dict__", {}):
@@ -579,6 +586,11 @@ def invalidate_caches(module):
     for m in module.modules():
         for key in [k for k in m.__dict__ if k.startswith("_alo_") or k in ("_folded", "_mask_quarter") or k.startswith("_zr")]:
             del m.__dict__[key]
+
+
+def cache_epoch(module):
+    """How many times :func:`invalidate_caches` ran on ``module`` — graphs captured under an older epoch read freed tensors."""
+    return module.__dict__.get("_cache_epoch_alo", 0)
 
 
 def add_layernorm(x, residual, weight, bias, eps=1e-5, pos=None):

@@ -27,6 +27,11 @@ class GraphedForward:
         self.warmup = warmup
         self.adopt_inputs = adopt_inputs
         self._graphs = {}
+        self._epoch = 0
+
+    def reset(self):
+        """Forget every captured graph (the next call captures again)."""
+        self._graphs.clear()
 
     @staticmethod
     def _key(frames, options):
@@ -35,7 +40,14 @@ class GraphedForward:
     def _capture(self, frames, options):
         import alo_hip
 
-        alo_hip.invalidate_caches(self.model)  # weights edited through .data since the last forward: re-derive before pinning
+        # Derived tensors (packed / folded / merged weights) are allocated in eager warm-ups, outside any graph's private pool, and
+        # every captured graph has their addresses baked in.  So they are re-derived only when NO graph of this object is alive —
+        # dropping them under a live graph would leave it replaying on freed memory.  Weight surgery later on goes through
+        # alo_hip.invalidate_caches(model) (load_weights calls it), which bumps the model's cache epoch: __call__ then drops
+        # every graph and captures again.
+        if not self._graphs:
+            alo_hip.invalidate_caches(self.model)  # weights edited through .data since the last forward: re-derive before pinning
+            self._epoch = alo_hip.cache_epoch(self.model)
         device = frames[0].device
         static_in = tuple(frames) if self.adopt_inputs else tuple(f.clone() for f in frames)
         side = torch.cuda.Stream(device=device)
@@ -55,6 +67,10 @@ class GraphedForward:
     def __call__(self, *frames, **options):
         if not frames or not all(f.is_cuda for f in frames):
             raise RuntimeError("GraphedForward: needs CUDA frames")
+        import alo_hip
+
+        if self._graphs and alo_hip.cache_epoch(self.model) != self._epoch:
+            self._graphs.clear()   # the tensors those graphs read were invalidated (load_weights, invalidate_caches): capture again
         key = self._key(frames, options)
         entry = self._graphs.get(key)
         if entry is None:

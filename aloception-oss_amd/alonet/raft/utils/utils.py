@@ -6,12 +6,12 @@ import torch.nn.functional as F
 def bilinear_sampler(img, coords, mode="bilinear", mask=False):
     """``grid_sample`` addressed in PIXEL coordinates (reference utils.py:5-19): ``img (N, C, H, W)``, ``coords
     (N, Ho, Wo, 2)`` with (x, y) in pixels, corners aligned.  With ``mask=True`` also returns the float mask of the
-    coordinates strictly inside the map.  The HIP ``CorrBlock`` lookup reproduces exactly this round trip
+    coordinates strictly inside the map.  ``mode`` is accepted and ignored, as in the reference.  The HIP ``CorrBlock`` lookup reproduces exactly this round trip
     (pixel -> [-1, 1] -> pixel) in its kernel; this torch form serves callers outside the correlation path."""
     H, W = img.shape[-2:]
     xgrid, ygrid = coords.split([1, 1], dim=-1)
     grid = torch.cat([2 * xgrid / (W - 1) - 1, 2 * ygrid / (H - 1) - 1], dim=-1)
-    out = F.grid_sample(img, grid, mode=mode, align_corners=True)
+    out = F.grid_sample(img, grid, align_corners=True)  # always bilinear: the reference accepts `mode` and ignores it (utils.py:14)
     if mask:
         inside = (grid[..., :1] > -1) & (grid[..., 1:] > -1) & (grid[..., :1] < 1) & (grid[..., 1:] < 1)
         return out, inside.float()
@@ -52,7 +52,10 @@ class Padder:
         out = F.pad(data[None] if lead else data, [self.left, self.right, self.top, self.bottom], mode="replicate")
         out = out[0] if lead else out
         if hasattr(frame, "as_tensor"):
-            return type(frame)(out, normalization=frame.normalization, mean_std=frame.mean_std, names=names)
+            # the pixels are padded, the frame's labels and properties are not: they ride along unchanged, as with the
+            # reference's F.pad on the augmented tensor ("pad frame but not its labels", utils.py:46-51)
+            res = out.as_subclass(type(frame))
+            return res._inherit(frame, names) if hasattr(res, "_inherit") else res
         return out
 
     def unpad(self, tensor):

@@ -30,6 +30,20 @@ inline int check_launch(const char* what) {
     return ALO_OK;
 }
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): a function attribute is per device, so a process-wide flag
+// would leave the second GPU of a single-process multi-GPU job at the 48/64 KB default.  `done` is one atomic bit mask per
+// call site (up to 64 devices); the attribute call itself is idempotent, so a race only repeats it.
+inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
 
 // Remap a launch-order block id so that each XCD (private 4 MiB L2) receives one CONTIGUOUS range of logical work

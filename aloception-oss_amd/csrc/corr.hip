@@ -45,9 +45,15 @@ pool2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// largest magnitude of each batch item of a (B, per_batch) fp32 tensor, as the bit pattern of a non-negative float (they order
-// like unsigned integers; a NaN ends up on top).  `bits` must be zero on entry.
+// largest FINITE magnitude of each batch item of a (B, per_batch) fp32 tensor, as the bit pattern of a non-negative float (they
+// order like unsigned integers).  Inf / NaN entries do not take part: the item's scale comes from its finite values, so a
+// non-finite feature spoils exactly its own row / column of the volume (as in the reference's fp32 matmul) and every other
+// entry keeps its full accuracy.  `bits` must be zero on entry.
 // ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned finite_mag(unsigned bits) {
+    const unsigned m = bits & 0x7fffffffu;
+    return m >= 0x7f800000u ? 0u : m;
+}
 __global__ void __launch_bounds__(256)
 corr_absmax_kernel(const float* __restrict__ in, unsigned* __restrict__ bits, long per_batch) {
     const int b = blockIdx.y;
@@ -57,10 +63,10 @@ corr_absmax_kernel(const float* __restrict__ in, unsigned* __restrict__ bits, lo
 #pragma unroll 8   // eight independent 16-byte loads in flight per thread
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
         const u32x4 v = reinterpret_cast<const u32x4*>(p)[i];
-        m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+        m = max(max(m, finite_mag(v.x)), max(max(finite_mag(v.y), finite_mag(v.z)), finite_mag(v.w)));
     }
     for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < per_batch; i += (long)gridDim.x * 256L)
-        m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+        m = max(m, finite_mag(__float_as_uint(p[i])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
     // one atomic per workgroup: they all aim at the item's one word and serialize there
@@ -74,7 +80,7 @@ corr_absmax_kernel(const float* __restrict__ in, unsigned* __restrict__ bits, lo
 }
 
 // The power of two a batch item is divided by before it is split: its largest magnitude lands in [2^14, 2^15) (fp16 holds up to
-// 65504), so the low terms of all but the very smallest values stay normal fp16 numbers.  0 for an all-zero, infinite or NaN item.
+// 65504), so the low terms of all but the very smallest values stay normal fp16 numbers.  0 for an item without a finite non-zero value.
 __device__ __forceinline__ int split_exponent(unsigned absmax_bits) {
     const int e = (int)(absmax_bits >> 23);
     if (e == 0 || e == 255) return 0;
@@ -653,12 +659,10 @@ int launch_lookup(const LookupArgs& a, hipStream_t stream) {
 }
 template <int R>
 int launch_lookup_conv(const LookupArgs& a, const ConvArgs& cv, hipStream_t stream) {
-    static bool attr_set = false;   // per template instance
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_lookup_conv_kernel<R>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ConvLds<R>::bytes);
+    static unsigned long long attr_done = 0;   // per template instance, one bit per device
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(corr_lookup_conv_kernel<R>), (int)ConvLds<R>::bytes, &attr_done);
         if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_lookup_conv1x1: %s", hipGetErrorString(e));
-        attr_set = true;
     }
     hipLaunchKernelGGL(corr_lookup_conv_kernel<R>, dim3(a.B * a.tiles_per_batch), dim3(kConvThreads), ConvLds<R>::bytes, stream, a, cv);
     return check_launch("alo_corr_lookup_conv1x1");
@@ -783,12 +787,11 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
     long nblocks = (long)((g.tiles_m + kRowGroup - 1) / kRowGroup) * kRowGroup * g.tiles_r * g.tiles_c * B;
     ALO_REQUIRE(nblocks < 0x7fffffffL, ALO_ERR_UNSUPPORTED, "alo_corr_build: grid too large");
     g.nblocks = (unsigned)nblocks;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_gemm3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(corr_gemm3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+    static unsigned long long attr_done[2] = {0, 0};   // one bit per device
+    {
+        hipError_t e1 = ensure_dynamic_lds(reinterpret_cast<const void*>(corr_gemm3_kernel<true>), kGemmLds, &attr_done[0]);
+        hipError_t e2 = ensure_dynamic_lds(reinterpret_cast<const void*>(corr_gemm3_kernel<false>), kGemmLds, &attr_done[1]);
         if (e1 != hipSuccess || e2 != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_build: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-        attr_set = true;
     }
     hipLaunchKernelGGL(corr_gemm3_kernel<true>, dim3(g.nblocks), dim3(kGemmThreads), kGemmLds, stream, g);
     if (int rc = check_launch("alo_corr_build(gemm)")) return rc;

@@ -220,12 +220,8 @@ int launch_shortk(const void* x, const void* weight, const void* bias, const voi
     if (gx > dm.tiles) gx = dm.tiles;
     if (gx < 1) gx = 1;
     void* args[] = {&x, &weight, &bias, &residual, &y, &dm};
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES, HM>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;  // per instantiation (lds depends on K only), one bit per device
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES, HM>), (int)lds, &attr_done);
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(linear_shortk_kernel<K, RELU, HAS_RES, HM>), dim3(gx, cols), dim3(256), args,
                                    lds, stream);
     if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_linear_shortk: %s", hipGetErrorString(e));
@@ -497,10 +493,15 @@ extern "C" int alo_ffn256(const void* x, const void* w1, const void* b1, const v
     const size_t lds = 2 * kFfnRows * kFfnStride + ((size_t)F + 256) * sizeof(float);
     int gx = dm.tiles < 512 ? dm.tiles : 512;
     void* args[] = {&x, &w1, &b1, &w2, &b2, &y, &dm};
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ffn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    if (lds > 160 * 1024) return fail(ALO_ERR_UNSUPPORTED, "alo_ffn256: hidden width %d needs %zu bytes of LDS", F, lds);
+    {   // lds grows with F: keep the largest limit set so far per device (a process-wide flag would miss a second device or a wider F)
+        static int limit_set[64] = {0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if ((int)lds > __atomic_load_n(&limit_set[dev & 63], __ATOMIC_ACQUIRE)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+                __atomic_store_n(&limit_set[dev & 63], (int)lds, __ATOMIC_RELEASE);
+        }
     }
     hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(ffn256_kernel), dim3(gx), dim3(256), args, lds,
                                    static_cast<hipStream_t>(stream));

@@ -780,9 +780,7 @@ constexpr int kTileLds = kWaveRegion + kRowTable * 4;   // 20480 bytes: 8 waves 
 struct TileDims {
     int S, M, Lq;
     int pyramid;        // 1: Lq == S and the queries are tiled as 4x4 blocks of their level; 0: 16 consecutive queries
-    int n_super;        // tiles per batch item
-    int tile0[4];       // pyramid: first tile of each level
-    int tiles_w[4];     // pyramid: tiles per row of each level
+    int n_super;        // tiles per batch item (pyramid: sum over levels of ceil(H/4) * ceil(W/4), from the host's copy of the shapes)
     unsigned nblocks;
 };
 
@@ -827,15 +825,25 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     const int M = td.M, S = td.S, Lq = td.Lq;
 
     // ---- which queries --------------------------------------------------------------------------------------------------
-    int lq = 0;
+    // The 4x4 tiling of every level is derived HERE from the device copy of the shapes (the one the arithmetic below uses); the
+    // host only sized the grid.  A tile index past the device-side tile count has no queries (query_of() returns -1).
+    int lq = 0, t0q = 0, twq = 1;
+    bool no_tile = false;
     if (td.pyramid) {
+        int t0 = 0;
+        lq = -1;
 #pragma unroll
-        for (int l = 1; l < 4; ++l)
-            if (st >= td.tile0[l]) lq = l;
+        for (int l = 0; l < 4; ++l) {
+            const int th = (shapes[2 * l] + 3) >> 2, tw = (shapes[2 * l + 1] + 3) >> 2;
+            if (lq < 0 && st < t0 + th * tw) { lq = l; t0q = t0; twq = tw; }
+            t0 += th * tw;
+        }
+        no_tile = lq < 0;
+        if (no_tile) lq = 0;
     }
-    const int trow = td.pyramid ? (st - td.tile0[lq]) / td.tiles_w[lq] : 0;
-    const int tcol = td.pyramid ? (st - td.tile0[lq]) - trow * td.tiles_w[lq] : 0;
-    const int Hq = shapes[2 * lq], Wq = shapes[2 * lq + 1], Sq = lstart[lq];
+    const int trow = td.pyramid ? (st - t0q) / twq : 0;
+    const int tcol = td.pyramid ? (st - t0q) - trow * twq : 0;
+    const int Hq = no_tile ? 0 : shapes[2 * lq], Wq = shapes[2 * lq + 1], Sq = lstart[lq];
     auto query_of = [&](int i) -> int {   // slot i of the tile -> query index, -1 past the edge
         if (td.pyramid) {
             const int qy = trow * 4 + (i >> 2), qx = tcol * 4 + (i & 3);
@@ -1397,19 +1405,18 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
         td.S = S; td.M = M; td.Lq = Lq;
         td.pyramid = 0;
         td.n_super = (Lq + 15) / 16;
-        for (int l = 0; l < 4; ++l) { td.tile0[l] = 0; td.tiles_w[l] = 1; }
         const int tile = 4;
         if (host_shapes && Lq == S) {
-            // queries = the pyramid's own pixels (encoder self-attention): 4x4 blocks of each level.  Only how queries are
-            // grouped depends on this; the kernel reads the geometry it computes with from the device copy.
+            // queries = the pyramid's own pixels (encoder self-attention): 4x4 blocks of each level.  The host copy of the shapes
+            // only SIZES the grid; the kernel derives which queries a tile owns from the device copy.  A host copy that disagrees
+            // with the device one can therefore only leave tiles empty or — if it under-counts — miss queries, which is why the
+            // Python host never caches it across tensors (alo_hip.msda_backward).
             long total = 0;
             int tiles = 0;
             bool ok = true;
             for (int l = 0; l < 4; ++l) {
                 const int h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
                 ok = ok && h > 0 && w > 0;
-                td.tile0[l] = tiles;
-                td.tiles_w[l] = (w + tile - 1) / tile;
                 tiles += ((h + tile - 1) / tile) * ((w + tile - 1) / tile);
                 total += (long)h * w;
             }
@@ -1418,12 +1425,10 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
         const long nb = (long)N * td.n_super * M;
         ALO_REQUIRE(nb < 0x7fffffffL, ALO_ERR_UNSUPPORTED, "alo_msda_backward: grid too large");
         td.nblocks = (unsigned)nb;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_tiled_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, kTileLds);
+        {
+            static unsigned long long attr_done = 0;   // one bit per device
+            hipError_t ea = ensure_dynamic_lds(reinterpret_cast<const void*>(msda_bwd_tiled_kernel), kTileLds, &attr_done);
             if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward: %s", hipGetErrorString(ea));
-            attr_set = true;
         }
         void* targs[] = {&value, &spatial_shapes, &level_start_index, &sampling_loc, &attn_weight, &grad_out,
                          &grad_value, &grad_sampling_loc, &grad_attn_weight, &td};

@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Benchmark of the dense-vision hot path on MI355X — prints ONE JSON line (see the driver's contract).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Started under ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every
+process is one rank; started plainly — ``python bench.py --gpus 8`` — it spawns its own N ranks through
+``torch.distributed.run --nproc-per-node N`` on 127.0.0.1 and rank 0 prints the line (the reference picks DDP by itself when it
+sees more than one device: alonet/common/pl_helpers.py:365-374).
 
 Step = one inference pass of DeformableDETR-R50 (``forward`` + ``inference``) over one batch of 8 synthetic 1333x800
 frames per GPU in bf16 — BASELINE.json configs[1].  ``value`` = frames/s of the whole job (all ranks), timed over
@@ -24,6 +29,13 @@ Beside it, in the same line:
   train         BASELINE.json configs[3] per-GPU share (fp32, 4 frames): forward + match + loss + alo_msda_backward + AdamW;
                 carries its own roofline entry for msda_bwd_tiled_kernel (HBM-bound, algorithmic bytes SURVEY 8d).
   panoptic      BASELINE.json configs[4] per-GPU share (bf16, 8 frames, 16 kept queries per frame).
+  eager         the same detection step with eager launches (no HIP graph), timed right after the headline steps.
+  fp32          the same detection workload in fp32 — the mode that meets the north-star's <= 1e-3 bar against the reference op,
+                which is float / double only (ms_deform_attn_cuda.cu:64) — with its own MSDA roofline entry.
+  micro         SURVEY 8(d)'s kernel micro-benchmarks on synthetic sampling distributions (model-like ring, own pixel centre +
+                U(-0.05, 0.05), uniform over the map) for the MSDA forward (N = 8) and backward (N = 4): the window-dense backward
+                depends on where the samples fall, so all three are in the line.
+  plumbing      BASELINE.json configs[0]: alonet.detr.DetrR50 on one 640x480 aloscene.Frame on the host CPU (rank 0, N = 1).
   cpu_baseline  rank 0, N = 1 only: the reference's CPU path (oracle/torch_ref.py, the torch restatement of
                 ms_deform_attn_core_pytorch / CorrBlock) on the host cores, on bounded samples: the detection model graph
                 (headline), the RAFT model graph (``raft.cpu_baseline``) and the two kernel-level units of SURVEY 8d
@@ -73,6 +85,12 @@ def parse():
     ap.add_argument("--no-raft", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch the detector's forward eagerly instead of replaying its HIP graph")
+    ap.add_argument("--eager-steps", type=int, default=10,
+                    help="also time K detection steps with eager launches after the graph-replayed ones (0 = skip)")
+    ap.add_argument("--fp32-steps", type=int, default=5,
+                    help="also time K detection steps in fp32 (the <= 1e-3 mode; skipped when --dtype fp32 is the headline); 0 = skip")
+    ap.add_argument("--micro-reps", type=int, default=10,
+                    help="launches per SURVEY 8(d) kernel micro-benchmark (MSDA forward / backward on three sampling distributions); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the bounded CPU sample (~13 s on 32 threads)")
     ap.add_argument("--train-steps", type=int, default=3,
@@ -95,12 +113,34 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` (N > 1) outside a torch.distributed environment: spawn the N ranks ourselves — one process
+    per GPU through ``torch.distributed.run`` on 127.0.0.1 (RCCL for the fences on the GPU, gloo in --selftest / --share-gpu) —
+    hand their output through and exit with their status.  Inside such an environment (WORLD_SIZE set) this is a no-op."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+
+    if not a.selftest and not a.share_gpu and torch.cuda.is_available() and torch.cuda.device_count() < a.gpus:
+        raise SystemExit(f"--gpus {a.gpus}: this node exposes {torch.cuda.device_count()} device(s); one rank per GPU is needed")
+    with socket.socket() as sk:   # a free rendezvous port (the driver may run several benches on one host back to back)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(32, (os.cpu_count() or 32) // a.gpus))))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def init_dist(n_gpus, on_gpu=True, share_gpu=False, force=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if n_gpus > 1 and world != n_gpus:
-        raise SystemExit(f"--gpus {n_gpus} needs WORLD_SIZE={n_gpus} (launch with torch.distributed.run); got {world}")
+        raise SystemExit(f"--gpus {n_gpus} but the environment says WORLD_SIZE={world}: launch N ranks (or unset WORLD_SIZE and let "
+                         "bench.py spawn them)")
     if on_gpu:
         torch.cuda.set_device(local)
     if world > 1 or force:
@@ -270,6 +310,58 @@ def cpu_kernel_baselines():
     return out
 
 
+def micro_benchmarks(reps):
+    """the MSDA kernels alone, B = 8 forward / B = 4 backward at the 1333x800 pyramid, on three synthetic
+    sampling distributions (generators: tools/kbench.py) — `ring`: the module's initial head-direction ring of 1-4 px + jitter
+    (what a randomly initialised model, i.e. bench.py's detection and training legs, produce); `survey`: own pixel centre +
+    U(-0.05, 0.05) in normalised units (SURVEY 8(d)'s encoder-like input: +-8 x +-5 px on level 0); `uniform`: U(0, 1) over the
+    whole map (decoder-like / worst case).  HIP events around `reps` back-to-back launches."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kbench
+
+    S = sum(h * w for h, w in kbench.DETR_SHAPES)
+    out = {}
+
+    def entry(r):
+        return {"ms": round(r["ms"], 4), "alg_bytes": r["alg_bytes"], "GBps": round(r["GBps"], 1),
+                "hbm_frac": round(r["GBps"] / HBM_PEAK_GBPS, 4)}
+
+    for r in kbench.bench_msda_fused_hm(8, reps):   # the bench's own kernel (bf16, fused prologue, head-major) on ring locations
+        if r["kernel"].startswith("msda_fwd"):
+            out["msda_fwd_fused_hm[ring] bf16 N=8"] = entry(r)
+    for kind, tag in (("encoder", "ring"), ("survey", "survey"), ("uniform", "uniform")):
+        for dt, dn in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
+            out[f"msda_fwd[{tag}] {dn} N=8"] = entry(kbench.bench_msda_fwd(8, S, kind, dt, reps))
+        out[f"msda_bwd[{tag}] f32 N=4"] = entry(kbench.bench_msda_bwd(4, S, kind, torch.float32, max(3, reps // 2)))
+        torch.cuda.empty_cache()
+    return out
+
+
+def plumbing_config0():
+    """BASELINE.json configs[0]: alonet.detr.DetrR50 inference on ONE 640x480 aloscene.Frame through the PyTorch CPU path (the
+    reference's CPU-runnable case, alonet/detr/detr_r50.py:55-75): plumbing, no HIP kernel involved."""
+    from alonet.detr import DetrR50
+
+    cores, avail = _cpu_threads()
+    torch.manual_seed(0)
+    model = DetrR50(num_classes=91, aux_loss=False).eval()
+    gen = torch.Generator().manual_seed(99)
+    frame = aloscene.Frame(torch.rand(3, 480, 640, generator=gen) * 255, normalization="255").norm_resnet()
+    frames = aloscene.Frame.batch_list([frame])
+    with torch.no_grad():
+        model.inference(model(frames))   # warm-up (thread pools, lazy caches)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3:
+            out = model(frames)
+            boxes = model.inference(out)
+            n += 1
+        spent = (time.perf_counter() - t0) / n
+    return {"workload": "alonet.detr.DetrR50, one 640x480 aloscene.Frame, forward + inference(), PyTorch CPU path, fp32",
+            "ms_per_frame": round(spent * 1e3, 1), "frames_per_s": round(1.0 / spent, 2), "cores": cores,
+            "pred_logits": list(out["pred_logits"].shape), "boxes_kept": int(boxes[0].shape[0])}
+
+
 def offline_traffic(a):
     """FETCH_SIZE + WRITE_SIZE per launch of the dominant kernel from the committed offline PMC collection (not this run)."""
     path = os.path.join(ROOT, "profiles", "msda_fwd_traffic.json")
@@ -298,6 +390,72 @@ def kernel_report(summary):
     return rep
 
 
+def detection_leg(a, rank, world, device, dtype, steps, warmup, eager_steps, full_table):
+    """DeformableDETR-R50 inference on one resident batch: ``steps`` timed steps (HIP-graph replay unless --no-graph), then
+    ``eager_steps`` timed steps with eager launches whose MSDA-forward launches carry HIP-event pairs (the in-step roofline
+    figure), then — ``full_table`` — two un-timed eager steps with an event pair around every launch of this library."""
+    model = build_detector(device, dtype)
+    frames = detection_inputs(a.batch, rank, device, dtype)
+
+    def eager_step():
+        with torch.no_grad():
+            out = model(frames)
+            return model.inference(out)  # ends with boxes.cpu(): the step is complete when it returns
+
+    graph = not a.no_graph
+    det_step = eager_step
+    if graph:
+        # The forward (~200 launches at a fixed shape) is captured once in a HIP graph and replayed: same kernels, same bits,
+        # back-to-back dispatch.  inference() — the device-to-host hand-over — runs eagerly every step.
+        from alonet.common import GraphedForward
+
+        # adopt_inputs: the graph reads the resident batch where it lies, as the eager path does (a serving loop would land each
+        # new batch's H2D copy in that same buffer)
+        graphed = GraphedForward(model, adopt_inputs=True)
+
+        def det_step():
+            with torch.no_grad():
+                return model.inference(graphed(frames))
+
+        try:
+            graphed(frames)  # capture outside the timed region (as the eager path's first-call caches are)
+        except Exception as exc:  # a runtime that cannot capture: the eager launches measure the same kernels
+            print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr, flush=True)
+            graph = False
+            det_step = eager_step
+
+    # Eager launches: inside the timed steps only the dominant kernel's launches carry an event pair (6 per step) — an event
+    # pair around each of the ~150 launches of this library per step costs the GPU more than a millisecond of dispatch
+    # bubbles.  Graph replay: no host-side wrapper runs, so nothing is instrumented inside the timed steps at all; the pairs
+    # then come from the eager steps timed right after them.
+    with alo_hip.LaunchTimer(only="msda_fwd") as timer:
+        seconds = timed_steps(det_step, steps, warmup, world, device)
+        eager_seconds = None
+        if graph and eager_steps > 0:
+            eager_seconds = timed_steps(eager_step, eager_steps, 1, world, device)
+        elif graph:
+            eager_step()
+            eager_step()
+    kernels = {}
+    src_timer = timer
+    if full_table:
+        with alo_hip.LaunchTimer() as full_timer:   # the table of every kernel of this library: two extra, un-timed EAGER steps
+            eager_step()
+            eager_step()
+        kernels = kernel_report(full_timer.summary())
+        if not any(k.startswith("msda_fwd") for k in timer.relaunch):
+            src_timer = full_timer
+    kernels.update(kernel_report(timer.summary()))  # includes warm-up launches of the same shapes
+    # the dominant kernel once more, 20 launches back to back on the buffers of its last in-model call: a single-launch
+    # event pair also spans the dispatch gaps around the launch (tens of microseconds), a train does not
+    enc_tag = next((k for k in src_timer.relaunch if k.startswith("msda_fwd") and k.endswith("Lq=22223")), None)
+    enc_b2b_ms = src_timer.replay_ms(enc_tag, 20) if enc_tag else None
+    del model, frames
+    torch.cuda.empty_cache()
+    return {"seconds": seconds, "eager_seconds": eager_seconds, "kernels": kernels, "enc_b2b_ms": enc_b2b_ms,
+            "launch": "HIP graph replay" if graph else "eager", "graph": graph}
+
+
 def selftest(a):
     """Same launch / shard / fence / max-over-ranks code path as the real run, on CPU tensors over gloo."""
     rank, world, _ = init_dist(a.gpus, on_gpu=False)
@@ -323,6 +481,7 @@ def selftest(a):
 
 def main():
     a = parse()
+    self_launch(a)   # --gpus N > 1 without a torch.distributed environment: re-executes under torch.distributed.run and exits
     if a.selftest:
         return selftest(a)
     rank, world, local = init_dist(a.gpus, share_gpu=a.share_gpu, force=a.force_dist)
@@ -332,55 +491,28 @@ def main():
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
     # ---- detection: the headline workload ---------------------------------------------------------------------------
-    model = build_detector(device, dtype)
-    frames = detection_inputs(a.batch, rank, device, dtype)
-
-    def eager_step():
-        with torch.no_grad():
-            out = model(frames)
-            return model.inference(out)  # ends with boxes.cpu(): the step is complete when it returns
-
-    if a.no_graph:
-        det_step = eager_step
-    else:
-        # The forward (~200 launches at a fixed shape) is captured once in a HIP graph and replayed: same kernels, same bits,
-        # back-to-back dispatch.  inference() — the device-to-host hand-over — runs eagerly every step.
-        from alonet.common import GraphedForward
-
-        # adopt_inputs: the graph reads the resident batch where it lies, as the eager path does (a serving loop would land each
-        # new batch's H2D copy in that same buffer)
-        graphed = GraphedForward(model, adopt_inputs=True)
-
-        def det_step():
-            with torch.no_grad():
-                return model.inference(graphed(frames))
-
-        try:
-            graphed(frames)  # capture outside the timed region (as the eager path's first-call caches are)
-        except Exception as exc:  # a runtime that cannot capture: the eager launches measure the same kernels
-            print(f"[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr, flush=True)
-            a.no_graph = True
-            det_step = eager_step
-
-    # Eager launches: inside the timed steps only the dominant kernel's launches carry an event pair (6 per step) — an event
-    # pair around each of the ~150 launches of this library per step costs the GPU more than a millisecond of dispatch
-    # bubbles.  Graph replay: no host-side wrapper runs, so nothing is instrumented inside the timed steps at all.
-    with alo_hip.LaunchTimer(only="msda_fwd") as timer:
-        det_seconds = timed_steps(det_step, a.steps, a.warmup, world, device)
-    dominant = kernel_report(timer.summary())  # includes warm-up launches of the same shapes
-    with alo_hip.LaunchTimer() as full_timer:   # the table of every kernel of this library: two extra, un-timed EAGER steps
-        eager_step()
-        eager_step()
-    kernels = kernel_report(full_timer.summary())
-    kernels.update(dominant)
-    # the dominant kernel once more, 20 launches back to back on the buffers of its last in-model call: a single-launch
-    # event pair also spans the dispatch gaps around the launch (tens of microseconds), a train does not
-    src_timer = timer if any(k.startswith("msda_fwd") for k in timer.relaunch) else full_timer
-    enc_tag = next((k for k in src_timer.relaunch if k.startswith("msda_fwd") and k.endswith("Lq=22223")), None)
-    enc_b2b_ms = src_timer.replay_ms(enc_tag, 20) if enc_tag else None
+    det = detection_leg(a, rank, world, device, dtype, a.steps, a.warmup, a.eager_steps, full_table=True)
+    det_seconds, kernels, enc_b2b_ms = det["seconds"], det["kernels"], det["enc_b2b_ms"]
     det_fps = a.batch * world * a.steps / det_seconds
-    del model, frames
-    torch.cuda.empty_cache()
+    # the same workload in fp32: the reference op is float / double only, and the north-star's <= 1e-3 bar is an fp32 statement
+    fp32 = None
+    if a.fp32_steps > 0 and dtype != torch.float32:
+        try:
+            d32 = detection_leg(a, rank, world, device, torch.float32, a.fp32_steps, 2, 0, full_table=False)
+            e32 = next((v for k, v in d32["kernels"].items() if k.startswith("msda_fwd") and k.endswith("Lq=22223")), None)
+            fp32 = {"metric": "frames/sec (whole node) DeformableDETR-R50 inference, fp32", "unit": "frames/s", "dtype": "f32",
+                    "value": round(a.batch * world * a.fp32_steps / d32["seconds"], 3), "steps": a.fp32_steps, "warmup": 2,
+                    "ms_per_step": round(d32["seconds"] / a.fp32_steps * 1e3, 3), "launch": d32["launch"],
+                    "note": "the mode that meets <= 1e-3 max-abs against the reference path (tests/test_models_gpu.py); the bf16 headline "
+                            "is held to the stated bf16 tolerances instead"}
+            if e32 is not None:
+                fp32["roofline"] = {"bound": "hbm", "kernel": "msda_fwd_kernel<float, fused prologue> (encoder call, N=%d, Lq=S=22223)" % a.batch,
+                                    "achieved": e32["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": e32["hbm_frac"], "traffic": None,
+                                    "alg_bytes_per_launch": e32["alg_bytes"], "ms_per_launch": e32["ms_avg"]}
+        except Exception as exc:
+            print(f"[bench] fp32 leg failed ({type(exc).__name__}: {exc}); omitted from the line", file=sys.stderr, flush=True)
+            fp32 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.empty_cache()
 
     # ---- flow -------------------------------------------------------------------------------------------------------
     raft = None
@@ -425,6 +557,14 @@ def main():
                                                "launch": "eager" if raft_step is raft_eager else "HIP graph replay",
                                                "per_gpu_batch": a.raft_batch}}
             cb = rk.get("corr_build") or rk_all.get("corr_build")  # graph replay runs no host wrapper: take the eager pass's events
+            lk = rk_all.get("corr_lookup")
+            if cb is not None and lk is not None:
+                # what section 8's two kernels contribute to the step: the pairs/s figure above is NOT a statement about them — the
+                # rest of the step is RAFT's encoders and update block on stock MIOpen fp32 convolutions (north_star keeps them stock)
+                raft["hot_path_ms_per_step"] = round(cb["ms_avg"] + lk["ms_avg"] * lk["launches"], 3)
+                raft["hot_path"] = {"corr_build_ms": cb["ms_avg"], "corr_lookup_ms": lk["ms_avg"], "lookups_per_step": lk["launches"],
+                                    "share_of_step": round((cb["ms_avg"] + lk["ms_avg"] * lk["launches"]) / (raft_seconds / a.raft_steps * 1e3), 4),
+                                    "rest_of_step": "feature / context encoders + 32 x update block: stock PyTorch-ROCm (MIOpen fp32 convolutions)"}
             if cb is not None:
                 # With three fp16 products the contraction needs 0.52 ms of matrix time at peak and the 4.5 GB it writes need 0.56 ms of
                 # HBM time: the write stream is the larger of the two (SURVEY 8(d) predicted the cross-over), so that is the roofline
@@ -520,6 +660,16 @@ def main():
             panoptic = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             torch.cuda.empty_cache()
 
+    # ---- SURVEY 8(d) kernel micro-benchmarks (rank 0 only: they are per-kernel figures, not part of the scaling metric) --------
+    micro = None
+    if rank == 0 and a.micro_reps > 0:
+        try:
+            micro = micro_benchmarks(a.micro_reps)
+        except Exception as exc:
+            print(f"[bench] micro-benchmarks failed ({type(exc).__name__}: {exc}); omitted from the line", file=sys.stderr, flush=True)
+            micro = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.empty_cache()
+
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -533,7 +683,7 @@ def main():
         "vs_baseline": None, "dtype": a.dtype if a.dtype != "fp32" else "f32", "data": "synthetic",
         "config": {"workload": f"DeformableDETR-R50 inference (forward + inference()), batch {a.batch} synthetic 1333x800 frames per GPU, "
                                "MSDeformAttn on HIP kernels; random-init weights",
-                   "launch": "eager" if a.no_graph else "HIP graph of the forward replayed per step on the resident batch (inference() eager)",
+                   "launch": "HIP graph of the forward replayed per step on the resident batch (inference() eager)" if det["graph"] else "eager",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": None if enc is None else {
             "bound": "hbm", "kernel": "msda_fwd_bf16_mfma_kernel<4, fused, head-major> (encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
@@ -550,6 +700,14 @@ def main():
             "frac_back_to_back": round(enc["alg_bytes"] / (enc_b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if enc_b2b_ms else None},
         "kernels": kernels,
     }
+    if det["eager_seconds"]:
+        line["eager"] = {"value": round(a.batch * world * a.eager_steps / det["eager_seconds"], 3), "unit": "frames/s", "steps": a.eager_steps,
+                         "warmup": 1, "ms_per_step": round(det["eager_seconds"] / a.eager_steps * 1e3, 3),
+                         "launch": "eager (every launch from the host; the dominant kernel's launches carry HIP-event pairs)"}
+    if fp32 is not None:
+        line["fp32"] = fp32
+    if micro is not None:
+        line["micro"] = micro
     if raft is not None:
         line["raft"] = raft
     if train is not None:
@@ -557,6 +715,7 @@ def main():
     if panoptic is not None:
         line["panoptic"] = panoptic
     if world == 1 and not a.no_cpu_baseline:
+        line["plumbing"] = plumbing_config0()
         line["cpu_baseline"] = cpu_baseline(a.cpu_frames)
         if raft is not None:
             raft["cpu_baseline"] = cpu_baseline_raft()

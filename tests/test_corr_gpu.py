@@ -188,6 +188,19 @@ def test_build_propagates_non_finite_features_like_the_reference():
     assert np.isnan(got[0, :, 1 * 12 + 1]).all()           # the column of the NaN feature
     ref1 = O.corr_pyramid(f1[1:], f2[1:], 2)[0]
     np.testing.assert_allclose(got[1].reshape(n, 1, 8, 12), ref1, rtol=0, atol=3e-5)   # the other item is untouched
+    # ... and so is the REST of the spoiled item: its power-of-two scale comes from the largest FINITE magnitude, so finite
+    # features above fp16's range (1e5 > 65504) sitting next to the non-finite ones neither overflow nor lose accuracy
+    f1[0, 5, 6, 7] = 1.0e5
+    f2[0, 9, 4, 4] = -3.0e5
+    got = alo_hip.corr_build(dev(f1), dev(f2), 1)[0].cpu().numpy().reshape(2, n, n)
+    a64, b64 = f1[0].astype(np.float64).reshape(32, n), f2[0].astype(np.float64).reshape(32, n)
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref0 = a64.T @ b64 / np.sqrt(32.0)
+    clean = np.isfinite(ref0)
+    assert clean.sum() == (n - 1) * (n - 1)                 # everything but one row and one column
+    assert np.isfinite(got[0][clean]).all()
+    assert np.abs(got[0][clean] - ref0[clean]).max() <= 3e-6 * np.abs(ref0[clean]).max()
+    assert not np.isfinite(got[0][~clean]).any()
 
 
 def test_batch_items_are_independent():
@@ -231,3 +244,106 @@ def test_corr_block_lookup_conv1x1_declines_what_the_kernel_does_not_cover():
     conv = torch.nn.Conv2d(4 * 49, 96, 1).to(DEV)   # RAFT-small's convc1: 96 output channels
     with torch.no_grad():
         assert blk.lookup_conv1x1(coords_grid(1, 16, 16, device=DEV), conv.weight, conv.bias) is None
+
+
+# ---- BASELINE configs[2] at its own batch size ------------------------------------------------------------------------------------
+def test_config3_build_and_lookup_at_batch4_720p():
+    """B = 4 pairs of 256 x 90 x 160 features — where level 0 (3.3 GB) crosses 2^31 bytes and the per-item power-of-two scales,
+    the flat-block -> (item, column tile, row tile) mapping and the lookup's slab offsets are all exercised together (reference:
+    alonet/raft/corr.py:12-60).  Items get different magnitudes on purpose."""
+    B, C, H, W = 4, 256, 90, 160
+    n = H * W
+    gen = torch.Generator(device="cpu").manual_seed(31)
+    f1 = torch.randn(B, C, H, W, generator=gen)
+    f2 = torch.randn(B, C, H, W, generator=gen)
+    for b, s in enumerate((1.0, 37.0, 0.02, 5.0)):
+        f1[b] *= s
+        f2[b] /= s if b != 3 else 1.0
+    f1, f2 = f1.to(DEV), f2.to(DEV)
+    blk = CorrBlock(f1, f2)
+    assert [tuple(p.shape) for p in blk.corr_pyramid] == [(B * n, 1, 90, 160), (B * n, 1, 45, 80), (B * n, 1, 22, 40), (B * n, 1, 11, 20)]
+    assert blk.corr_pyramid[0].numel() * 4 > 2 ** 31
+    # (1) row slabs of items 0 and 3 (first, strided middle, last rows) against a float64 product
+    for b in (0, 3):
+        rows = torch.cat([torch.arange(0, 64), torch.arange(64, n - 64, 211), torch.arange(n - 64, n)]).to(DEV)
+        ref = (f1[b].view(C, n)[:, rows].t().double() @ f2[b].view(C, n).double()) / 16.0
+        got = blk.corr_pyramid[0].view(B, n, n)[b][rows].double()
+        assert (got - ref).abs().max().item() <= 3e-6 * ref.abs().max().item(), b
+    # (2) levels 1-3 against pooling of the level below (pool-after-correlate), every 41st volume of every item
+    for lvl in range(3):
+        pooled = torch.nn.functional.avg_pool2d(blk.corr_pyramid[lvl][::41], 2, stride=2)
+        scale = blk.corr_pyramid[lvl][::41].abs().max().item()
+        assert (blk.corr_pyramid[lvl + 1][::41] - pooled).abs().max().item() <= 2e-6 * scale, lvl
+    # (3) item 3 of the batched build is BIT-equal to a solo build of that pair, and so is its lookup
+    solo = CorrBlock(f1[3:4].contiguous(), f2[3:4].contiguous())
+    for lvl in range(4):
+        assert torch.equal(blk.corr_pyramid[lvl][3 * n:], solo.corr_pyramid[lvl]), lvl
+    coords = coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 4.0
+    out = blk(coords)
+    assert out.shape == (B, 324, H, W) and torch.isfinite(out).all()
+    assert torch.equal(out[3], solo(coords[3:4].contiguous())[0])
+    del solo
+    # (4) lookup of a strided query subset of item 3 against the C oracle fed the same volumes
+    import ctypes
+    sel = np.arange(0, n, 48)
+    pyr_sel = [np.ascontiguousarray(p[3 * n:][sel].cpu().numpy()) for p in blk.corr_pyramid]
+    cc = np.ascontiguousarray(coords[3].view(2, -1)[:, sel].cpu().numpy().reshape(1, 2, 1, len(sel)))
+    o = np.empty((1, 324, 1, len(sel)), np.float32)
+    ptrs = (ctypes.c_void_p * 4)(*[p.ctypes.data for p in pyr_sel])
+    hw = np.array([[p.shape[2], p.shape[3]] for p in pyr_sel], np.int32)
+    O.lib().oracle_corr_lookup(ptrs, hw.ctypes.data_as(ctypes.c_void_p), cc.ctypes.data_as(ctypes.c_void_p),
+                               o.ctypes.data_as(ctypes.c_void_p), 1, 1, len(sel), 4, 4)
+    got = out[3].reshape(324, -1)[:, torch.from_numpy(sel).to(DEV)].cpu().numpy()
+    np.testing.assert_allclose(got, o.reshape(324, len(sel)), rtol=0, atol=2e-5 * max(1.0, float(np.abs(o).max())))
+
+
+def test_hip_corr_block_under_autograd_has_the_gradients_of_the_torch_formulation():
+    """The reference's CorrBlock is differentiable torch code (corr.py:12-60).  Here the forward is the HIP kernels whatever the
+    grad mode; under autograd their backward re-evaluates the torch formulation: gradients w.r.t. both feature maps (through the
+    pyramid AND the lookup) and w.r.t. the coordinates must equal those of TorchCorrBlock."""
+    from alonet.raft.corr import TorchCorrBlock
+
+    gen = torch.Generator(device="cpu").manual_seed(17)
+    B, C, H, W = 2, 48, 12, 20
+    f1 = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    f2 = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    coords = (coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 2.0)
+    wts = torch.randn(B, 324, H, W, generator=gen).to(DEV)
+    grads = {}
+    for name, cls in (("hip", CorrBlock), ("torch", TorchCorrBlock)):
+        a, b, c = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True), coords.clone().requires_grad_(True)
+        blk = cls(a, b, radius=4)
+        out = blk(c)
+        assert out.requires_grad
+        loss = (out * wts).sum() + sum(p.square().sum() for p in blk.corr_pyramid) * 1e-3
+        loss.backward()
+        grads[name] = (out.detach(), a.grad, b.grad, c.grad)
+    assert (grads["hip"][0] - grads["torch"][0]).abs().max().item() <= 5e-5      # forward: kernels vs torch ops
+    for got, want in zip(grads["hip"][1:], grads["torch"][1:]):
+        assert got is not None and (got - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
+    # RAFT's own call pattern: coords detached, only the feature maps train
+    a = f1.clone().requires_grad_(True)
+    CorrBlock(a, f2)(coords).sum().backward()
+    assert a.grad is not None and torch.isfinite(a.grad).all()
+    # no autograd graph: the plain kernels, no Function objects in the way
+    with torch.no_grad():
+        assert not CorrBlock(a, f2)(coords).requires_grad
+
+
+def test_raft_is_trainable_with_the_default_corr_block():
+    """`RAFT()` (default corr_block = the HIP CorrBlock) under autograd: the feature encoder receives gradients through the
+    correlation volume — fine-tuning is drop-in, as with the reference's torch CorrBlock."""
+    import aloscene
+    from alonet.raft import RAFT
+
+    torch.manual_seed(0)
+    model = RAFT().to(DEV).train()
+    model.freeze_bn()
+    mk = lambda x: aloscene.Frame(x, normalization="minmax_sym", names=("B", "C", "H", "W")).to(DEV)  # noqa: E731
+    f1 = torch.rand(1, 3, 128, 160) * 2 - 1
+    f2 = torch.roll(f1, shifts=(2, -3), dims=(2, 3))
+    outs = model(mk(f1), mk(f2), iters=2)
+    loss = sum(o["up_flow"].abs().mean() for o in outs)
+    loss.backward()
+    g = model.fnet.conv1.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0

@@ -34,8 +34,25 @@ def test_two_ranks_weak_scaling_and_max_over_ranks():
     assert abs(r2["checksum"] - (s0 + s1)) < 1e-3 and abs(s0 - s1) > 1e-6
 
 
+def _plain_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_plain_invocation_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver runs it — no torch.distributed environment — launches its two ranks by itself
+    and rank 0 prints the one JSON line (the reference picks DDP by itself when it sees >= 2 devices, pl_helpers.py:365-374)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "8",
+                          "--selftest"], capture_output=True, text=True, timeout=180, cwd=ROOT, env=dict(_plain_env(), OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["ms_per_step"] >= 19.0
+    assert abs(line["value"] - 2 * 8 * 4 / (line["ms_per_step"] * 4 / 1e3)) / line["value"] < 1e-6
+
+
 def test_mismatched_world_size_is_refused():
+    """An environment that says WORLD_SIZE = 1 while --gpus 2 is asked for is a launch error, not something to paper over."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest"],
-                         capture_output=True, text=True, timeout=120, cwd=ROOT,
-                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(_plain_env(), WORLD_SIZE="1", RANK="0"))
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

@@ -226,12 +226,44 @@ def test_level_geometry_built_under_inference_mode_is_not_an_inference_tensor():
     assert torch.equal(x.grad, torch.full((3,), 2.0))
 
 
-def test_corr_block_refuses_to_cut_the_autograd_graph():
-    f1 = torch.randn(1, 8, 4, 4, requires_grad=True)
-    with pytest.raises(RuntimeError, match="no backward"):
-        CorrBlock(f1, torch.randn(1, 8, 4, 4))
-    with pytest.raises(RuntimeError, match="no backward"):
-        CorrBlock.corr(f1, f1)
+def test_torch_corr_block_matches_reference_outputs_and_is_differentiable(golden):
+    """The torch formulation shipped for gradients (alonet.raft.corr.TorchCorrBlock: the backward of the HIP CorrBlock
+    re-evaluates it) against G6 = the reference's own CorrBlock outputs, and through autograd."""
+    from alonet.raft.corr import TorchCorrBlock
+
+    g = golden("g6_corr.npz")
+    f1, f2 = torch.from_numpy(g["f1"]), torch.from_numpy(g["f2"])
+    blk = TorchCorrBlock(f1, f2, radius=4)
+    for lvl in range(4):
+        assert (blk.corr_pyramid[lvl] - torch.from_numpy(g[f"lvl{lvl}"])).abs().max().item() <= 1e-5
+    for k in "abc":
+        assert (blk(torch.from_numpy(g["coords_" + k])) - torch.from_numpy(g["out_" + k])).abs().max().item() <= 2e-5
+    blk3 = TorchCorrBlock(torch.from_numpy(g["f1o"]), torch.from_numpy(g["f2o"]), radius=3)
+    assert (blk3(torch.from_numpy(g["coords_o"])) - torch.from_numpy(g["out_o"])).abs().max().item() <= 2e-5
+    a = f1.clone().requires_grad_(True)
+    TorchCorrBlock(a, f2)(torch.from_numpy(g["coords_a"])).square().sum().backward()
+    assert a.grad is not None and torch.isfinite(a.grad).all() and a.grad.abs().max() > 0
+    assert TorchCorrBlock.corr(f1, f2).shape == (1, 16, 20, 1, 16, 20)
+
+
+def test_hip_corr_block_on_cpu_tensors_raises_instead_of_falling_back():
+    with pytest.raises(RuntimeError, match="CUDA"):
+        CorrBlock(torch.randn(1, 8, 4, 4), torch.randn(1, 8, 4, 4))
+    with pytest.raises(RuntimeError, match="CUDA"):   # ... and under autograd as well: the forward is always the HIP kernel
+        CorrBlock(torch.randn(1, 8, 4, 4, requires_grad=True), torch.randn(1, 8, 4, 4))
+
+
+def test_padder_keeps_the_frames_labels():
+    """"Pad frame but not its labels" (reference utils.py:46-51): children and properties ride along unchanged."""
+    import aloscene
+    from alonet.raft.utils.utils import Padder
+
+    lab = aloscene.Labels(torch.tensor([1.0, 2.0]), encoding="id", labels_names=["a", "b", "c"])
+    bx = aloscene.BoundingBoxes2D(torch.tensor([[0.5, 0.5, 0.2, 0.2], [0.3, 0.3, 0.1, 0.1]]), "xcyc", False, labels=lab)
+    frame = aloscene.Frame(torch.rand(3, 30, 45), normalization="minmax_sym", boxes2d=bx)
+    padded = Padder().pad(frame)
+    assert tuple(padded.shape[-2:]) == (32, 48) and padded.normalization == "minmax_sym" and padded.names == frame.names
+    assert padded.boxes2d is bx
 
 
 def test_fused_inference_path_is_off_when_any_layer_parameter_trains():

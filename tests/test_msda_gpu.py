@@ -517,3 +517,62 @@ def test_backward_is_linear_in_grad_out_at_batch4():
     ab = alo_hip.msda_backward(v, sh, st, loc, attn, 2 * g1 + g2, 64)
     for x, y, z in zip(a, b, ab):
         assert (z - (2 * x + y)).abs().max().item() <= 1e-3 * max(1.0, z.abs().max().item())
+
+
+def test_tiled_backward_with_two_pyramids_of_the_same_total_size():
+    """Two pyramids with the same S but different level shapes, their `spatial_shapes` tensors built fresh per call the way the
+    reference transformer builds them (freed and re-allocated, possibly at the same address): each backward must tile the
+    queries by ITS pyramid.  (Round-2 advisor finding: a host cache keyed on the storage pointer handed the second call the first
+    call's shapes; the kernel now derives the tiling from the device copy and the host copy rides on the tensor object.)"""
+    rng = np.random.default_rng(5)
+    N, M = 1, 8
+    for shapes_l in ([(20, 30), (10, 15), (5, 8), (3, 4)], [(30, 20), (15, 10), (8, 5), (4, 3)], [(20, 30), (10, 15), (5, 8), (3, 4)]):
+        loc = _encoder_like_loc(N, shapes_l, rng, spread_px=2.0)
+        S = loc.shape[1]
+        assert S == 802
+        value = rng.standard_normal((N, S, M, 32)).astype(np.float32)
+        attn = rng.random((N, S, M, 4, 4)).astype(np.float32)
+        attn /= attn.reshape(N, S, M, 16).sum(-1)[..., None, None]
+        go = rng.standard_normal((N, S, M * 32)).astype(np.float32)
+        shapes = np.asarray(shapes_l, np.int32)
+        c = dict(value=value, shapes=shapes, level_start=level_start(shapes), loc=loc, attn=attn, grad_out=go)
+        gv, gl, ga = (x.cpu().numpy() for x in hip_backward(c, torch.float32))   # fresh device tensors, dropped on return
+        rgv, rgl, rga = O.msda_backward(value.astype(np.float64), shapes, c["level_start"], loc.astype(np.float64),
+                                        attn.astype(np.float64), go.astype(np.float64))
+        assert np.isfinite(gl).all() and np.isfinite(ga).all()
+        assert np.abs(gv - rgv).max() <= 1e-4 * max(1.0, np.abs(rgv).max())
+        assert np.abs(ga - rga).max() <= 1e-4 * max(1.0, np.abs(rga).max())
+        ok = _away_from_pixel_edges(loc, shapes_l)
+        assert np.abs((gl - rgl) * ok).max() <= 1e-4 * max(1.0, np.abs(rgl).max())
+
+
+def test_tiled_backward_survives_a_host_hint_that_disagrees_with_the_device_shapes():
+    """The C ABI's host copy of the shapes only sizes the grid: handing alo_msda_backward_hinted the shapes of ANOTHER pyramid
+    with the same S and the same tile count must not change a bit of which queries are served (transposed levels: 25 x 38 tiles
+    either way)."""
+    import ctypes
+
+    rng = np.random.default_rng(6)
+    shapes_l = [(20, 28), (10, 14), (5, 8), (3, 4)]
+    wrong = [(28, 20), (14, 10), (8, 5), (4, 3)]
+    loc = _encoder_like_loc(1, shapes_l, rng, spread_px=2.0)
+    S = loc.shape[1]
+    value = dev(rng.standard_normal((1, S, 8, 32)).astype(np.float32))
+    attn = rng.random((1, S, 8, 4, 4)).astype(np.float32)
+    attn = dev(attn / attn.reshape(1, S, 8, 16).sum(-1)[..., None, None])
+    go = dev(rng.standard_normal((1, S, 256)).astype(np.float32))
+    shapes = np.asarray(shapes_l, np.int32)
+    sh, st, tl = dev(shapes), dev(level_start(shapes)), dev(loc)
+    outs = []
+    for hint_shapes in (shapes_l, wrong):
+        gv, gl, ga = torch.empty_like(value), torch.full_like(tl, float("nan")), torch.full_like(attn, float("nan"))
+        hint = (ctypes.c_int32 * 8)(*[int(v) for hw in hint_shapes for v in hw])
+        rc = alo_hip.lib().alo_msda_backward_hinted(
+            *(ctypes.c_void_p(t.data_ptr()) for t in (value, sh, st, tl, attn, go, gv, gl, ga)), 1, S, 8, 32, 4, S, 4,
+            alo_hip.ALO_F32, alo_hip.ALO_F32, hint, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append((gv, gl, ga))
+    assert torch.isfinite(outs[1][1]).all() and torch.isfinite(outs[1][2]).all()   # every query was served
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-4 * outs[0][0].abs().max().item()   # atomics: order-dependent bits
