@@ -66,6 +66,8 @@ def _declare(lib):
     lib.alo_msda_forward_fused_hm_rows.restype = ip
     lib.alo_msda_forward_fused_hm_rows.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [vp]
     lib.alo_msda_forward_fused_hm.argtypes = [vp] * 7 + [ip] * 9 + [vp]
+    lib.alo_msda_forward_fused_hm_resident.restype = ip
+    lib.alo_msda_forward_fused_hm_resident.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [c.POINTER(c.c_int32), vp]
     lib.alo_value_head_major.restype = ip
     lib.alo_value_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
     lib.alo_bias_act_nchw.restype = ip
@@ -364,10 +366,16 @@ def _query_rows(t, inner):
     return rs
 
 
-def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points):
-    """``msda_forward_fused`` on a head-major value (N, M, S, D) (see ``value_head_major``): same result, bit for bit.
+def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
+                          resident=True):
+    """``msda_forward_fused`` on a head-major value (N, M, S, D) (see ``value_head_major``).
     ``sampling_offsets`` (N, Lq, M, L, P, 2) and ``attn_logits`` (N, Lq, M, L*P) may be column slices of one wider (N, Lq, C)
-    buffer (a merged projection): only their per-query blocks have to be dense."""
+    buffer (a merged projection): only their per-query blocks have to be dense.
+    ``resident`` (default): when a host copy of ``spatial_shapes`` rides on the tensor (``_alo_shapes``, set by
+    DeformableTransformer) and D = 32, large launches keep the coarse pyramid levels in LDS
+    (``alo_msda_forward_fused_hm_resident``: same products, fp32 accumulation order of the levels unchanged; the library falls
+    back to the plain head-major kernel by itself for small launches).  ``resident=False`` always runs the plain kernel, whose
+    output is bit-identical to ``msda_forward_fused``."""
     if not value_hm.is_cuda:
         raise RuntimeError("Not implemented on the CPU")
     N, M, S, D = value_hm.shape
@@ -388,15 +396,53 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     out = torch.empty((N, Lq, M * D), dtype=value_hm.dtype, device=value_hm.device)
     e = value_hm.element_size()
     nbytes = e * (N * S * M * D + N * Lq * M * D + N * Lq * M * L * P * 3) + 4 * reference_points.numel()
+    # coarse levels resident in LDS: needs a HOST copy of the level starts (it picks the resident levels and sizes the grid; the
+    # kernel re-checks it against the device copy).  Only a copy that is already at hand is used — no device read in a forward.
+    host = getattr(spatial_shapes, "_alo_shapes", None) if resident else None
+    if host is None and resident:
+        hit = getattr(spatial_shapes, "_alo_shapes_read", None)
+        host = hit[1] if hit is not None and hit[0] == spatial_shapes._version else None
+    starts = None
+    if host is not None and D == 32 and len(host) == L:
+        acc, vals = 0, []
+        for h, w in host:
+            vals.append(acc)
+            acc += int(h) * int(w)
+        starts = (ctypes.c_int32 * L)(*vals) if acc == S else None
+
     def launch():
+        if starts is not None:
+            _check(lib().alo_msda_forward_fused_hm_resident(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
+                                                            _ptr(sampling_offsets), _ptr(attn_logits), off_rs, log_rs,
+                                                            _ptr(reference_points), _ptr(out), N, S, M, D, L, Lq, P, ref_dim,
+                                                            _DTYPE_CODE[value_hm.dtype], starts, _stream(value_hm.device)))
+            return
         _check(lib().alo_msda_forward_fused_hm_rows(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
                                                     _ptr(sampling_offsets), _ptr(attn_logits), off_rs, log_rs,
                                                     _ptr(reference_points), _ptr(out), N, S, M, D, L, Lq, P, ref_dim,
                                                     _DTYPE_CODE[value_hm.dtype], _stream(value_hm.device)))
 
-    with torch.cuda.device(value_hm.device), _timed(f"msda_fwd_fused/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
+    tag = "msda_fwd_fused_resident" if starts is not None and resident_launch_eligible(N, M, Lq, S, list(starts)) else "msda_fwd_fused"
+    with torch.cuda.device(value_hm.device), _timed(f"{tag}/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
         launch()
     return out
+
+
+RESIDENT_MAX_ROWS = 1358   # csrc/msda.hip kResMaxRows: 64-byte rows that fit in a CU's LDS next to 12 waves' work areas
+_CU_COUNT = {}
+
+
+def resident_launch_eligible(N, M, Lq, S, starts):
+    """Mirror of the dispatch rule in csrc/msda.hip (forward_impl): which launches alo_msda_forward_fused_hm_resident serves with
+    the LDS-resident kernel rather than by falling back to the plain head-major one.  Used for the launch tag only."""
+    if not any(0 < starts[l] < S and S - starts[l] <= RESIDENT_MAX_ROWS for l in (2, 3)):
+        return False
+    dev = torch.cuda.current_device()
+    if dev not in _CU_COUNT:
+        _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    cus, slabs, runs = _CU_COUNT[dev], N * M, (Lq + 15) // 16
+    wps = 1 if slabs >= cus else (cus + slabs - 1) // slabs
+    return min(wps, runs // 48) >= 1
 
 
 def _host_spatial_shapes(spatial_shapes):

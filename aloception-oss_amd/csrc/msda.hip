@@ -605,6 +605,237 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// forward, bf16, head-major, L = P = 4, D = 32: the COARSE pyramid levels of one (image, head) slab resident in LDS.
+//
+// What bounds msda_fwd_bf16_mfma_kernel: every corner row is a 64-byte request through the texture path, whose
+// address / tag pipeline serves about one L1 line per two clocks per CU: stage 2 alone takes 0.22 ms for the 91 M rows of an
+// encoder call and the descriptor arithmetic hides behind it.  Half of those rows belong to the two coarse levels, which are
+// SMALL: levels 2 and 3 of the 1333 x 800 pyramid are 1050 + 273 pixels = 84.7 KB per (image, head) — they fit in a CU's LDS.
+// So here one 12-wave workgroup per CU is pinned to a slab, copies the slab's coarse rows [res_row0, S) into LDS once (one
+// coalesced pass, 22 MB over the whole launch), and its waves then serve every sample of a resident level with ds_read_b128
+// (no address coalescer, no tag lookup, 4x the L1's byte rate) and only the level-0 / level-1 samples through the buffer path.
+// The waves of a workgroup take runs of 16 consecutive queries from a workgroup-local counter, so at any time a CU works on
+// ~200 consecutive queries of ONE head — a band of the image about one row wide whose level-0/1 footprints overlap in L1.
+//   * sample descriptors no longer travel through LDS whole: the lane that builds a sample keeps its four corner addresses in
+//     registers and the other lanes of the quad read them with DPP quad broadcasts folded into the address add (v_add_u32_dpp);
+//     only the A rows of the MFMA (the three bf16 terms of the corner weights, 24 bytes per sample) go through the wave's LDS
+//     slice, which is the transposition "row i of every sample to lane i" — 6.4 KB per wave instead of 12.5.
+//   * corners outside the map aim at an all-zero LDS row (resident levels) or past the slab (buffer bounds check): no branches,
+//     and no byte outside the sampled footprint is ever read (NaN-safe like the other kernels).
+//   * RL = first resident level (2: levels 2-3, 3: level 3 only).  `res_row0` comes from the HOST's copy of the level starts;
+//     the kernel compares it with the device copy and, should they disagree, serves every level through the buffer path: the
+//     hint steers speed, never results.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kResWaves = 12;                            // 3 waves per SIMD: <= 168 registers
+constexpr int kResThreads = 64 * kResWaves;
+constexpr int kResSampleStride = 16 * 24 + 16;           // bytes between the A rows of consecutive samples (16 pairs x 24 B + pad:
+                                                         // the four writers of a pair land on distinct banks)
+constexpr int kResWaveLds = 16 * kResSampleStride;       // 6400 B per wave
+constexpr int kResLdsTotal = 160 * 1024;
+constexpr int kResFixed = 64 /* zero row */ + 16 /* run counter */;
+constexpr int kResMaxRows = (kResLdsTotal - kResWaves * kResWaveLds - kResFixed) / 64;   // 1358 rows of 64 B
+
+struct ResDims {
+    int res_row0;       // first resident row of a slab (host copy of level_start_index[RL])
+    int res_rows;       // S - res_row0
+    int wps;            // workgroups per (image, head) slab
+    int runs_per_slab;  // ceil(Lq / 16)
+    int runs_per_wg;    // ceil(runs_per_slab / wps)
+};
+
+template <int J>
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {   // value of lane J of every quad (v_mov_dpp quad_perm:[J,J,J,J])
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
+}
+
+template <int RL>
+__global__ void __launch_bounds__(kResThreads)
+msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* __restrict__ shapes,
+                              const int32_t* __restrict__ lstart, const void* __restrict__ loc_,
+                              const void* __restrict__ attn_, const float* __restrict__ ref, bf16_t* __restrict__ out,
+                              const Dims dm, const ResDims rd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Ld = Loader<bf16_t, float, 8>;
+
+    const unsigned lb = xcd_contiguous_block(blockIdx.x, dm.nblocks);
+    const int slab = (int)(lb / (unsigned)rd.wps), part = (int)(lb % (unsigned)rd.wps);
+    const int b = slab / dm.M, m = slab - b * dm.M;
+    const int lid = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = lid >> 2, lane = lid & 3;   // pair slot in the wave, lane in the quad (= level in stage 1)
+
+    const bf16_t* slab_base = value + ((size_t)b * dm.M + m) * dm.S * 32;
+    const unsigned zero_row = (unsigned)rd.res_rows * 64u;                       // LDS byte address of the all-zero row
+    int* counter = reinterpret_cast<int*>(smem + zero_row + 64);
+    unsigned char* aw = smem + zero_row + kResFixed + wave * kResWaveLds;         // this wave's A rows
+
+    // the host's view of the pyramid must be the device's; otherwise nothing is treated as resident (wave-uniform)
+    bool res_ok = rd.res_row0 == lstart[RL];
+#pragma unroll
+    for (int l = RL; l < 4; ++l)
+        res_ok = res_ok && lstart[l] >= rd.res_row0 && (long)lstart[l] + (long)shapes[2 * l] * shapes[2 * l + 1] <= (long)dm.S;
+
+    // ---- the slab's coarse rows -> LDS (one coalesced pass), zero row, run counter ------------------------------------------
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(slab_base + (size_t)rd.res_row0 * 32);
+        u32x4* dst = reinterpret_cast<u32x4*>(smem);
+        const int ngran = rd.res_rows * 4;
+        for (int g = threadIdx.x; g < ngran; g += kResThreads) dst[g] = src[g];
+        if (threadIdx.x < 4) dst[ngran + threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
+        if (threadIdx.x == 0) *counter = 0;
+    }
+    __syncthreads();
+
+    const unsigned row_bytes = 64u;
+    const int Lq = dm.pairs_per_batch / dm.M;
+    const long batch_pair0 = (long)b * dm.pairs_per_batch;
+    const int Hl = shapes[2 * lane], Wl = shapes[2 * lane + 1];
+    const bool lane_res = res_ok && lane >= RL;
+    const int start = lane_res ? lstart[lane] - rd.res_row0 : lstart[lane];
+    const unsigned oor = lane_res ? zero_row : kOutOfRange;
+    const float inv_w = 1.0f / (float)Wl, inv_h = 1.0f / (float)Hl;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(slab_base, (unsigned)dm.S * row_bytes);
+    const unsigned coff = (unsigned)lane * 16u;   // this lane's 8 channels of a 64-byte row
+    const int run_lo = part * rd.runs_per_wg;
+    const int run_hi = min(run_lo + rd.runs_per_wg, rd.runs_per_slab);
+    unsigned char* aw_wr = aw + (4 * lane) * kResSampleStride + pl * 24;
+    const unsigned char* aw_rd = aw + pl * 24 + 8 * min(lane, 2);   // lane 3's row of A is ignored (D[3] is never summed)
+
+    for (;;) {
+        int r = 0;
+        if (lid == 0) r = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int run = run_lo + __builtin_amdgcn_readfirstlane(r);
+        if (run >= run_hi) break;   // wave-uniform
+        const int q = run * 16 + pl;
+        const bool dead = q >= Lq;
+        const int qc = min(q, Lq - 1);
+        const long qrow = (long)b * Lq + qc;
+
+        // ---- stage 1: the 4 points of level `lane` of this quad's (query, head) pair --------------------------------------------
+        unsigned off[4][4];
+        {
+            float x[4], y[4], a[4];
+            const u32x4 lr = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(loc_) + qrow * dm.loc_row_elems + 32 * m + 8 * lane);
+            const u32x2 ar = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(attn_) + qrow * dm.attn_row_elems + 16 * m + 4 * lane);
+            const float* rp = ref + (qrow * dm.L + lane) * dm.ref_dim;
+            float r0, r1, r2 = 0.f, r3 = 0.f;
+            if (dm.ref_dim == 2) {
+                const float2 rv = *reinterpret_cast<const float2*>(rp);
+                r0 = rv.x; r1 = rv.y;
+            } else {
+                const float4 rv = *reinterpret_cast<const float4*>(rp);
+                r0 = rv.x; r1 = rv.y; r2 = rv.z; r3 = rv.w;
+            }
+            const unsigned lw[4] = {lr.x, lr.y, lr.z, lr.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                x[i] = __uint_as_float(lw[i] << 16);
+                y[i] = __uint_as_float(lw[i] & 0xffff0000u);
+            }
+            a[0] = __uint_as_float(ar.x << 16); a[1] = __uint_as_float(ar.x & 0xffff0000u);
+            a[2] = __uint_as_float(ar.y << 16); a[3] = __uint_as_float(ar.y & 0xffff0000u);
+            // softmax over the pair's 16 logits (4 here, 12 in the other lanes of the quad): same arithmetic as msda_fwd_bf16_mfma_kernel
+            const float mx = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = __expf(a[i] - mx);
+            const float inv = __builtin_amdgcn_rcpf(quad_sum((a[0] + a[1]) + (a[2] + a[3])));
+            const float half_pw = 0.5f / (float)dm.P;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] *= inv;
+                if (dm.ref_dim == 2) {
+                    x[i] = r0 + x[i] * inv_w;
+                    y[i] = r1 + y[i] * inv_h;
+                } else {
+                    x[i] = r0 + x[i] / (float)dm.P * r2 * 0.5f;
+                    y[i] = r1 + y[i] / (float)dm.P * r3 * 0.5f;
+                }
+            }
+            (void)half_pw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // a pair past the end samples far outside the map: every corner becomes "not read, weight 0" by itself
+                const FwdDesc<float> fd = make_desc<float, true>(dead ? -8.0f : x[i], dead ? -8.0f : y[i], a[i], Hl, Wl, start, row_bytes);
+                unsigned wb[4], r1b[4], r2b[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    off[i][k] = fd.off[k] == kOutOfRange ? oor : fd.off[k];
+                    const float w = fd.w[k];
+                    wb[k] = __float_as_uint(w);
+                    const float t1 = w - __uint_as_float(wb[k] & 0xffff0000u);    // exact: the low 16 mantissa bits
+                    r1b[k] = __float_as_uint(t1);
+                    const float t2 = t1 - __uint_as_float(r1b[k] & 0xffff0000u);  // exact: <= 8 significant bits left
+                    r2b[k] = __float_as_uint(t2);
+                }
+                // bf16(x) by truncation = the upper half of x; v_perm packs two upper halves into one register
+                u32x2* dst = reinterpret_cast<u32x2*>(aw_wr + i * kResSampleStride);
+                dst[0] = u32x2{__builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u), __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u)};
+                dst[1] = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
+                dst[2] = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
+            }
+        }
+        // A rows are exchanged inside the wave only: LDS operations of one wave execute in order, the fence keeps the compiler
+        // from moving the reads below above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- stage 2: gather + MFMA accumulate; group J = the 4 samples of level J, built by lane J of the quad -----------------
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto consume = [&](const u32x4 (&raw)[4][4], const s16x4 (&arow)[4]) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned t0 = raw[p][0][c], t1 = raw[p][1][c], t2 = raw[p][2][c], t3 = raw[p][3][c];
+                    const s16x4 b_even = as_s16x4(__builtin_amdgcn_perm(t1, t0, 0x05040100u), __builtin_amdgcn_perm(t3, t2, 0x05040100u));
+                    const s16x4 b_odd = as_s16x4(__builtin_amdgcn_perm(t1, t0, 0x07060302u), __builtin_amdgcn_perm(t3, t2, 0x07060302u));
+                    acc[2 * c] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[p], b_even, acc[2 * c], 0, 0, 0);
+                    acc[2 * c + 1] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[p], b_odd, acc[2 * c + 1], 0, 0, 0);
+                }
+            }
+        };
+#define ALO_RES_GROUP(J)                                                                                                       \
+        {                                                                                                                      \
+            u32x4 raw[4][4];                                                                                                   \
+            s16x4 arow[4];                                                                                                     \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                   \
+                const u32x2 ar = *reinterpret_cast<const u32x2*>(aw_rd + (4 * J + p) * kResSampleStride);                     \
+                arow[p] = as_s16x4(ar.x, ar.y);                                                                                \
+            }                                                                                                                  \
+            if (J >= RL && res_ok) {                                                                                           \
+                _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                 \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                 \
+                    raw[p][k] = *reinterpret_cast<const u32x4*>(smem + (quad_bcast<J>(off[p][k]) + coff));                     \
+            } else {                                                                                                           \
+                _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                 \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                 \
+                    raw[p][k] = Ld::load(rsrc, quad_bcast<J>(off[p][k]) + coff);                                               \
+            }                                                                                                                  \
+            consume(raw, arow);                                                                                                \
+        }
+        ALO_RES_GROUP(0)
+        __builtin_amdgcn_sched_barrier(0);
+        ALO_RES_GROUP(1)
+        __builtin_amdgcn_sched_barrier(0);
+        ALO_RES_GROUP(2)
+        __builtin_amdgcn_sched_barrier(0);
+        ALO_RES_GROUP(3)
+#undef ALO_RES_GROUP
+        if (!dead) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (acc[i][0] + acc[i][1]) + acc[i][2];
+            store_vec<bf16_t, float, 8>(out + (batch_pair0 + (long)qc * dm.M + m) * 32 + lane * 8, o);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT>
@@ -1286,7 +1517,7 @@ namespace {
 int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
                  const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
                  int P, int value_dtype, int loc_dtype, void* stream_, bool head_major = false, long loc_row_elems = 0,
-                 long attn_row_elems = 0) {
+                 long attn_row_elems = 0, const int32_t* host_level_start = nullptr) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
                           loc_dtype, &elem))
@@ -1314,6 +1545,40 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
         dm.runs_per_batch = (int)runs;
         dm.blocks_per_batch = (int)((runs + dm.iters_per_block - 1) / dm.iters_per_block);
         dm.nblocks = (unsigned)(dm.blocks_per_batch * N);
+        if (host_level_start && D == 32) {
+            // coarse levels resident in LDS (msda_fwd_bf16_resident_kernel): one 12-wave workgroup per CU pinned to an (image, head) slab
+            int rl = 0;
+            for (int l = 2; l < 4 && !rl; ++l) {
+                const long r0 = host_level_start[l];
+                if (r0 > 0 && r0 < S && S - r0 <= kResMaxRows) rl = l;
+            }
+            int cus = 256, dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (cus < 1) cus = 256;
+            const long slabs = (long)N * M;
+            ResDims rd;
+            rd.runs_per_slab = (Lq + 15) / 16;
+            long wps = slabs >= cus ? 1 : (cus + slabs - 1) / slabs;
+            const long wps_cap = rd.runs_per_slab / (4 * kResWaves);   // >= 4 runs per wave, or the resident copy does not pay
+            if (wps > wps_cap) wps = wps_cap;
+            if (rl && wps >= 1 && slabs * wps < 0x7fffffffL) {
+                rd.res_row0 = host_level_start[rl];
+                rd.res_rows = S - rd.res_row0;
+                rd.wps = (int)wps;
+                rd.runs_per_wg = (int)((rd.runs_per_slab + wps - 1) / wps);
+                dm.nblocks = (unsigned)(slabs * wps);
+                void* rargs[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm, &rd};
+                const size_t lds = (size_t)rd.res_rows * 64 + kResFixed + (size_t)kResWaves * kResWaveLds;
+                static unsigned long long attr_done[2] = {0, 0};   // one bit per device
+                const void* fn = rl == 2 ? reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<2>)
+                                         : reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<3>);
+                hipError_t ea = ensure_dynamic_lds(fn, kResLdsTotal, &attr_done[rl - 2]);
+                if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(ea));
+                hipError_t el = hipLaunchKernel(fn, dim3(dm.nblocks), dim3(kResThreads), rargs, lds, stream);
+                if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(el));
+                return check_launch("alo_msda_forward_fused_hm_resident");
+            }
+        }
         return launch(msda_fwd_bf16_mfma_kernel<4, true, true>, dm, kWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
     }
     if (wave_kernel) {
@@ -1379,6 +1644,25 @@ extern "C" int alo_msda_forward_fused_hm_rows(const void* value_hm, const int32_
     return forward_impl(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
                         ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true, offsets_row_elems,
                         logits_row_elems);
+}
+
+extern "C" int alo_msda_forward_fused_hm_resident(const void* value_hm, const int32_t* spatial_shapes,
+                                                  const int32_t* level_start_index, const void* sampling_offsets,
+                                                  const void* attn_logits, long offsets_row_elems, long logits_row_elems,
+                                                  const void* reference_points, void* out, int N, int S, int M, int D, int L,
+                                                  int Lq, int P, int ref_dim, int value_dtype, const int32_t* host_level_start,
+                                                  void* stream_) {
+    ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_resident: reference_points is null");
+    ALO_REQUIRE(host_level_start, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_resident: host_level_start is null");
+    ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_forward_fused_hm_resident: last dim of reference_points must be 2 or 4, got %d", ref_dim);
+    ALO_REQUIRE(offsets_row_elems >= (long)M * L * P * 2 && logits_row_elems >= (long)M * L * P && offsets_row_elems % 8 == 0 &&
+                    logits_row_elems % 8 == 0 && offsets_row_elems < (1L << 30) && logits_row_elems < (1L << 30),
+                ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_forward_fused_hm_resident: row strides must cover a query's M*L*P*2 offsets / M*L*P logits and keep 16-byte alignment");
+    return forward_impl(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
+                        ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true, offsets_row_elems,
+                        logits_row_elems, host_level_start);
 }
 
 namespace {

@@ -304,7 +304,7 @@ def test_hip_corr_block_under_autograd_has_the_gradients_of_the_torch_formulatio
     from alonet.raft.corr import TorchCorrBlock
 
     gen = torch.Generator(device="cpu").manual_seed(17)
-    B, C, H, W = 2, 48, 12, 20
+    B, C, H, W = 2, 48, 16, 24
     f1 = torch.randn(B, C, H, W, generator=gen).to(DEV)
     f2 = torch.randn(B, C, H, W, generator=gen).to(DEV)
     coords = (coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 2.0)

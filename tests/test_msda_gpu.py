@@ -378,6 +378,7 @@ def _bench_path_case(N, Lq_is_S, shapes_l, seed, encoder_like):
     M, D, L, P = 8, 32, 4, 4
     gen = torch.Generator(device=DEV).manual_seed(seed)
     shapes = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
+    shapes._alo_shapes = [tuple(hw) for hw in shapes_l]   # the host copy DeformableTransformer attaches: enables the LDS-resident kernel
     start = dev(level_start(shapes_l))
     S = int((shapes[:, 0] * shapes[:, 1]).sum())
     Lq = S if Lq_is_S else 300
@@ -420,10 +421,14 @@ def test_bench_kernel_direct_vs_oracle_small(encoder_like):
 
 def test_bench_kernel_direct_vs_oracle_full_size_batch8():
     """BASELINE configs[1] shape of the encoder call (N = 8, S = Lq = 22223): every 41st query of the launch bench.py times
-    against the float64 oracle."""
+    (msda_fwd_bf16_resident_kernel: levels 2-3 of every (image, head) slab resident in LDS) against the float64 oracle, and the
+    whole output against the plain head-major kernel."""
     value, mask, offsets, logits, ref, shapes, start = _bench_path_case(8, True, DETR_SHAPES, 32, True)
     vhm = alo_hip.value_head_major(value, mask)
-    got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    with alo_hip.LaunchTimer() as timer:
+        got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    assert "msda_fwd_fused_resident/Lq=22223" in timer.summary(), timer.summary().keys()
+    assert torch.equal(got, alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=False))
     qsel = slice(0, None, 41)
     exact = _oracle_on_queries(value, mask, offsets, logits, ref, shapes, start, qsel)
     err = np.abs(got[:, qsel].double().cpu().numpy() - exact)
@@ -576,3 +581,94 @@ def test_tiled_backward_survives_a_host_hint_that_disagrees_with_the_device_shap
     assert torch.isfinite(outs[1][1]).all() and torch.isfinite(outs[1][2]).all()   # every query was served
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-4 * outs[0][0].abs().max().item()   # atomics: order-dependent bits
+
+
+# ---- coarse levels resident in LDS (alo_msda_forward_fused_hm_resident) ---------------------------------------------------------------
+RESIDENT_CASES = [  # (N, shapes, Lq or None = S, ref_dim)                        which route
+    (2, [(40, 50), (20, 25), (10, 13), (5, 7)], None, 2),      # levels 2-3 resident (165 rows), 3 workgroups per slab, ragged tail run
+    (1, [(40, 50), (20, 25), (10, 13), (5, 7)], 1000, 4),      # free queries with box reference points
+    (3, [(64, 80), (37, 37), (37, 37), (10, 10)], 2500, 2),    # levels 2-3 = 1469 rows: too many -> level 3 alone resident
+    (1, [(30, 40), (15, 20), (8, 10), (4, 5)], None, 2),       # N * M = 8 slabs: many workgroups per slab
+]
+
+
+def _resident_case(N, shapes_l, Lq, ref_dim, seed):
+    M, D, L, P = 8, 32, 4, 4
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    shapes = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
+    shapes._alo_shapes = [tuple(hw) for hw in shapes_l]
+    start = dev(level_start(shapes_l))
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    Lq = S if Lq is None else Lq
+    value = torch.randn(N, S, M, D, generator=gen, device=DEV).bfloat16()
+    mask = torch.rand(N, S, generator=gen, device=DEV) < 0.1
+    offsets = (torch.randn(N, Lq, M, L, P, 2, generator=gen, device=DEV) * 4.0).bfloat16()
+    logits = (torch.randn(N, Lq, M, L * P, generator=gen, device=DEV) * 2.0).bfloat16()
+    ref = torch.rand(N, Lq, L, ref_dim, generator=gen, device=DEV) * 1.2 - 0.1     # some reference points outside the map
+    if ref_dim == 4:
+        ref[..., 2:] = ref[..., 2:].abs() * 0.4
+    return value, mask, offsets, logits, ref, shapes, start
+
+
+@pytest.mark.parametrize("case", RESIDENT_CASES, ids=lambda c: f"N{c[0]}-{c[1][2][0]}x{c[1][2][1]}-Lq{c[2]}-ref{c[3]}")
+def test_resident_forward_is_bit_identical_to_the_plain_head_major_kernel(case):
+    """Same descriptors, same products, same accumulation order: serving the coarse levels from LDS must not change a bit —
+    borders, samples outside the map (zero row in LDS / buffer range check), padded pixels and the ragged last run included.
+    And against the float64 oracle directly."""
+    N, shapes_l, Lq, ref_dim = case
+    value, mask, offsets, logits, ref, shapes, start = _resident_case(N, shapes_l, Lq, ref_dim, 41 + N)
+    vhm = alo_hip.value_head_major(value, mask)
+    with alo_hip.LaunchTimer() as timer:
+        got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    assert any(k.startswith("msda_fwd_fused_resident") for k in timer.summary()), timer.summary().keys()
+    want = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=False)
+    assert torch.equal(got, want)
+    sel = slice(0, None, 7)
+    loc, attn = _prologue_in_torch(offsets[:, sel].float(), logits[:, sel].float(), ref[:, sel], shapes, 4)
+    exact = O.msda_forward(value.masked_fill(mask[..., None, None], 0).double().cpu().numpy(), shapes.cpu().numpy(),
+                           start.cpu().numpy(), loc.double().cpu().numpy(), attn.double().cpu().numpy())
+    err = np.abs(got[:, sel].double().cpu().numpy() - exact)
+    assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)
+
+
+def test_resident_forward_with_nan_outside_the_sampled_footprint():
+    """NaN in pixels no sample touches — inside the LDS-resident levels too — must not reach any output: corners outside the map
+    read the all-zero LDS row, never a neighbouring pixel."""
+    N, shapes_l = 1, [(40, 50), (20, 25), (10, 13), (5, 7)]
+    value, mask, offsets, logits, ref, shapes, start = _resident_case(N, shapes_l, None, 2, 77)
+    offsets.zero_()                      # every query samples exactly its reference point on every level
+    ref[:] = 0.25                        # ... which lies in the interior of every level
+    vhm = alo_hip.value_head_major(value, None)
+    clean = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    poisoned = vhm.clone()
+    st = level_start(shapes_l)
+    for lvl, (h, w) in enumerate(shapes_l):
+        keep = torch.zeros(h, w, dtype=torch.bool, device=DEV)
+        y, x = int(np.floor(0.25 * h - 0.5)), int(np.floor(0.25 * w - 0.5))
+        keep[y:y + 2, x:x + 2] = True
+        rows = torch.nonzero(~keep.view(-1)).view(-1) + int(st[lvl])
+        poisoned[:, :, rows] = float("nan")
+    got = alo_hip.msda_forward_fused_hm(poisoned, shapes, start, offsets, logits, ref)
+    assert torch.isfinite(got.float()).all() and torch.equal(got, clean)
+
+
+def test_resident_forward_ignores_a_host_copy_that_disagrees_with_the_device_metadata():
+    """The host copy of the level starts picks the resident levels and sizes the grid; a WRONG one (another pyramid with the same
+    S) must only cost speed: the kernel compares it with the device copy and serves every level through the buffer path."""
+    import ctypes
+
+    N, shapes_l = 2, [(40, 50), (20, 25), (10, 13), (5, 7)]
+    value, mask, offsets, logits, ref, shapes, start = _resident_case(N, shapes_l, None, 2, 55)
+    vhm = alo_hip.value_head_major(value, mask)
+    want = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=False)
+    S, Lq = vhm.shape[2], offsets.shape[1]
+    for wrong in ([0, 2000, 2400, 2600], [0, 2000, 2500, 2630], [0, 100, 200, 2664]):   # true starts: 0, 2000, 2500, 2630
+        out = torch.full_like(want, float("nan"))
+        hint = (ctypes.c_int32 * 4)(*wrong)
+        rc = alo_hip.lib().alo_msda_forward_fused_hm_resident(
+            *(ctypes.c_void_p(t.data_ptr()) for t in (vhm, shapes, start, offsets, logits)), 8 * 16 * 2, 8 * 16,
+            ctypes.c_void_p(ref.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, S, 8, 32, 4, Lq, 4, 2, alo_hip.ALO_BF16, hint,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, alo_hip.lib().alo_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), wrong

@@ -36,6 +36,7 @@ def time_launches(fn, reps, warmup=5):
 
 def detr_geometry(device=DEV):
     shapes = torch.tensor(DETR_SHAPES, dtype=torch.int32, device=device)
+    shapes._alo_shapes = list(DETR_SHAPES)   # the host copy DeformableTransformer attaches (enables the LDS-resident forward)
     start = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]]).to(torch.int32)
     return shapes, start, int((shapes[:, 0] * shapes[:, 1]).sum())
 
@@ -129,18 +130,18 @@ def bench_msda_fused(N, dtype, reps):
                 alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
-def bench_msda_fused_hm(N, reps):
+def bench_msda_fused_hm(N, reps, resident=True):
     """Head-major path: the re-layout (+ padding mask) pass and the gather, separately."""
     value, shapes, start, offsets, logits, ref = fused_inputs(N, torch.bfloat16)
     S = value.shape[1]
     mask = torch.zeros(N, S, dtype=torch.bool, device=DEV)
     t0 = time_launches(lambda: alo_hip.value_head_major(value, mask), reps)
     vhm = alo_hip.value_head_major(value, mask)
-    t = time_launches(lambda: alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref), reps)
+    t = time_launches(lambda: alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=resident), reps)
     nbytes = 2 * (N * S * 256 * 2 + N * S * 8 * 16 * 3) + ref.numel() * 4
     return [dict(kernel="value_head_major[+mask]", N=N, dtype="bfloat16", ms=t0 * 1e3, alg_bytes=4 * value.numel(),
                  GBps=4 * value.numel() / t0 / 1e9),
-            dict(kernel="msda_fwd_fused_hm[encoder]", N=N, Lq=S, dtype="bfloat16", ms=t * 1e3, alg_bytes=nbytes,
+            dict(kernel="msda_fwd_fused_hm[encoder]" + ("" if resident else "[plain]"), N=N, Lq=S, dtype="bfloat16", ms=t * 1e3, alg_bytes=nbytes,
                  GBps=nbytes / t / 1e9)]
 
 
@@ -243,6 +244,8 @@ def main():
             res = [bench_msda_fused(a.N, dt, a.reps) for dt in dts]
         elif w == "msda_fused_hm":
             res = bench_msda_fused_hm(a.N, a.reps)
+        elif w == "msda_fused_hm_plain":   # the plain head-major kernel (no LDS-resident levels), for A/B
+            res = bench_msda_fused_hm(a.N, a.reps, resident=False)
         elif w == "msda_rand":
             res = [bench_msda_fwd(a.N, S, "uniform", dt, a.reps) for dt in dts]
         elif w == "msda_dec":
