@@ -62,11 +62,19 @@ struct Tap {
 };
 // MUL24: index arithmetic on the full-rate 24-bit integer multiplier (v_mul_lo_u32 is quarter rate); the caller
 // guarantees S < 2^23 and row_bytes < 2^23.
+// The float arithmetic of the sampling geometry is written with explicit fused multiply-adds and `fp contract(off)`: which
+// products the compiler fuses otherwise depends on how the SLP vectoriser happened to pack the surrounding code, i.e. two
+// kernels inlining the same source could disagree in the last bit of a sampling location — and kernels that promise
+// bit-identical outputs (head-major, LDS-resident) would differ by a bf16 ulp on a few outputs per ten thousand.
+__device__ __forceinline__ float fma_ct(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_ct(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename CT, bool MUL24 = false>
 __device__ __forceinline__ Tap<CT> make_tap(CT loc_x, CT loc_y, int H, int W, int start) {
+#pragma clang fp contract(off)
     Tap<CT> t;
-    const CT h_im = loc_y * (CT)H - (CT)0.5;
-    const CT w_im = loc_x * (CT)W - (CT)0.5;
+    const CT h_im = fma_ct(loc_y, (CT)H, (CT)-0.5);
+    const CT w_im = fma_ct(loc_x, (CT)W, (CT)-0.5);
     t.valid = (h_im > (CT)-1) && (w_im > (CT)-1) && (h_im < (CT)H) && (w_im < (CT)W);
     const CT hs = t.valid ? h_im : (CT)0, ws = t.valid ? w_im : (CT)0;  // keep the int conversion defined
     const CT hf = floor(hs), wf = floor(ws);
@@ -98,6 +106,7 @@ __device__ __forceinline__ void load_meta(int* meta, const int32_t* shapes, cons
 // weights already multiplied by the attention weight.
 template <typename CT, bool MUL24 = false>
 __device__ __forceinline__ FwdDesc<CT> make_desc(CT x, CT y, CT a, int H, int W, int start, unsigned row_bytes) {
+#pragma clang fp contract(off)
     FwdDesc<CT> d;
     const Tap<CT> t = make_tap<CT, MUL24>(x, y, H, W, start);
     const CT hh = (CT)1 - t.lh, hw = (CT)1 - t.lw;
@@ -411,6 +420,57 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// MSDeformAttn's arithmetic between its linear layers and the op (ms_deform_attn.py:119-133) for the 4 points of ONE level of a
+// (query, head) pair, bf16 storage: lane q of a quad holds level q.  `lr` = the 4 raw (x, y) offsets, `ar` = the 4 raw logits,
+// r0..r3 = the reference point (r2, r3 used when ref_dim == 4).  Softmax over the pair's 16 logits (4 here, 12 in the other
+// lanes of the quad); bf16 inputs carry 2^-9 relative error themselves, so the hardware exp / reciprocal (<= 2 ulp) are used.
+// Shared by every wave kernel so that they agree bit for bit.
+__device__ __forceinline__ void wave_prologue(const u32x4 lr, const u32x2 ar, float r0, float r1, float r2, float r3, int ref_dim,
+                                              float inv_w, float inv_h, int P, float (&x)[4], float (&y)[4], float (&a)[4]) {
+#pragma clang fp contract(off)
+    const unsigned lw[4] = {lr.x, lr.y, lr.z, lr.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = __uint_as_float(lw[i] << 16);
+        y[i] = __uint_as_float(lw[i] & 0xffff0000u);
+    }
+    a[0] = __uint_as_float(ar.x << 16); a[1] = __uint_as_float(ar.x & 0xffff0000u);
+    a[2] = __uint_as_float(ar.y << 16); a[3] = __uint_as_float(ar.y & 0xffff0000u);
+    const float mx = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = __expf(a[i] - mx);
+    const float inv = __builtin_amdgcn_rcpf(quad_sum((a[0] + a[1]) + (a[2] + a[3])));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] *= inv;
+        if (ref_dim == 2) {
+            x[i] = __builtin_fmaf(x[i], inv_w, r0);
+            y[i] = __builtin_fmaf(y[i], inv_h, r1);
+        } else {
+            x[i] = r0 + x[i] / (float)P * r2 * 0.5f;
+            y[i] = r1 + y[i] / (float)P * r3 * 0.5f;
+        }
+    }
+}
+
+// The four fp32 corner weights of a sample as the three A rows {hi, mid, lo} of the 4x4x4 MFMA: w = hi + mid + lo EXACTLY
+// (8 + 8 + 8 significant bits by truncation; bf16(x) by truncation = the upper half of x, v_perm packs two upper halves).
+__device__ __forceinline__ void split_weights(const float (&w)[4], u32x2 (&rows)[3]) {
+#pragma clang fp contract(off)
+    unsigned wb[4], r1b[4], r2b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        wb[k] = __float_as_uint(w[k]);
+        const float t1 = w[k] - __uint_as_float(wb[k] & 0xffff0000u);    // exact: the low 16 mantissa bits
+        r1b[k] = __float_as_uint(t1);
+        const float t2 = t1 - __uint_as_float(r1b[k] & 0xffff0000u);      // exact: <= 8 significant bits left
+        r2b[k] = __float_as_uint(t2);
+    }
+    rows[0] = u32x2{__builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u), __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u)};
+    rows[1] = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
+    rows[2] = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
+}
+
 // One WAVE is the unit of work (64-thread workgroups, no block barrier anywhere): its 16 quads serve 16 consecutive
 // (query, head) pairs.  In stage 1 lane q of a quad turns the pair's 4 sampling points of level q into descriptors — its
 // inputs are one 16-byte (offsets), one 8-byte (logits) and one 8/16-byte (reference point) load instead of 16 narrow
@@ -487,31 +547,7 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
                     const float4 rv = *reinterpret_cast<const float4*>(rp);
                     r0 = rv.x; r1 = rv.y; r2 = rv.z; r3 = rv.w;
                 }
-                const unsigned lw[4] = {lr.x, lr.y, lr.z, lr.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    x[i] = __uint_as_float(lw[i] << 16);
-                    y[i] = __uint_as_float(lw[i] & 0xffff0000u);
-                }
-                a[0] = __uint_as_float(ar.x << 16); a[1] = __uint_as_float(ar.x & 0xffff0000u);
-                a[2] = __uint_as_float(ar.y << 16); a[3] = __uint_as_float(ar.y & 0xffff0000u);
-                // softmax over the pair's 16 logits (4 here, 12 in the other lanes of the quad); bf16 inputs carry 2^-9
-                // relative error themselves, so the hardware exp / reciprocal (<= 2 ulp) are used, as in the generic kernel
-                const float mx = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = __expf(a[i] - mx);
-                const float inv = __builtin_amdgcn_rcpf(quad_sum((a[0] + a[1]) + (a[2] + a[3])));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] *= inv;
-                    if (dm.ref_dim == 2) {
-                        x[i] = r0 + x[i] * inv_w;
-                        y[i] = r1 + y[i] * inv_h;
-                    } else {
-                        x[i] = r0 + x[i] / (float)dm.P * r2 * 0.5f;
-                        y[i] = r1 + y[i] / (float)dm.P * r3 * 0.5f;
-                    }
-                }
+                wave_prologue(lr, ar, r0, r1, r2, r3, dm.ref_dim, inv_w, inv_h, dm.P, x, y, a);
             } else {
                 const float* lp = static_cast<const float*>(loc_) + 2 * g0;
                 const f32x4 l0 = *reinterpret_cast<const f32x4*>(lp), l1 = *reinterpret_cast<const f32x4*>(lp + 4);
@@ -527,24 +563,12 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
                 const FwdDesc<float> fd = make_desc<float, true>(dead ? -8.0f : x[i], dead ? -8.0f : y[i], a[i], Hl, Wl,
                                                                  start, row_bytes);
                 MfmaDesc d;
-                unsigned wb[4], r1b[4], r2b[4];
+                u32x2 rows[3];
+                split_weights(fd.w, rows);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    d.off[k] = fd.off[k];
-                    const float w = fd.w[k];
-                    wb[k] = __float_as_uint(w);
-                    const float r1 = w - __uint_as_float(wb[k] & 0xffff0000u);    // exact: the low 16 mantissa bits
-                    r1b[k] = __float_as_uint(r1);
-                    const float r2 = r1 - __uint_as_float(r1b[k] & 0xffff0000u);  // exact: <= 8 significant bits left
-                    r2b[k] = __float_as_uint(r2);
-                }
-                // bf16(x) by truncation = the upper half of x; v_perm packs two upper halves into one register
-                d.arow[0][0] = __builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u);
-                d.arow[0][1] = __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u);
-                d.arow[1][0] = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u);
-                d.arow[1][1] = __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u);
-                d.arow[2][0] = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u);
-                d.arow[2][1] = __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u);
+                for (int k = 0; k < 4; ++k) d.off[k] = fd.off[k];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { d.arow[t][0] = rows[t].x; d.arow[t][1] = rows[t].y; }
                 d.arow[3][0] = 0u;
                 d.arow[3][1] = 0u;
                 *reinterpret_cast<MfmaDesc*>(dp + (4 * lane + i) * (int)sizeof(MfmaDesc)) = d;
@@ -725,52 +749,19 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
                 const float4 rv = *reinterpret_cast<const float4*>(rp);
                 r0 = rv.x; r1 = rv.y; r2 = rv.z; r3 = rv.w;
             }
-            const unsigned lw[4] = {lr.x, lr.y, lr.z, lr.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                x[i] = __uint_as_float(lw[i] << 16);
-                y[i] = __uint_as_float(lw[i] & 0xffff0000u);
-            }
-            a[0] = __uint_as_float(ar.x << 16); a[1] = __uint_as_float(ar.x & 0xffff0000u);
-            a[2] = __uint_as_float(ar.y << 16); a[3] = __uint_as_float(ar.y & 0xffff0000u);
-            // softmax over the pair's 16 logits (4 here, 12 in the other lanes of the quad): same arithmetic as msda_fwd_bf16_mfma_kernel
-            const float mx = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = __expf(a[i] - mx);
-            const float inv = __builtin_amdgcn_rcpf(quad_sum((a[0] + a[1]) + (a[2] + a[3])));
-            const float half_pw = 0.5f / (float)dm.P;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] *= inv;
-                if (dm.ref_dim == 2) {
-                    x[i] = r0 + x[i] * inv_w;
-                    y[i] = r1 + y[i] * inv_h;
-                } else {
-                    x[i] = r0 + x[i] / (float)dm.P * r2 * 0.5f;
-                    y[i] = r1 + y[i] / (float)dm.P * r3 * 0.5f;
-                }
-            }
-            (void)half_pw;
+            wave_prologue(lr, ar, r0, r1, r2, r3, dm.ref_dim, inv_w, inv_h, dm.P, x, y, a);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // a pair past the end samples far outside the map: every corner becomes "not read, weight 0" by itself
                 const FwdDesc<float> fd = make_desc<float, true>(dead ? -8.0f : x[i], dead ? -8.0f : y[i], a[i], Hl, Wl, start, row_bytes);
-                unsigned wb[4], r1b[4], r2b[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    off[i][k] = fd.off[k] == kOutOfRange ? oor : fd.off[k];
-                    const float w = fd.w[k];
-                    wb[k] = __float_as_uint(w);
-                    const float t1 = w - __uint_as_float(wb[k] & 0xffff0000u);    // exact: the low 16 mantissa bits
-                    r1b[k] = __float_as_uint(t1);
-                    const float t2 = t1 - __uint_as_float(r1b[k] & 0xffff0000u);  // exact: <= 8 significant bits left
-                    r2b[k] = __float_as_uint(t2);
-                }
-                // bf16(x) by truncation = the upper half of x; v_perm packs two upper halves into one register
+                for (int k = 0; k < 4; ++k) off[i][k] = fd.off[k] == kOutOfRange ? oor : fd.off[k];
+                u32x2 rows[3];
+                split_weights(fd.w, rows);
                 u32x2* dst = reinterpret_cast<u32x2*>(aw_wr + i * kResSampleStride);
-                dst[0] = u32x2{__builtin_amdgcn_perm(wb[1], wb[0], 0x07060302u), __builtin_amdgcn_perm(wb[3], wb[2], 0x07060302u)};
-                dst[1] = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
-                dst[2] = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
+                dst[0] = rows[0];
+                dst[1] = rows[1];
+                dst[2] = rows[2];
             }
         }
         // A rows are exchanged inside the wave only: LDS operations of one wave execute in order, the fence keeps the compiler
