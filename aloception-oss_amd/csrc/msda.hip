@@ -420,6 +420,40 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// One sampling point -> four corner byte offsets + four corner weights (already times the attention weight), the lean way the
+// wave kernels use (fp32, `W * row_bytes` and `H * W` below 2^23).  Same semantics as make_desc (cuh:285-291, :38-78):
+//   * the sample counts iff  h_im > -1 && w_im > -1 && h_im < H && w_im < W  (and the query exists: `alive`);
+//   * a corner is read iff its row and its column are inside the map; every other corner gets the offset `oor`, which the
+//     caller makes read as ZEROS without touching the map (past the buffer's range, or an all-zero LDS row).
+// Unlike make_desc the weights of corners that are not read are NOT zeroed — they are finite and meet a zero row, which
+// saves eight selects per sample (the descriptor stage is what bounds the LDS-resident kernel: VALU 88 % busy).  Weights are
+// built separably: (1 - lh) * a and lh * a once per row, times (1 - lw) / lw per column.
+__device__ __forceinline__ void lean_sample(float x, float y, float a, bool alive, float Hf, float Wf, unsigned base0,
+                                            unsigned row_bytes, unsigned w_bytes, unsigned oor, unsigned (&off)[4], float (&w)[4]) {
+#pragma clang fp contract(off)
+    const float h_im = __builtin_fmaf(y, Hf, -0.5f), w_im = __builtin_fmaf(x, Wf, -0.5f);
+    const bool valid = alive && (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);
+    const float hs = valid ? h_im : 0.f, ws = valid ? w_im : 0.f;   // keeps the arithmetic below finite and the conversions defined
+    const float hf = floorf(hs), wf = floorf(ws);   // in [-1, H - 1] x [-1, W - 1] for a valid sample, 0 otherwise
+    const float lh = hs - hf, lw = ws - wf;
+    // row / column tests and the pixel index stay in fp32 (exact: |h * W + w| < 2^23): no conversions, no integer multiply
+    // (v_mul_lo_u32 is quarter rate and the compiler reaches for it)
+    const bool r0 = valid && hf >= 0.f, r1 = valid && hf < Hf - 1.f, c0 = wf >= 0.f, c1 = wf < Wf - 1.f;
+    const float wy1 = lh * a, wy0 = (1.f - lh) * a, hw = 1.f - lw;
+    w[0] = wy0 * hw;
+    w[1] = wy0 * lw;
+    w[2] = wy1 * hw;
+    w[3] = wy1 * lw;
+    // hf may be -1 with the lower corners still inside: the index is negative then and the byte offset wraps like the 32-bit one
+    const int pix = (int)__builtin_fmaf(hf, Wf, wf);
+    const unsigned o0 = base0 + (unsigned)pix * row_bytes;
+    const unsigned o2 = o0 + w_bytes;
+    off[0] = (r0 && c0) ? o0 : oor;
+    off[1] = (r0 && c1) ? o0 + row_bytes : oor;
+    off[2] = (r1 && c0) ? o2 : oor;
+    off[3] = (r1 && c1) ? o2 + row_bytes : oor;
+}
+
 // MSDeformAttn's arithmetic between its linear layers and the op (ms_deform_attn.py:119-133) for the 4 points of ONE level of a
 // (query, head) pair, bf16 storage: lane q of a quad holds level q.  `lr` = the 4 raw (x, y) offsets, `ar` = the 4 raw logits,
 // r0..r3 = the reference point (r2, r3 used when ref_dim == 4).  Softmax over the pair's 16 logits (4 here, 12 in the other
@@ -504,7 +538,9 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
     const int Lq = dm.pairs_per_batch / dm.M;
 
     const int Hl = shapes[2 * lane], Wl = shapes[2 * lane + 1], start = lstart[lane];
-    const float inv_w = 1.0f / (float)Wl, inv_h = 1.0f / (float)Hl;
+    const float Hf = (float)Hl, Wf = (float)Wl;
+    const float inv_w = 1.0f / Wf, inv_h = 1.0f / Hf;
+    const unsigned base0 = (unsigned)start * row_bytes, w_bytes = (unsigned)Wl * row_bytes;
     unsigned char* dp = smem + pl * kMfmaPairStride;
     const int c0 = lane * 8;  // lanes with c0 >= D only feed the A rows
 
@@ -559,14 +595,11 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // a pair past the end samples far outside the map: every corner becomes "not read, weight 0" by itself
-                const FwdDesc<float> fd = make_desc<float, true>(dead ? -8.0f : x[i], dead ? -8.0f : y[i], a[i], Hl, Wl,
-                                                                 start, row_bytes);
                 MfmaDesc d;
+                float w4[4];
+                lean_sample(x[i], y[i], a[i], !dead, Hf, Wf, base0, row_bytes, w_bytes, kOutOfRange, d.off, w4);
                 u32x2 rows[3];
-                split_weights(fd.w, rows);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d.off[k] = fd.off[k];
+                split_weights(w4, rows);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) { d.arow[t][0] = rows[t].x; d.arow[t][1] = rows[t].y; }
                 d.arow[3][0] = 0u;
@@ -586,8 +619,11 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
             f32x4 acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // order of the sum: levels 2, 3, 0, 1 — the order msda_fwd_bf16_resident_kernel needs (resident levels while the
+            // buffer loads of the others are in flight); every wave kernel uses it, so they agree bit for bit
 #pragma unroll 1
-            for (int s0 = 0; s0 < 16; s0 += SB) {
+            for (int t0 = 0; t0 < 16; t0 += SB) {
+                const int s0 = (t0 + 8) & 15;
                 u32x4 raw[SB][4];
                 s16x4 arow[SB];
 #pragma unroll
@@ -644,20 +680,34 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 //     registers and the other lanes of the quad read them with DPP quad broadcasts folded into the address add (v_add_u32_dpp);
 //     only the A rows of the MFMA (the three bf16 terms of the corner weights, 24 bytes per sample) go through the wave's LDS
 //     slice, which is the transposition "row i of every sample to lane i" — 6.4 KB per wave instead of 12.5.
+//   * resident rows are consumed with ds_read_b64_tr_b16, the LDS transpose read: in every 16-lane group lane 4 r + p fetches
+//     eight bytes of corner r of pair p, and lane 4 p + j receives element j of the four corners — which IS the K-vector of the
+//     4x4x4 MFMA for one channel (the buffer path needs 16 v_perm per sample for that 2-byte transposition: the kernel is VALU
+//     bound, so they are what the resident half no longer pays).  For lane j to receive "its" channel 8 j + n from the n-th read,
+//     a resident row is stored channel-permuted: position 4 n + j holds channel 8 j + n.  The fetching lane learns the corner's
+//     address from a 2 KB table the sample's owner writes over the (by then consumed) A rows of the buffer-path samples.
 //   * corners outside the map aim at an all-zero LDS row (resident levels) or past the slab (buffer bounds check): no branches,
 //     and no byte outside the sampled footprint is ever read (NaN-safe like the other kernels).
 //   * RL = first resident level (2: levels 2-3, 3: level 3 only).  `res_row0` comes from the HOST's copy of the level starts;
 //     the kernel compares it with the device copy and, should they disagree, serves every level through the buffer path: the
 //     hint steers speed, never results.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kResWaves = 12;                            // 3 waves per SIMD: <= 168 registers
+#ifndef ALO_RES_WAVES
+#define ALO_RES_WAVES 8
+#endif
+constexpr int kResWaves = ALO_RES_WAVES;                 // 2 waves per SIMD: up to 256 registers, 32 buffer loads in flight per wave
 constexpr int kResThreads = 64 * kResWaves;
-constexpr int kResSampleStride = 16 * 24 + 16;           // bytes between the A rows of consecutive samples (16 pairs x 24 B + pad:
-                                                         // the four writers of a pair land on distinct banks)
-constexpr int kResWaveLds = 16 * kResSampleStride;       // 6400 B per wave
+constexpr int kResSampleStride = 16 * 24;                // bytes between the A rows of consecutive samples (16 pairs x 24 B)
+constexpr int kResTable = 8 * 256;                       // corner addresses of up to 8 resident samples x 16 pairs x 4 corners
+constexpr int kResWaveLds = 16 * kResSampleStride + kResTable;   // 8192 B per wave
 constexpr int kResLdsTotal = 160 * 1024;
-constexpr int kResFixed = 64 /* zero row */ + 16 /* run counter */;
-constexpr int kResMaxRows = (kResLdsTotal - kResWaves * kResWaveLds - kResFixed) / 64;   // 1358 rows of 64 B
+#ifndef ALO_RES_PITCH
+#define ALO_RES_PITCH 72
+#endif
+constexpr int kResPitch = ALO_RES_PITCH;                 // bytes between resident rows in LDS
+constexpr int kResFixed = kResPitch /* zero row */ + 16 /* run counter */;
+constexpr int kResMaxRows = (kResLdsTotal - kResWaves * kResWaveLds - kResFixed) / kResPitch;   // 1406 rows
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 struct ResDims {
     int res_row0;       // first resident row of a slab (host copy of level_start_index[RL])
@@ -688,9 +738,10 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
     const int pl = lid >> 2, lane = lid & 3;   // pair slot in the wave, lane in the quad (= level in stage 1)
 
     const bf16_t* slab_base = value + ((size_t)b * dm.M + m) * dm.S * 32;
-    const unsigned zero_row = (unsigned)rd.res_rows * 64u;                       // LDS byte address of the all-zero row
-    int* counter = reinterpret_cast<int*>(smem + zero_row + 64);
-    unsigned char* aw = smem + zero_row + kResFixed + wave * kResWaveLds;         // this wave's A rows
+    const unsigned zero_row = (unsigned)rd.res_rows * (unsigned)kResPitch;       // LDS byte address of the all-zero row
+    int* counter = reinterpret_cast<int*>(smem + zero_row + kResPitch);
+    unsigned char* aw = smem + zero_row + kResFixed + wave * kResWaveLds;         // this wave's A rows ...
+    unsigned char* tab = aw + 16 * kResSampleStride;                              // ... and its table of resident corner addresses
 
     // the host's view of the pyramid must be the device's; otherwise nothing is treated as resident (wave-uniform)
     bool res_ok = rd.res_row0 == lstart[RL];
@@ -700,64 +751,96 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
 
     // ---- the slab's coarse rows -> LDS (one coalesced pass), zero row, run counter ------------------------------------------
     {
+        // channel-permuted image: a 16-byte granule holds channels 8 j .. 8 j + 7 of its row; channel 8 j + n goes to position 4 n + j
         const u32x4* src = reinterpret_cast<const u32x4*>(slab_base + (size_t)rd.res_row0 * 32);
-        u32x4* dst = reinterpret_cast<u32x4*>(smem);
         const int ngran = rd.res_rows * 4;
-        for (int g = threadIdx.x; g < ngran; g += kResThreads) dst[g] = src[g];
-        if (threadIdx.x < 4) dst[ngran + threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
+        for (int g = threadIdx.x; g < ngran; g += kResThreads) {
+            const u32x4 v = src[g];
+            unsigned short* row = reinterpret_cast<unsigned short*>(smem + (unsigned)(g >> 2) * (unsigned)kResPitch) + (g & 3);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) row[4 * n] = (unsigned short)(v[n >> 1] >> (16 * (n & 1)));
+        }
+        if (threadIdx.x < kResPitch / 4) reinterpret_cast<unsigned*>(smem + zero_row)[threadIdx.x] = 0u;
         if (threadIdx.x == 0) *counter = 0;
     }
     __syncthreads();
 
     const unsigned row_bytes = 64u;
     const int Lq = dm.pairs_per_batch / dm.M;
-    const long batch_pair0 = (long)b * dm.pairs_per_batch;
+    // wave-uniform bases of this image's rows + 32-bit per-lane element offsets: the loads take an SGPR base and one VGPR offset
+    const bf16_t* loc_b = static_cast<const bf16_t*>(loc_) + (size_t)b * Lq * dm.loc_row_elems;
+    const bf16_t* attn_b = static_cast<const bf16_t*>(attn_) + (size_t)b * Lq * dm.attn_row_elems;
+    const float* ref_b = ref + (size_t)b * Lq * 4 * dm.ref_dim;
+    bf16_t* out_b = out + (size_t)b * dm.pairs_per_batch * 32;
+    const unsigned lane_loc = 32u * m + 8u * lane, lane_attn = 16u * m + 4u * lane, lane_out = 32u * m + 8u * lane;
     const int Hl = shapes[2 * lane], Wl = shapes[2 * lane + 1];
     const bool lane_res = res_ok && lane >= RL;
     const int start = lane_res ? lstart[lane] - rd.res_row0 : lstart[lane];
     const unsigned oor = lane_res ? zero_row : kOutOfRange;
-    const float inv_w = 1.0f / (float)Wl, inv_h = 1.0f / (float)Hl;
+    const float Hf = (float)Hl, Wf = (float)Wl;
+    const float inv_w = 1.0f / Wf, inv_h = 1.0f / Hf;
+    const unsigned lane_pitch = lane_res ? (unsigned)kResPitch : row_bytes;   // bytes between neighbouring pixels where this lane's level lives
+    const unsigned base0 = (unsigned)start * lane_pitch, w_bytes = (unsigned)Wl * lane_pitch;
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(slab_base, (unsigned)dm.S * row_bytes);
     const unsigned coff = (unsigned)lane * 16u;   // this lane's 8 channels of a 64-byte row
+    // transpose-read roles: in its 16-lane group this lane FETCHES corner (lid >> 2) & 3 of the group's pair lid & 3
+    const unsigned fetch_off = (unsigned)((((lid >> 4) * 4 + (lid & 3)) * 16) + ((lid >> 2) & 3) * 4);
     const int run_lo = part * rd.runs_per_wg;
     const int run_hi = min(run_lo + rd.runs_per_wg, rd.runs_per_slab);
     unsigned char* aw_wr = aw + (4 * lane) * kResSampleStride + pl * 24;
     const unsigned char* aw_rd = aw + pl * 24 + 8 * min(lane, 2);   // lane 3's row of A is ignored (D[3] is never summed)
 
-    for (;;) {
+    // The raw offsets / logits / reference point of a run are requested ONE RUN AHEAD (under the previous run's gathers): with two
+    // waves per SIMD a run that starts by waiting for its own inputs leaves the SIMD idle for a memory round trip.
+    struct RunIn {
+        int run;
+        bool dead;
+        unsigned qc;
+        u32x4 lr;
+        u32x2 ar;
+        f32x4 rv;
+    };
+    auto next_run = [&]() -> RunIn {
+        RunIn in;
         int r = 0;
         if (lid == 0) r = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int run = run_lo + __builtin_amdgcn_readfirstlane(r);
-        if (run >= run_hi) break;   // wave-uniform
-        const int q = run * 16 + pl;
-        const bool dead = q >= Lq;
-        const int qc = min(q, Lq - 1);
-        const long qrow = (long)b * Lq + qc;
+        in.run = run_lo + __builtin_amdgcn_readfirstlane(r);
+        const int q = in.run * 16 + pl;
+        in.dead = q >= Lq || in.run >= run_hi;
+        in.qc = (unsigned)min(q, Lq - 1);   // row of this query inside the image: 32-bit element offsets (host-checked)
+        in.lr = *reinterpret_cast<const u32x4*>(loc_b + (in.qc * (unsigned)dm.loc_row_elems + lane_loc));
+        in.ar = *reinterpret_cast<const u32x2*>(attn_b + (in.qc * (unsigned)dm.attn_row_elems + lane_attn));
+        const float* rp = ref_b + (in.qc * 4u + (unsigned)lane) * (unsigned)dm.ref_dim;
+        if (dm.ref_dim == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(rp);
+            in.rv = f32x4{v.x, v.y, 0.f, 0.f};
+        } else {
+            in.rv = *reinterpret_cast<const f32x4*>(rp);
+        }
+        return in;
+    };
+    RunIn nxt = next_run();
+    for (;;) {
+        const RunIn cur = nxt;
+        if (cur.run >= run_hi) break;   // wave-uniform
+        nxt = next_run();               // a run index past the end clamps to the image's last query: the loads stay in bounds
+        const bool dead = cur.dead;
+        const unsigned qc = cur.qc;
 
         // ---- stage 1: the 4 points of level `lane` of this quad's (query, head) pair --------------------------------------------
         unsigned off[4][4];
         {
             float x[4], y[4], a[4];
-            const u32x4 lr = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(loc_) + qrow * dm.loc_row_elems + 32 * m + 8 * lane);
-            const u32x2 ar = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(attn_) + qrow * dm.attn_row_elems + 16 * m + 4 * lane);
-            const float* rp = ref + (qrow * dm.L + lane) * dm.ref_dim;
-            float r0, r1, r2 = 0.f, r3 = 0.f;
-            if (dm.ref_dim == 2) {
-                const float2 rv = *reinterpret_cast<const float2*>(rp);
-                r0 = rv.x; r1 = rv.y;
-            } else {
-                const float4 rv = *reinterpret_cast<const float4*>(rp);
-                r0 = rv.x; r1 = rv.y; r2 = rv.z; r3 = rv.w;
-            }
+            const u32x4 lr = cur.lr;
+            const u32x2 ar = cur.ar;
+            const float r0 = cur.rv[0], r1 = cur.rv[1], r2 = cur.rv[2], r3 = cur.rv[3];
             wave_prologue(lr, ar, r0, r1, r2, r3, dm.ref_dim, inv_w, inv_h, dm.P, x, y, a);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // a pair past the end samples far outside the map: every corner becomes "not read, weight 0" by itself
-                const FwdDesc<float> fd = make_desc<float, true>(dead ? -8.0f : x[i], dead ? -8.0f : y[i], a[i], Hl, Wl, start, row_bytes);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) off[i][k] = fd.off[k] == kOutOfRange ? oor : fd.off[k];
+                float w4[4];
+                lean_sample(x[i], y[i], a[i], !dead, Hf, Wf, base0, lane_pitch, w_bytes, oor, off[i], w4);
                 u32x2 rows[3];
-                split_weights(fd.w, rows);
+                split_weights(w4, rows);
                 u32x2* dst = reinterpret_cast<u32x2*>(aw_wr + i * kResSampleStride);
                 dst[0] = rows[0];
                 dst[1] = rows[1];
@@ -787,38 +870,97 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
                 }
             }
         };
-#define ALO_RES_GROUP(J)                                                                                                       \
+        // buffer path: group J's corner addresses come from lane J of the quad (DPP broadcast folded into the add)
+#define ALO_RES_ISSUE(J, RAW)                                                                                                  \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                         \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                         \
+            RAW[p][k] = Ld::load(rsrc, quad_bcast<J>(off[p][k]) + coff);
+#define ALO_RES_CONSUME(J, RAW)                                                                                                \
         {                                                                                                                      \
-            u32x4 raw[4][4];                                                                                                   \
             s16x4 arow[4];                                                                                                     \
             _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                   \
                 const u32x2 ar = *reinterpret_cast<const u32x2*>(aw_rd + (4 * J + p) * kResSampleStride);                     \
                 arow[p] = as_s16x4(ar.x, ar.y);                                                                                \
             }                                                                                                                  \
-            if (J >= RL && res_ok) {                                                                                           \
-                _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                 \
-                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                 \
-                    raw[p][k] = *reinterpret_cast<const u32x4*>(smem + (quad_bcast<J>(off[p][k]) + coff));                     \
-            } else {                                                                                                           \
-                _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                 \
-                _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                 \
-                    raw[p][k] = Ld::load(rsrc, quad_bcast<J>(off[p][k]) + coff);                                               \
-            }                                                                                                                  \
-            consume(raw, arow);                                                                                                \
+            consume(RAW, arow);                                                                                                \
         }
-        ALO_RES_GROUP(0)
-        __builtin_amdgcn_sched_barrier(0);
-        ALO_RES_GROUP(1)
-        __builtin_amdgcn_sched_barrier(0);
-        ALO_RES_GROUP(2)
-        __builtin_amdgcn_sched_barrier(0);
-        ALO_RES_GROUP(3)
-#undef ALO_RES_GROUP
+        // LDS path: the fetching lane reads its corner's address from the table, eight transpose reads deliver the eight B operands
+#define ALO_RES_GROUP_TR(J)                                                                                                    \
+        {                                                                                                                      \
+            unsigned ca[4];                                                                                                    \
+            s16x4 arow[4];                                                                                                     \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                   \
+                ca[p] = *reinterpret_cast<const unsigned*>(tab + ((J - RL) * 4 + p) * 256 + fetch_off);                       \
+                const u32x2 ar = *reinterpret_cast<const u32x2*>(aw_rd + (4 * J + p) * kResSampleStride);                     \
+                arow[p] = as_s16x4(ar.x, ar.y);                                                                                \
+            }                                                                                                                  \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                   \
+                v4i16_t bt[8];                                                                                                 \
+                _Pragma("unroll") for (int n = 0; n < 8; ++n)                                                                 \
+                    bt[n] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                                           \
+                        (__attribute__((address_space(3))) v4i16_t*)(smem + ca[p] + 8 * n));                                  \
+                _Pragma("unroll") for (int n = 0; n < 8; ++n)                                                                 \
+                    acc[n] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[p], bt[n], acc[n], 0, 0, 0);                          \
+            }                                                                                                                  \
+        }
+        // Order of the sum: resident levels first, then the buffer-path levels (every wave kernel sums in this order, so they
+        // agree bit for bit).  All buffer loads of the run are in flight while the resident samples are served from LDS.
+        if (res_ok) {   // wave-uniform
+            u32x4 raw0[4][4], raw1[4][4];
+            // corner addresses of the resident samples -> table
+            if (lane >= RL) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    *reinterpret_cast<u32x4*>(tab + ((lane - RL) * 4 + p) * 256 + pl * 16) = u32x4{off[p][0], off[p][1], off[p][2], off[p][3]};
+            }
+            if constexpr (RL == 2) {
+                ALO_RES_ISSUE(0, raw0)
+                ALO_RES_ISSUE(1, raw1)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                ALO_RES_GROUP_TR(2)
+                __builtin_amdgcn_sched_barrier(0);
+                ALO_RES_GROUP_TR(3)
+                __builtin_amdgcn_sched_barrier(0);
+                ALO_RES_CONSUME(0, raw0)
+                __builtin_amdgcn_sched_barrier(0);
+                ALO_RES_CONSUME(1, raw1)
+            } else {   // level 3 alone is resident; level 2 is summed first all the same
+                ALO_RES_ISSUE(2, raw0)
+                ALO_RES_ISSUE(0, raw1)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                ALO_RES_CONSUME(2, raw0)
+                __builtin_amdgcn_sched_barrier(0);
+                ALO_RES_GROUP_TR(3)
+                ALO_RES_ISSUE(1, raw0)
+                __builtin_amdgcn_sched_barrier(0);
+                ALO_RES_CONSUME(0, raw1)
+                __builtin_amdgcn_sched_barrier(0);
+                ALO_RES_CONSUME(1, raw0)
+            }
+        } else {   // the host's view of the pyramid is not the device's: every level through the buffer path, same order of the sum
+            u32x4 raw0[4][4], raw1[4][4];
+            ALO_RES_ISSUE(2, raw0)
+            ALO_RES_ISSUE(3, raw1)
+            ALO_RES_CONSUME(2, raw0)
+            ALO_RES_CONSUME(3, raw1)
+            __builtin_amdgcn_sched_barrier(0);
+            ALO_RES_ISSUE(0, raw0)
+            ALO_RES_ISSUE(1, raw1)
+            ALO_RES_CONSUME(0, raw0)
+            ALO_RES_CONSUME(1, raw1)
+        }
+#undef ALO_RES_ISSUE
+#undef ALO_RES_CONSUME
+#undef ALO_RES_GROUP_TR
         if (!dead) {
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (acc[i][0] + acc[i][1]) + acc[i][2];
-            store_vec<bf16_t, float, 8>(out + (batch_pair0 + (long)qc * dm.M + m) * 32 + lane * 8, o);
+            store_vec<bf16_t, float, 8>(out_b + (qc * (unsigned)dm.M * 32u + lane_out), o);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1552,14 +1694,16 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
             long wps = slabs >= cus ? 1 : (cus + slabs - 1) / slabs;
             const long wps_cap = rd.runs_per_slab / (4 * kResWaves);   // >= 4 runs per wave, or the resident copy does not pay
             if (wps > wps_cap) wps = wps_cap;
-            if (rl && wps >= 1 && slabs * wps < 0x7fffffffL) {
+            const bool offs32 = (double)Lq * dm.loc_row_elems < 4.0e9 && (double)Lq * dm.attn_row_elems < 4.0e9 &&
+                                (double)Lq * M * 32 < 4.0e9 && (double)Lq * 4 * ref_dim < 4.0e9;   // 32-bit element offsets per image
+            if (rl && wps >= 1 && slabs * wps < 0x7fffffffL && offs32) {
                 rd.res_row0 = host_level_start[rl];
                 rd.res_rows = S - rd.res_row0;
                 rd.wps = (int)wps;
                 rd.runs_per_wg = (int)((rd.runs_per_slab + wps - 1) / wps);
                 dm.nblocks = (unsigned)(slabs * wps);
                 void* rargs[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm, &rd};
-                const size_t lds = (size_t)rd.res_rows * 64 + kResFixed + (size_t)kResWaves * kResWaveLds;
+                const size_t lds = (size_t)rd.res_rows * kResPitch + kResFixed + (size_t)kResWaves * kResWaveLds;
                 static unsigned long long attr_done[2] = {0, 0};   // one bit per device
                 const void* fn = rl == 2 ? reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<2>)
                                          : reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<3>);
