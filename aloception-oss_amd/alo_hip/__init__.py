@@ -428,7 +428,7 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     return out
 
 
-RESIDENT_MAX_ROWS = 1364   # csrc/msda.hip kResMaxRows: 72-byte-pitch rows that fit in a CU's LDS next to 8 waves' work areas
+RESIDENT_MAX_ROWS = 1335   # csrc/msda.hip kResMaxRows: 72-byte-pitch rows that fit in a CU's LDS next to 11 waves' work areas
 _CU_COUNT = {}
 
 

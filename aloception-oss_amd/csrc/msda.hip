@@ -619,11 +619,8 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
             f32x4 acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // order of the sum: levels 2, 3, 0, 1 — the order msda_fwd_bf16_resident_kernel needs (resident levels while the
-            // buffer loads of the others are in flight); every wave kernel uses it, so they agree bit for bit
 #pragma unroll 1
-            for (int t0 = 0; t0 < 16; t0 += SB) {
-                const int s0 = (t0 + 8) & 15;
+            for (int s0 = 0; s0 < 16; s0 += SB) {
                 u32x4 raw[SB][4];
                 s16x4 arow[SB];
 #pragma unroll
@@ -670,16 +667,17 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 // What bounds msda_fwd_bf16_mfma_kernel: every corner row is a 64-byte request through the texture path, whose
 // address / tag pipeline serves about one L1 line per two clocks per CU: stage 2 alone takes 0.22 ms for the 91 M rows of an
 // encoder call and the descriptor arithmetic hides behind it.  Half of those rows belong to the two coarse levels, which are
-// SMALL: levels 2 and 3 of the 1333 x 800 pyramid are 1050 + 273 pixels = 84.7 KB per (image, head) — they fit in a CU's LDS.
-// So here one 12-wave workgroup per CU is pinned to a slab, copies the slab's coarse rows [res_row0, S) into LDS once (one
-// coalesced pass, 22 MB over the whole launch), and its waves then serve every sample of a resident level with ds_read_b128
-// (no address coalescer, no tag lookup, 4x the L1's byte rate) and only the level-0 / level-1 samples through the buffer path.
-// The waves of a workgroup take runs of 16 consecutive queries from a workgroup-local counter, so at any time a CU works on
-// ~200 consecutive queries of ONE head — a band of the image about one row wide whose level-0/1 footprints overlap in L1.
+// SMALL: levels 2 and 3 of the 1333 x 800 pyramid are 1050 + 273 pixels = 84.7 KB per (image, head) (95 KB at the 72-byte
+// pitch used below) — they fit in a CU's 160 KB of LDS.
+// So here one 11-wave workgroup per CU is pinned to a slab, copies the slab's coarse rows [res_row0, S) into LDS once (one
+// coalesced pass, 22 MB over the whole launch), and its waves then serve every sample of a resident level from LDS and only the
+// level-0 / level-1 samples through the buffer path.  The waves of a workgroup take runs of 16 consecutive queries round-robin,
+// so at any time a CU works on ~180 consecutive queries of ONE head — a band of the image about one row wide whose level-0/1
+// footprints overlap in L1.
 //   * sample descriptors no longer travel through LDS whole: the lane that builds a sample keeps its four corner addresses in
 //     registers and the other lanes of the quad read them with DPP quad broadcasts folded into the address add (v_add_u32_dpp);
 //     only the A rows of the MFMA (the three bf16 terms of the corner weights, 24 bytes per sample) go through the wave's LDS
-//     slice, which is the transposition "row i of every sample to lane i" — 6.4 KB per wave instead of 12.5.
+//     slice, which is the transposition "row i of every sample to lane i" — 6 KB per wave instead of 12.5.
 //   * resident rows are consumed with ds_read_b64_tr_b16, the LDS transpose read: in every 16-lane group lane 4 r + p fetches
 //     eight bytes of corner r of pair p, and lane 4 p + j receives element j of the four corners — which IS the K-vector of the
 //     4x4x4 MFMA for one channel (the buffer path needs 16 v_perm per sample for that 2-byte transposition: the kernel is VALU
@@ -692,21 +690,17 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 //     the kernel compares it with the device copy and, should they disagree, serves every level through the buffer path: the
 //     hint steers speed, never results.
 // ------------------------------------------------------------------------------------------------------------------
-#ifndef ALO_RES_WAVES
-#define ALO_RES_WAVES 8
-#endif
-constexpr int kResWaves = ALO_RES_WAVES;                 // 2 waves per SIMD: up to 256 registers, 32 buffer loads in flight per wave
+constexpr int kResWaves = 11;                            // 3 + 3 + 3 + 2 waves on the CU's four SIMDs: <= 168 registers
 constexpr int kResThreads = 64 * kResWaves;
 constexpr int kResSampleStride = 16 * 24;                // bytes between the A rows of consecutive samples (16 pairs x 24 B)
 constexpr int kResTable = 8 * 256;                       // corner addresses of up to 8 resident samples x 16 pairs x 4 corners
-constexpr int kResWaveLds = 16 * kResSampleStride + kResTable;   // 8192 B per wave
+constexpr int kResWaveLds = 16 * kResSampleStride;       // 6144 B per wave (the table takes over consumed A rows)
+static_assert(kResTable <= 8 * kResSampleStride, "the table must fit in the A rows of the buffer-path samples");
 constexpr int kResLdsTotal = 160 * 1024;
-#ifndef ALO_RES_PITCH
-#define ALO_RES_PITCH 72
-#endif
-constexpr int kResPitch = ALO_RES_PITCH;                 // bytes between resident rows in LDS
+constexpr int kResPitch = 72;                            // bytes between resident rows in LDS: 18 dwords, so the rows a transpose read
+                                                         // touches spread over all 64 banks (64-byte pitch: 4 bank groups, 8-way conflicts)
 constexpr int kResFixed = kResPitch /* zero row */ + 16 /* run counter */;
-constexpr int kResMaxRows = (kResLdsTotal - kResWaves * kResWaveLds - kResFixed) / kResPitch;   // 1406 rows
+constexpr int kResMaxRows = (kResLdsTotal - kResWaves * kResWaveLds - kResFixed) / kResPitch;   // 1335 rows
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 struct ResDims {
@@ -722,6 +716,15 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {   // value of lane 
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
 }
 
+// LDS operations of ONE wave execute in order, so data handed from lane to lane of a wave through LDS needs no wait at all — only
+// the compiler must not move the reads above the writes.  (The fence builtins at "wavefront" scope drain vmcnt and lgkmcnt:
+// every run then waited for its own output store and for the next run's inputs.)
+#define ALO_WAVE_LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+#ifdef ALO_RES_TRACE
+#define ALO_T(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_[i] += now_ - last_; last_ = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ALO_T(i)
+#endif
 template <int RL>
 __global__ void __launch_bounds__(kResThreads)
 msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* __restrict__ shapes,
@@ -739,9 +742,8 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
 
     const bf16_t* slab_base = value + ((size_t)b * dm.M + m) * dm.S * 32;
     const unsigned zero_row = (unsigned)rd.res_rows * (unsigned)kResPitch;       // LDS byte address of the all-zero row
-    int* counter = reinterpret_cast<int*>(smem + zero_row + kResPitch);
     unsigned char* aw = smem + zero_row + kResFixed + wave * kResWaveLds;         // this wave's A rows ...
-    unsigned char* tab = aw + 16 * kResSampleStride;                              // ... and its table of resident corner addresses
+    unsigned char* tab = aw;   // ... whose first rows, once consumed, take the table of the resident samples' corner addresses
 
     // the host's view of the pyramid must be the device's; otherwise nothing is treated as resident (wave-uniform)
     bool res_ok = rd.res_row0 == lstart[RL];
@@ -761,7 +763,6 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
             for (int n = 0; n < 8; ++n) row[4 * n] = (unsigned short)(v[n >> 1] >> (16 * (n & 1)));
         }
         if (threadIdx.x < kResPitch / 4) reinterpret_cast<unsigned*>(smem + zero_row)[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) *counter = 0;
     }
     __syncthreads();
 
@@ -800,11 +801,11 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
         u32x2 ar;
         f32x4 rv;
     };
+    int next_index = wave;   // runs are dealt out round-robin over the workgroup's waves (every run costs the same instructions)
     auto next_run = [&]() -> RunIn {
         RunIn in;
-        int r = 0;
-        if (lid == 0) r = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        in.run = run_lo + __builtin_amdgcn_readfirstlane(r);
+        in.run = run_lo + next_index;
+        next_index += kResWaves;
         const int q = in.run * 16 + pl;
         in.dead = q >= Lq || in.run >= run_hi;
         in.qc = (unsigned)min(q, Lq - 1);   // row of this query inside the image: 32-bit element offsets (host-checked)
@@ -819,13 +820,16 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
         }
         return in;
     };
-    RunIn nxt = next_run();
-    for (;;) {
-        const RunIn cur = nxt;
-        if (cur.run >= run_hi) break;   // wave-uniform
-        nxt = next_run();               // a run index past the end clamps to the image's last query: the loads stay in bounds
+#ifdef ALO_RES_TRACE
+    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+    int nruns_ = 0;
+#endif
+    RunIn cur = next_run();
+    while (cur.run < run_hi) {   // wave-uniform
+        ALO_T(7)
         const bool dead = cur.dead;
         const unsigned qc = cur.qc;
+        ALO_T(0)
 
         // ---- stage 1: the 4 points of level `lane` of this quad's (query, head) pair --------------------------------------------
         unsigned off[4][4];
@@ -847,11 +851,13 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
                 dst[2] = rows[2];
             }
         }
+        // the next run's inputs are requested NOW, into the registers stage 1 has just finished with: they travel under this run's
+        // gathers (a run index past the end clamps to the image's last query: the loads stay in bounds)
+        const RunIn nxt = next_run();
+        ALO_T(1)
         // A rows are exchanged inside the wave only: LDS operations of one wave execute in order, the fence keeps the compiler
         // from moving the reads below above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
 
         // ---- stage 2: gather + MFMA accumulate; group J = the 4 samples of level J, built by lane J of the quad -----------------
         f32x4 acc[8];
@@ -885,87 +891,100 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
             consume(RAW, arow);                                                                                                \
         }
         // LDS path: the fetching lane reads its corner's address from the table, eight transpose reads deliver the eight B operands
-#define ALO_RES_GROUP_TR(J)                                                                                                    \
-        {                                                                                                                      \
-            unsigned ca[4];                                                                                                    \
-            s16x4 arow[4];                                                                                                     \
-            _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                   \
-                ca[p] = *reinterpret_cast<const unsigned*>(tab + ((J - RL) * 4 + p) * 256 + fetch_off);                       \
-                const u32x2 ar = *reinterpret_cast<const u32x2*>(aw_rd + (4 * J + p) * kResSampleStride);                     \
-                arow[p] = as_s16x4(ar.x, ar.y);                                                                                \
-            }                                                                                                                  \
-            _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                                   \
-                v4i16_t bt[8];                                                                                                 \
-                _Pragma("unroll") for (int n = 0; n < 8; ++n)                                                                 \
-                    bt[n] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                                           \
-                        (__attribute__((address_space(3))) v4i16_t*)(smem + ca[p] + 8 * n));                                  \
-                _Pragma("unroll") for (int n = 0; n < 8; ++n)                                                                 \
-                    acc[n] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[p], bt[n], acc[n], 0, 0, 0);                          \
-            }                                                                                                                  \
-        }
-        // Order of the sum: resident levels first, then the buffer-path levels (every wave kernel sums in this order, so they
-        // agree bit for bit).  All buffer loads of the run are in flight while the resident samples are served from LDS.
+        // of a sample.  The reads of sample t + 1 are issued BEFORE the MFMAs of sample t (left to itself the compiler keeps three
+        // reads in flight and every MFMA waits most of an LDS round trip: 2.5 k cycles per run).
+        auto resident_samples = [&]() {
+            constexpr int NS = 4 * (4 - RL);
+            unsigned ca[NS];
+            s16x4 arow[NS];
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                ca[t] = *reinterpret_cast<const unsigned*>(tab + t * 256 + fetch_off);
+                const u32x2 ar = *reinterpret_cast<const u32x2*>(aw_rd + (4 * RL + t) * kResSampleStride);
+                arow[t] = as_s16x4(ar.x, ar.y);
+            }
+            v4i16_t bt[2][8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                bt[0][n] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)(smem + ca[0] + 8 * n));
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                if (t + 1 < NS) {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n)
+                        bt[(t + 1) & 1][n] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) v4i16_t*)(smem + ca[t + 1] + 8 * n));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(arow[t], bt[t & 1][n], acc[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // Order of the sum: levels 0, 1, 2, 3, as in the other wave kernels (same products, same order: bit-identical outputs).
         if (res_ok) {   // wave-uniform
-            u32x4 raw0[4][4], raw1[4][4];
-            // corner addresses of the resident samples -> table
+            static_assert(RL == 2 || RL == 3, "first resident level");
+            {
+                u32x4 raw[4][4];
+                ALO_RES_ISSUE(0, raw)
+                ALO_RES_CONSUME(0, raw)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                u32x4 raw[4][4];
+                ALO_RES_ISSUE(1, raw)
+                ALO_RES_CONSUME(1, raw)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (RL == 3) {
+                u32x4 raw[4][4];
+                ALO_RES_ISSUE(2, raw)
+                ALO_RES_CONSUME(2, raw)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ALO_WAVE_LDS_ORDER();
             if (lane >= RL) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
                     *reinterpret_cast<u32x4*>(tab + ((lane - RL) * 4 + p) * 256 + pl * 16) = u32x4{off[p][0], off[p][1], off[p][2], off[p][3]};
             }
-            if constexpr (RL == 2) {
-                ALO_RES_ISSUE(0, raw0)
-                ALO_RES_ISSUE(1, raw1)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                ALO_RES_GROUP_TR(2)
-                __builtin_amdgcn_sched_barrier(0);
-                ALO_RES_GROUP_TR(3)
-                __builtin_amdgcn_sched_barrier(0);
-                ALO_RES_CONSUME(0, raw0)
-                __builtin_amdgcn_sched_barrier(0);
-                ALO_RES_CONSUME(1, raw1)
-            } else {   // level 3 alone is resident; level 2 is summed first all the same
-                ALO_RES_ISSUE(2, raw0)
-                ALO_RES_ISSUE(0, raw1)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                ALO_RES_CONSUME(2, raw0)
-                __builtin_amdgcn_sched_barrier(0);
-                ALO_RES_GROUP_TR(3)
-                ALO_RES_ISSUE(1, raw0)
-                __builtin_amdgcn_sched_barrier(0);
-                ALO_RES_CONSUME(0, raw1)
-                __builtin_amdgcn_sched_barrier(0);
-                ALO_RES_CONSUME(1, raw0)
-            }
-        } else {   // the host's view of the pyramid is not the device's: every level through the buffer path, same order of the sum
-            u32x4 raw0[4][4], raw1[4][4];
-            ALO_RES_ISSUE(2, raw0)
-            ALO_RES_ISSUE(3, raw1)
-            ALO_RES_CONSUME(2, raw0)
-            ALO_RES_CONSUME(3, raw1)
+            ALO_WAVE_LDS_ORDER();
+            resident_samples();
+        } else {   // the host's view of the pyramid is not the device's: every level through the buffer path
+            u32x4 raw[4][4];
+            ALO_RES_ISSUE(0, raw)
+            ALO_RES_CONSUME(0, raw)
             __builtin_amdgcn_sched_barrier(0);
-            ALO_RES_ISSUE(0, raw0)
-            ALO_RES_ISSUE(1, raw1)
-            ALO_RES_CONSUME(0, raw0)
-            ALO_RES_CONSUME(1, raw1)
+            ALO_RES_ISSUE(1, raw)
+            ALO_RES_CONSUME(1, raw)
+            __builtin_amdgcn_sched_barrier(0);
+            ALO_RES_ISSUE(2, raw)
+            ALO_RES_CONSUME(2, raw)
+            __builtin_amdgcn_sched_barrier(0);
+            ALO_RES_ISSUE(3, raw)
+            ALO_RES_CONSUME(3, raw)
         }
 #undef ALO_RES_ISSUE
 #undef ALO_RES_CONSUME
-#undef ALO_RES_GROUP_TR
         if (!dead) {
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (acc[i][0] + acc[i][1]) + acc[i][2];
             store_vec<bf16_t, float, 8>(out_b + (qc * (unsigned)dm.M * 32u + lane_out), o);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_T(6)
+#ifdef ALO_RES_TRACE
+        ++nruns_;
+#endif
+        cur = nxt;
+        ALO_WAVE_LDS_ORDER();
     }
+#ifdef ALO_RES_TRACE
+    if (lid == 0 && (blockIdx.x == 3 || blockIdx.x == 100) && wave < 2)
+        printf("blk %d wave %d runs %d | next_run %llu | stage1 %llu | issue+table %llu | resident %llu | consume0 %llu | consume1 %llu | store %llu | loop %llu (cycles per run)\n",
+               (int)blockIdx.x, wave, nruns_, tr_[0] / nruns_, tr_[1] / nruns_, tr_[2] / nruns_, tr_[3] / nruns_, tr_[4] / nruns_, tr_[5] / nruns_,
+               tr_[6] / nruns_, tr_[7] / nruns_);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
