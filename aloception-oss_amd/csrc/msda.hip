@@ -420,6 +420,12 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// LDS operations of ONE wave execute in order, so data handed from lane to lane of a wave through LDS needs no wait at all — only
+// the compiler must not move the reads above the writes.  The fence builtins at "wavefront" scope are NOT that: they lower to
+// s_waitcnt vmcnt(0) lgkmcnt(0), i.e. every hand-over also waited for the wave's outstanding global loads, stores and atomics
+// (the forward: its own output store and the next run's inputs; the tiled backward: all of a pass's row atomics).
+#define ALO_WAVE_LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 // One sampling point -> four corner byte offsets + four corner weights (already times the attention weight), the lean way the
 // wave kernels use (fp32, `W * row_bytes` and `H * W` below 2^23).  Same semantics as make_desc (cuh:285-291, :38-78):
 //   * the sample counts iff  h_im > -1 && w_im > -1 && h_im < H && w_im < W  (and the query exists: `alive`);
@@ -609,9 +615,7 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
         }
         // descriptors are exchanged inside the wave only: LDS operations of one wave execute in order, the fence keeps the
         // compiler from moving the reads below above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
 
         // ---- stage 2: gather + MFMA accumulate -----------------------------------------------------------------------
         {
@@ -655,9 +659,7 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
                 store_vec<bf16_t, float, 8>(out + (batch_pair0 + pair) * dm.D + c0, o);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
     }
 }
 
@@ -716,10 +718,6 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {   // value of lane 
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
 }
 
-// LDS operations of ONE wave execute in order, so data handed from lane to lane of a wave through LDS needs no wait at all — only
-// the compiler must not move the reads above the writes.  (The fence builtins at "wavefront" scope drain vmcnt and lgkmcnt:
-// every run then waited for its own output store and for the next run's inputs.)
-#define ALO_WAVE_LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 #ifdef ALO_RES_TRACE
 #define ALO_T(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_[i] += now_ - last_; last_ = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
@@ -1384,9 +1382,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
             const int ry = (int)(((float)rl + 0.5f) * inv), rx = rl - ry * wwl;
             rowoff[r] = r < used ? (unsigned)(Sv + (wy + ry) * Wv + wx + rx) * row_b : kDropped;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (mine && (flags[p] & 16u)) {
@@ -1401,9 +1397,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                     if ((flags[p] >> k) & 1u) region[(off + idx[k]) * 16 + qi] = cur[k] + w4[k];
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
 
         // ---- stage 2: grad_value of the stacked rows, 32 at a time -----------------------------------------------------------------
         // (rows of the last block past `used` multiply whatever the region holds there: each output row depends on its own A row
@@ -1460,9 +1454,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
                     if (row0 + reg < used) region[(row0 + reg) * 16 + (lane & 15)] = d[reg];
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
         if (mine && live) {
             f32x4 ga, gl0, gl1;
 #pragma unroll
@@ -1488,9 +1480,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
             *reinterpret_cast<f32x4*>(glp + 4) = gl1;
             *reinterpret_cast<f32x4*>(grad_attn + (qm * 4 + lev) * 4) = ga;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
     }
     // levels with nothing to do (no valid sample of the sub-tile): their gradients are zero
     if (my_pass == 9 && live) {
@@ -1511,9 +1501,7 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
             dst[0] = u32x4{flags[p], (unsigned)q_own, (unsigned)h_low[p], (unsigned)w_low[p]};
             dst[1] = u32x4{__float_as_uint(lh[p]), __float_as_uint(lw[p]), __float_as_uint(at[p]), 0u};
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        ALO_WAVE_LDS_ORDER();
     }
 #pragma unroll
     for (int lv = 0; lv < 4; ++lv) {
