@@ -68,6 +68,8 @@ def _declare(lib):
     lib.alo_msda_forward_fused_hm.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_msda_forward_fused_hm_resident.restype = ip
     lib.alo_msda_forward_fused_hm_resident.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [c.POINTER(c.c_int32), vp]
+    lib.alo_msda_resident_levels.restype = ip
+    lib.alo_msda_resident_levels.argtypes = [c.POINTER(c.c_int32)] + [ip] * 5
     lib.alo_value_head_major.restype = ip
     lib.alo_value_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
     lib.alo_bias_act_nchw.restype = ip
@@ -396,19 +398,15 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     out = torch.empty((N, Lq, M * D), dtype=value_hm.dtype, device=value_hm.device)
     e = value_hm.element_size()
     nbytes = e * (N * S * M * D + N * Lq * M * D + N * Lq * M * L * P * 3) + 4 * reference_points.numel()
-    # coarse levels resident in LDS: needs a HOST copy of the level starts (it picks the resident levels and sizes the grid; the
-    # kernel re-checks it against the device copy).  Only a copy that is already at hand is used — no device read in a forward.
+    # coarse levels resident in LDS: needs a HOST copy of the shapes (it picks the resident levels, fixes the LDS layout and sizes the
+    # grid; the kernel re-checks it against the device copy).  Only a copy that is already at hand is used — no device read in a forward.
     host = getattr(spatial_shapes, "_alo_shapes", None) if resident else None
     if host is None and resident:
         hit = getattr(spatial_shapes, "_alo_shapes_read", None)
         host = hit[1] if hit is not None and hit[0] == spatial_shapes._version else None
     starts = None
-    if host is not None and D == 32 and len(host) == L:
-        acc, vals = 0, []
-        for h, w in host:
-            vals.append(acc)
-            acc += int(h) * int(w)
-        starts = (ctypes.c_int32 * L)(*vals) if acc == S else None
+    if host is not None and D == 32 and len(host) == L and sum(int(h) * int(w) for h, w in host) == S:
+        starts = (ctypes.c_int32 * (2 * L))(*[int(v) for hw in host for v in hw])
 
     def launch():
         if starts is not None:
@@ -422,27 +420,10 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
                                                     _ptr(reference_points), _ptr(out), N, S, M, D, L, Lq, P, ref_dim,
                                                     _DTYPE_CODE[value_hm.dtype], _stream(value_hm.device)))
 
-    tag = "msda_fwd_fused_resident" if starts is not None and resident_launch_eligible(N, M, Lq, S, list(starts)) else "msda_fwd_fused"
+    tag = "msda_fwd_fused_resident" if starts is not None and lib().alo_msda_resident_levels(starts, N, S, M, L, Lq) else "msda_fwd_fused"
     with torch.cuda.device(value_hm.device), _timed(f"{tag}/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
         launch()
     return out
-
-
-RESIDENT_MAX_ROWS = 1335   # csrc/msda.hip kResMaxRows: 72-byte-pitch rows that fit in a CU's LDS next to 11 waves' work areas
-_CU_COUNT = {}
-
-
-def resident_launch_eligible(N, M, Lq, S, starts):
-    """Mirror of the dispatch rule in csrc/msda.hip (forward_impl): which launches alo_msda_forward_fused_hm_resident serves with
-    the LDS-resident kernel rather than by falling back to the plain head-major one.  Used for the launch tag only."""
-    if not any(0 < starts[l] < S and S - starts[l] <= RESIDENT_MAX_ROWS for l in (2, 3)):
-        return False
-    dev = torch.cuda.current_device()
-    if dev not in _CU_COUNT:
-        _CU_COUNT[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
-    cus, slabs, runs = _CU_COUNT[dev], N * M, (Lq + 15) // 16
-    wps = 1 if slabs >= cus else (cus + slabs - 1) // slabs
-    return min(wps, runs // 48) >= 1
 
 
 def _host_spatial_shapes(spatial_shapes):

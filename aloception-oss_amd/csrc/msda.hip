@@ -434,16 +434,20 @@ __device__ __forceinline__ float quad_sum(float v) {
 // Unlike make_desc the weights of corners that are not read are NOT zeroed — they are finite and meet a zero row, which
 // saves eight selects per sample (the descriptor stage is what bounds the LDS-resident kernel: VALU 88 % busy).  Weights are
 // built separably: (1 - lh) * a and lh * a once per row, times (1 - lw) / lw per column.
-__device__ __forceinline__ void lean_sample(float x, float y, float a, bool alive, float Hf, float Wf, unsigned base0,
-                                            unsigned row_bytes, unsigned w_bytes, unsigned oor, unsigned (&off)[4], float (&w)[4]) {
+// Addressing: pixel (h, w) of the level lives at base0 + (h * row_units + w * px_units) * unit_bytes — `row_units` / `px_units` are the
+// row stride and the pixel pitch in units of `unit_bytes`, as floats.  The plain kernels use unit = one pixel (px_units = 1, folded
+// away); the LDS-resident kernel pads every image row of a resident level by half a pixel (bank spreading), hence half-pixel units.
+__device__ __forceinline__ void lean_sample(float x, float y, float a, bool alive, float Hf, float Wf, float row_units, float px_units,
+                                            unsigned base0, unsigned unit_bytes, unsigned px_bytes, unsigned row_bytes_stride, unsigned oor,
+                                            unsigned (&off)[4], float (&w)[4]) {
 #pragma clang fp contract(off)
     const float h_im = __builtin_fmaf(y, Hf, -0.5f), w_im = __builtin_fmaf(x, Wf, -0.5f);
     const bool valid = alive && (h_im > -1.f) && (w_im > -1.f) && (h_im < Hf) && (w_im < Wf);
     const float hs = valid ? h_im : 0.f, ws = valid ? w_im : 0.f;   // keeps the arithmetic below finite and the conversions defined
     const float hf = floorf(hs), wf = floorf(ws);   // in [-1, H - 1] x [-1, W - 1] for a valid sample, 0 otherwise
     const float lh = hs - hf, lw = ws - wf;
-    // row / column tests and the pixel index stay in fp32 (exact: |h * W + w| < 2^23): no conversions, no integer multiply
-    // (v_mul_lo_u32 is quarter rate and the compiler reaches for it)
+    // row / column tests and the pixel index stay in fp32 (exact: |h * row_units + w * px_units| < 2^23): no conversions, no integer
+    // multiply (v_mul_lo_u32 is quarter rate and the compiler reaches for it)
     const bool r0 = valid && hf >= 0.f, r1 = valid && hf < Hf - 1.f, c0 = wf >= 0.f, c1 = wf < Wf - 1.f;
     const float wy1 = lh * a, wy0 = (1.f - lh) * a, hw = 1.f - lw;
     w[0] = wy0 * hw;
@@ -451,13 +455,13 @@ __device__ __forceinline__ void lean_sample(float x, float y, float a, bool aliv
     w[2] = wy1 * hw;
     w[3] = wy1 * lw;
     // hf may be -1 with the lower corners still inside: the index is negative then and the byte offset wraps like the 32-bit one
-    const int pix = (int)__builtin_fmaf(hf, Wf, wf);
-    const unsigned o0 = base0 + (unsigned)pix * row_bytes;
-    const unsigned o2 = o0 + w_bytes;
+    const int units = (int)__builtin_fmaf(hf, row_units, wf * px_units);
+    const unsigned o0 = base0 + (unsigned)units * unit_bytes;
+    const unsigned o2 = o0 + row_bytes_stride;
     off[0] = (r0 && c0) ? o0 : oor;
-    off[1] = (r0 && c1) ? o0 + row_bytes : oor;
+    off[1] = (r0 && c1) ? o0 + px_bytes : oor;
     off[2] = (r1 && c0) ? o2 : oor;
-    off[3] = (r1 && c1) ? o2 + row_bytes : oor;
+    off[3] = (r1 && c1) ? o2 + px_bytes : oor;
 }
 
 // MSDeformAttn's arithmetic between its linear layers and the op (ms_deform_attn.py:119-133) for the 4 points of ONE level of a
@@ -603,7 +607,7 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
             for (int i = 0; i < 4; ++i) {
                 MfmaDesc d;
                 float w4[4];
-                lean_sample(x[i], y[i], a[i], !dead, Hf, Wf, base0, row_bytes, w_bytes, kOutOfRange, d.off, w4);
+                lean_sample(x[i], y[i], a[i], !dead, Hf, Wf, Wf, 1.0f, base0, row_bytes, row_bytes, w_bytes, kOutOfRange, d.off, w4);
                 u32x2 rows[3];
                 split_weights(w4, rows);
 #pragma unroll
@@ -669,12 +673,12 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 // What bounds msda_fwd_bf16_mfma_kernel: every corner row is a 64-byte request through the texture path, whose
 // address / tag pipeline serves about one L1 line per two clocks per CU: stage 2 alone takes 0.22 ms for the 91 M rows of an
 // encoder call and the descriptor arithmetic hides behind it.  Half of those rows belong to the two coarse levels, which are
-// SMALL: levels 2 and 3 of the 1333 x 800 pyramid are 1050 + 273 pixels = 84.7 KB per (image, head) (95 KB at the 72-byte
-// pitch used below) — they fit in a CU's 160 KB of LDS.
-// So here one 11-wave workgroup per CU is pinned to a slab, copies the slab's coarse rows [res_row0, S) into LDS once (one
+// SMALL: levels 2 and 3 of the 1333 x 800 pyramid are 1050 + 273 pixels = 84.7 KB per (image, head) — they fit in a CU's 160 KB
+// of LDS.
+// So here one 12-wave workgroup per CU is pinned to a slab, copies the slab's coarse rows [res_row0, S) into LDS once (one
 // coalesced pass, 22 MB over the whole launch), and its waves then serve every sample of a resident level from LDS and only the
 // level-0 / level-1 samples through the buffer path.  The waves of a workgroup take runs of 16 consecutive queries round-robin,
-// so at any time a CU works on ~180 consecutive queries of ONE head — a band of the image about one row wide whose level-0/1
+// so at any time a CU works on ~190 consecutive queries of ONE head — a band of the image about one row wide whose level-0/1
 // footprints overlap in L1.
 //   * sample descriptors no longer travel through LDS whole: the lane that builds a sample keeps its four corner addresses in
 //     registers and the other lanes of the quad read them with DPP quad broadcasts folded into the address add (v_add_u32_dpp);
@@ -692,22 +696,23 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 //     the kernel compares it with the device copy and, should they disagree, serves every level through the buffer path: the
 //     hint steers speed, never results.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kResWaves = 11;                            // 3 + 3 + 3 + 2 waves on the CU's four SIMDs: <= 168 registers
+constexpr int kResWaves = 12;                            // 3 waves per SIMD: <= 168 registers
 constexpr int kResThreads = 64 * kResWaves;
 constexpr int kResSampleStride = 16 * 24;                // bytes between the A rows of consecutive samples (16 pairs x 24 B)
 constexpr int kResTable = 8 * 256;                       // corner addresses of up to 8 resident samples x 16 pairs x 4 corners
 constexpr int kResWaveLds = 16 * kResSampleStride;       // 6144 B per wave (the table takes over consumed A rows)
 static_assert(kResTable <= 8 * kResSampleStride, "the table must fit in the A rows of the buffer-path samples");
 constexpr int kResLdsTotal = 160 * 1024;
-constexpr int kResPitch = 72;                            // bytes between resident rows in LDS: 18 dwords, so the rows a transpose read
-                                                         // touches spread over all 64 banks (64-byte pitch: 4 bank groups, 8-way conflicts)
-constexpr int kResFixed = kResPitch /* zero row */ + 16 /* run counter */;
-constexpr int kResMaxRows = (kResLdsTotal - kResWaves * kResWaveLds - kResFixed) / kResPitch;   // 1335 rows
+constexpr int kResRowPad = 8;                            // bytes appended to every image row of a resident level (see below)
+constexpr int kResFixed = 64 /* zero row */ + 16;
+constexpr int kResMaxImage = kResLdsTotal - kResWaves * kResWaveLds - kResFixed;   // 90 032 bytes for the resident image
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 struct ResDims {
     int res_row0;       // first resident row of a slab (host copy of level_start_index[RL])
     int res_rows;       // S - res_row0
+    int h[2], w[2];     // host copy of the shapes of the resident levels RL, RL + 1 (h[1] = 0 when only one level is resident)
+    int image_bytes;    // LDS bytes of the resident image = sum over resident levels of H * (W * 64 + kResRowPad)
     int wps;            // workgroups per (image, head) slab
     int runs_per_slab;  // ceil(Lq / 16)
     int runs_per_wg;    // ceil(runs_per_slab / wps)
@@ -739,28 +744,41 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
     const int pl = lid >> 2, lane = lid & 3;   // pair slot in the wave, lane in the quad (= level in stage 1)
 
     const bf16_t* slab_base = value + ((size_t)b * dm.M + m) * dm.S * 32;
-    const unsigned zero_row = (unsigned)rd.res_rows * (unsigned)kResPitch;       // LDS byte address of the all-zero row
+    const unsigned zero_row = (unsigned)rd.image_bytes;                           // LDS byte address of the all-zero row
     unsigned char* aw = smem + zero_row + kResFixed + wave * kResWaveLds;         // this wave's A rows ...
     unsigned char* tab = aw;   // ... whose first rows, once consumed, take the table of the resident samples' corner addresses
 
-    // the host's view of the pyramid must be the device's; otherwise nothing is treated as resident (wave-uniform)
-    bool res_ok = rd.res_row0 == lstart[RL];
-#pragma unroll
-    for (int l = RL; l < 4; ++l)
-        res_ok = res_ok && lstart[l] >= rd.res_row0 && (long)lstart[l] + (long)shapes[2 * l] * shapes[2 * l + 1] <= (long)dm.S;
+    // Resident image: level l (H x W) is stored row by row at a 64-byte pixel pitch, every image row followed by kResRowPad = 8
+    // bytes.  With nothing between the rows the four corners of a sample and the samples of neighbouring queries would share four
+    // bank groups (8-way conflicts on the transpose reads: 0.285 ms); the pad moves the rows y and y + 1 two banks apart.  A 72-byte
+    // PIXEL pitch spreads a little better (16 M instead of 27 M conflict cycles per launch) but costs 10 KB more LDS, i.e. the twelfth
+    // wave; row pads of 8 / 16 / 32 bytes and the 72-byte pitch all measure 0.177-0.180 ms.
+    const unsigned rs0 = (unsigned)rd.w[0] * 64u + kResRowPad, rs1 = (unsigned)rd.w[1] * 64u + kResRowPad;
+    const unsigned lds_lvl1 = (unsigned)rd.h[0] * rs0;   // where the second resident level starts
 
-    // ---- the slab's coarse rows -> LDS (one coalesced pass), zero row, run counter ------------------------------------------
+    // the host's view of the resident levels must be the device's; otherwise nothing is treated as resident (wave-uniform)
+    bool res_ok = rd.res_row0 == lstart[RL] && shapes[2 * RL] == rd.h[0] && shapes[2 * RL + 1] == rd.w[0];
+    if (RL == 2) res_ok = res_ok && lstart[3] == rd.res_row0 + rd.h[0] * rd.w[0] && shapes[6] == rd.h[1] && shapes[7] == rd.w[1];
+    res_ok = res_ok && rd.res_row0 + rd.h[0] * rd.w[0] + rd.h[1] * rd.w[1] == dm.S;
+
+    // ---- the slab's coarse rows -> LDS (one coalesced pass), zero row ---------------------------------------------------------
     {
-        // channel-permuted image: a 16-byte granule holds channels 8 j .. 8 j + 7 of its row; channel 8 j + n goes to position 4 n + j
+        // channel-permuted image: a 16-byte granule holds channels 8 j .. 8 j + 7 of its pixel; channel 8 j + n goes to position 4 n + j
         const u32x4* src = reinterpret_cast<const u32x4*>(slab_base + (size_t)rd.res_row0 * 32);
-        const int ngran = rd.res_rows * 4;
+        const int ngran = rd.res_rows * 4, n0 = rd.h[0] * rd.w[0];
         for (int g = threadIdx.x; g < ngran; g += kResThreads) {
             const u32x4 v = src[g];
-            unsigned short* row = reinterpret_cast<unsigned short*>(smem + (unsigned)(g >> 2) * (unsigned)kResPitch) + (g & 3);
+            int r = g >> 2;
+            const bool second = r >= n0;
+            r -= second ? n0 : 0;
+            const int wl = second ? rd.w[1] : rd.w[0];
+            const int y = r / wl, x = r - y * wl;
+            const unsigned at = (second ? lds_lvl1 : 0u) + (unsigned)y * (second ? rs1 : rs0) + (unsigned)x * 64u;
+            unsigned short* px = reinterpret_cast<unsigned short*>(smem + at) + (g & 3);
 #pragma unroll
-            for (int n = 0; n < 8; ++n) row[4 * n] = (unsigned short)(v[n >> 1] >> (16 * (n & 1)));
+            for (int n = 0; n < 8; ++n) px[4 * n] = (unsigned short)(v[n >> 1] >> (16 * (n & 1)));
         }
-        if (threadIdx.x < kResPitch / 4) reinterpret_cast<unsigned*>(smem + zero_row)[threadIdx.x] = 0u;
+        if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + zero_row)[threadIdx.x] = 0u;
     }
     __syncthreads();
 
@@ -774,12 +792,14 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
     const unsigned lane_loc = 32u * m + 8u * lane, lane_attn = 16u * m + 4u * lane, lane_out = 32u * m + 8u * lane;
     const int Hl = shapes[2 * lane], Wl = shapes[2 * lane + 1];
     const bool lane_res = res_ok && lane >= RL;
-    const int start = lane_res ? lstart[lane] - rd.res_row0 : lstart[lane];
     const unsigned oor = lane_res ? zero_row : kOutOfRange;
     const float Hf = (float)Hl, Wf = (float)Wl;
     const float inv_w = 1.0f / Wf, inv_h = 1.0f / Hf;
-    const unsigned lane_pitch = lane_res ? (unsigned)kResPitch : row_bytes;   // bytes between neighbouring pixels where this lane's level lives
-    const unsigned base0 = (unsigned)start * lane_pitch, w_bytes = (unsigned)Wl * lane_pitch;
+    // addressing in units of kResRowPad bytes: a pixel is 64 / pad units, an image row W * 64 / pad units in the slab and one more in LDS
+    constexpr float kPxUnits = 64.0f / (float)kResRowPad;
+    const float row_units = lane_res ? kPxUnits * Wf + 1.0f : kPxUnits * Wf;
+    const unsigned w_bytes = (unsigned)Wl * 64u + (lane_res ? (unsigned)kResRowPad : 0u);
+    const unsigned base0 = lane_res ? (lane == RL ? 0u : lds_lvl1) : (unsigned)lstart[lane] * row_bytes;
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(slab_base, (unsigned)dm.S * row_bytes);
     const unsigned coff = (unsigned)lane * 16u;   // this lane's 8 channels of a 64-byte row
     // transpose-read roles: in its 16-lane group this lane FETCHES corner (lid >> 2) & 3 of the group's pair lid & 3
@@ -840,7 +860,7 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float w4[4];
-                lean_sample(x[i], y[i], a[i], !dead, Hf, Wf, base0, lane_pitch, w_bytes, oor, off[i], w4);
+                lean_sample(x[i], y[i], a[i], !dead, Hf, Wf, row_units, kPxUnits, base0, (unsigned)kResRowPad, row_bytes, w_bytes, oor, off[i], w4);
                 u32x2 rows[3];
                 split_weights(w4, rows);
                 u32x2* dst = reinterpret_cast<u32x2*>(aw_wr + i * kResSampleStride);
@@ -1654,10 +1674,46 @@ int validate(const void* value, const int32_t* shapes, const int32_t* lstart, co
 using namespace alo;
 
 namespace {
+// Which levels msda_fwd_bf16_resident_kernel keeps in LDS for a launch, from the HOST's copy of the shapes: 2 (levels 2 and 3),
+// 3 (level 3 alone) or 0 (none: the plain head-major kernel serves the launch).  Fills `rd` when it returns non-zero.
+int resident_plan(const int32_t* host_shapes, int N, int S, int M, int L, int Lq, ResDims* rd) {
+    if (L != 4) return 0;
+    long start[5] = {0, 0, 0, 0, 0};
+    for (int l = 0; l < 4; ++l) {
+        const long h = host_shapes[2 * l], w = host_shapes[2 * l + 1];
+        if (h <= 0 || w <= 0 || h * (w * 64 + kResRowPad) / kResRowPad >= (1L << 23)) return 0;   // offsets in pad units must stay exact in fp32
+        start[l + 1] = start[l] + h * w;
+    }
+    if (start[4] != S) return 0;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 256;
+    const long slabs = (long)N * M;
+    rd->runs_per_slab = (Lq + 15) / 16;
+    long wps = slabs >= cus ? 1 : (cus + slabs - 1) / slabs;
+    const long wps_cap = rd->runs_per_slab / (4 * kResWaves);   // >= 4 runs per wave, or the resident copy does not pay
+    if (wps > wps_cap) wps = wps_cap;
+    if (wps < 1 || slabs * wps >= 0x7fffffffL) return 0;
+    for (int rl = 2; rl < 4; ++rl) {
+        long bytes = 0;
+        for (int l = rl; l < 4; ++l) bytes += (long)host_shapes[2 * l] * (host_shapes[2 * l + 1] * 64L + kResRowPad);
+        if (bytes > kResMaxImage) continue;
+        rd->res_row0 = (int)start[rl];
+        rd->res_rows = (int)(S - start[rl]);
+        rd->h[0] = host_shapes[2 * rl]; rd->w[0] = host_shapes[2 * rl + 1];
+        rd->h[1] = rl == 2 ? host_shapes[6] : 0; rd->w[1] = rl == 2 ? host_shapes[7] : 1;
+        rd->image_bytes = (int)bytes;
+        rd->wps = (int)wps;
+        rd->runs_per_wg = (int)((rd->runs_per_slab + wps - 1) / wps);
+        return rl;
+    }
+    return 0;
+}
+
 int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
                  const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
                  int P, int value_dtype, int loc_dtype, void* stream_, bool head_major = false, long loc_row_elems = 0,
-                 long attn_row_elems = 0, const int32_t* host_level_start = nullptr) {
+                 long attn_row_elems = 0, const int32_t* host_shapes = nullptr) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
                           loc_dtype, &elem))
@@ -1685,41 +1741,23 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
         dm.runs_per_batch = (int)runs;
         dm.blocks_per_batch = (int)((runs + dm.iters_per_block - 1) / dm.iters_per_block);
         dm.nblocks = (unsigned)(dm.blocks_per_batch * N);
-        if (host_level_start && D == 32) {
+        ResDims rd;
+        const int rl = host_shapes && D == 32 ? resident_plan(host_shapes, N, S, M, L, Lq, &rd) : 0;
+        const bool offs32 = (double)Lq * dm.loc_row_elems < 4.0e9 && (double)Lq * dm.attn_row_elems < 4.0e9 &&
+                            (double)Lq * M * 32 < 4.0e9 && (double)Lq * 4 * ref_dim < 4.0e9;   // 32-bit element offsets per image
+        if (rl && offs32) {
             // coarse levels resident in LDS (msda_fwd_bf16_resident_kernel): one 12-wave workgroup per CU pinned to an (image, head) slab
-            int rl = 0;
-            for (int l = 2; l < 4 && !rl; ++l) {
-                const long r0 = host_level_start[l];
-                if (r0 > 0 && r0 < S && S - r0 <= kResMaxRows) rl = l;
-            }
-            int cus = 256, dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (cus < 1) cus = 256;
-            const long slabs = (long)N * M;
-            ResDims rd;
-            rd.runs_per_slab = (Lq + 15) / 16;
-            long wps = slabs >= cus ? 1 : (cus + slabs - 1) / slabs;
-            const long wps_cap = rd.runs_per_slab / (4 * kResWaves);   // >= 4 runs per wave, or the resident copy does not pay
-            if (wps > wps_cap) wps = wps_cap;
-            const bool offs32 = (double)Lq * dm.loc_row_elems < 4.0e9 && (double)Lq * dm.attn_row_elems < 4.0e9 &&
-                                (double)Lq * M * 32 < 4.0e9 && (double)Lq * 4 * ref_dim < 4.0e9;   // 32-bit element offsets per image
-            if (rl && wps >= 1 && slabs * wps < 0x7fffffffL && offs32) {
-                rd.res_row0 = host_level_start[rl];
-                rd.res_rows = S - rd.res_row0;
-                rd.wps = (int)wps;
-                rd.runs_per_wg = (int)((rd.runs_per_slab + wps - 1) / wps);
-                dm.nblocks = (unsigned)(slabs * wps);
-                void* rargs[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm, &rd};
-                const size_t lds = (size_t)rd.res_rows * kResPitch + kResFixed + (size_t)kResWaves * kResWaveLds;
-                static unsigned long long attr_done[2] = {0, 0};   // one bit per device
-                const void* fn = rl == 2 ? reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<2>)
-                                         : reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<3>);
-                hipError_t ea = ensure_dynamic_lds(fn, kResLdsTotal, &attr_done[rl - 2]);
-                if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(ea));
-                hipError_t el = hipLaunchKernel(fn, dim3(dm.nblocks), dim3(kResThreads), rargs, lds, stream);
-                if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(el));
-                return check_launch("alo_msda_forward_fused_hm_resident");
-            }
+            dm.nblocks = (unsigned)((long)N * M * rd.wps);
+            void* rargs[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm, &rd};
+            const size_t lds = (size_t)rd.image_bytes + kResFixed + (size_t)kResWaves * kResWaveLds;
+            static unsigned long long attr_done[2] = {0, 0};   // one bit per device
+            const void* fn = rl == 2 ? reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<2>)
+                                     : reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<3>);
+            hipError_t ea = ensure_dynamic_lds(fn, kResLdsTotal, &attr_done[rl - 2]);
+            if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(ea));
+            hipError_t el = hipLaunchKernel(fn, dim3(dm.nblocks), dim3(kResThreads), rargs, lds, stream);
+            if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(el));
+            return check_launch("alo_msda_forward_fused_hm_resident");
         }
         return launch(msda_fwd_bf16_mfma_kernel<4, true, true>, dm, kWaveLds, stream, "alo_msda_forward_fused_hm", args, 64);
     }
@@ -1792,10 +1830,10 @@ extern "C" int alo_msda_forward_fused_hm_resident(const void* value_hm, const in
                                                   const int32_t* level_start_index, const void* sampling_offsets,
                                                   const void* attn_logits, long offsets_row_elems, long logits_row_elems,
                                                   const void* reference_points, void* out, int N, int S, int M, int D, int L,
-                                                  int Lq, int P, int ref_dim, int value_dtype, const int32_t* host_level_start,
+                                                  int Lq, int P, int ref_dim, int value_dtype, const int32_t* host_spatial_shapes,
                                                   void* stream_) {
     ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_resident: reference_points is null");
-    ALO_REQUIRE(host_level_start, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_resident: host_level_start is null");
+    ALO_REQUIRE(host_spatial_shapes, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_resident: host_spatial_shapes is null");
     ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
                 "alo_msda_forward_fused_hm_resident: last dim of reference_points must be 2 or 4, got %d", ref_dim);
     ALO_REQUIRE(offsets_row_elems >= (long)M * L * P * 2 && logits_row_elems >= (long)M * L * P && offsets_row_elems % 8 == 0 &&
@@ -1804,7 +1842,12 @@ extern "C" int alo_msda_forward_fused_hm_resident(const void* value_hm, const in
                 "alo_msda_forward_fused_hm_resident: row strides must cover a query's M*L*P*2 offsets / M*L*P logits and keep 16-byte alignment");
     return forward_impl(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
                         ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true, offsets_row_elems,
-                        logits_row_elems, host_level_start);
+                        logits_row_elems, host_spatial_shapes);
+}
+
+extern "C" int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq) {
+    ResDims rd;
+    return host_spatial_shapes ? resident_plan(host_spatial_shapes, N, S, M, L, Lq, &rd) : 0;
 }
 
 namespace {

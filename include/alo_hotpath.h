@@ -124,19 +124,21 @@ int alo_msda_forward_fused_hm_rows(const void* value_hm, const int32_t* spatial_
 
 /*
  * Same as alo_msda_forward_fused_hm_rows, with the COARSE pyramid levels of every (image, head) slab kept resident in LDS (extension;
- * csrc/msda.hip: msda_fwd_bf16_resident_kernel).  `host_level_start` is a HOST copy of level_start_index (L int32 values): it only
- * decides which levels may be resident (levels 2-3 when rows [start[2], S) fit in a CU's LDS next to the waves' work areas, level 3
- * alone otherwise) and sizes the grid; the kernel compares it with the device copy and serves every level through the ordinary
- * buffer path if the two disagree, so a stale host copy costs time, never correctness.  D must be 32.  Falls back to the plain
- * head-major kernel by itself when nothing fits or the launch is too small to amortise the resident copy (few queries per CU,
- * e.g. the decoder's 300): callers may use it unconditionally.  Results agree with alo_msda_forward_fused_hm to the last fp32
- * accumulation order (same products; <= 1 bf16 ulp of the rounded output).
+ * csrc/msda.hip: msda_fwd_bf16_resident_kernel).  `host_spatial_shapes` is a HOST copy of spatial_shapes (L x 2 int32, [H, W] per
+ * level): it decides which levels may be resident (levels 2-3 when their rows fit in a CU's LDS next to the waves' work areas,
+ * level 3 alone otherwise), fixes the layout of the LDS image and sizes the grid; the kernel compares it with the device copy and
+ * serves every level through the ordinary buffer path if the two disagree, so a stale host copy costs time, never correctness.
+ * D must be 32.  Falls back to the plain head-major kernel by itself when nothing fits or the launch is too small to amortise the
+ * resident copy (few queries per CU, e.g. the decoder's 300): callers may use it unconditionally.  Results are bit-identical to
+ * alo_msda_forward_fused_hm (same products, same order of the sum).
+ * alo_msda_resident_levels reports what a launch of these dimensions would keep resident: 2, 3, or 0 (plain kernel).
  */
 int alo_msda_forward_fused_hm_resident(const void* value_hm, const int32_t* spatial_shapes, const int32_t* level_start_index,
                                        const void* sampling_offsets, const void* attn_logits, long offsets_row_elems,
                                        long logits_row_elems, const void* reference_points, void* out, int N, int S, int M, int D,
-                                       int L, int Lq, int P, int ref_dim, int value_dtype, const int32_t* host_level_start,
+                                       int L, int Lq, int P, int ref_dim, int value_dtype, const int32_t* host_spatial_shapes,
                                        void* stream);
+int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq);
 
 /*
  * value (N, S, M, D) -> out (N, M, S, D), rows of padded pixels zeroed (padding_mask (N, S) uint8/bool, nullable):

@@ -653,8 +653,9 @@ def test_resident_forward_with_nan_outside_the_sampled_footprint():
 
 
 def test_resident_forward_ignores_a_host_copy_that_disagrees_with_the_device_metadata():
-    """The host copy of the level starts picks the resident levels and sizes the grid; a WRONG one (another pyramid with the same
-    S) must only cost speed: the kernel compares it with the device copy and serves every level through the buffer path."""
+    """The host copy of the shapes picks the resident levels, lays out the LDS image and sizes the grid; a WRONG one (another
+    pyramid with the same S) must only cost speed: the kernel compares it with the device copy and serves every level through the
+    buffer path.  (The third copy is right about the resident levels and wrong about the others: that one stays resident.)"""
     import ctypes
 
     N, shapes_l = 2, [(40, 50), (20, 25), (10, 13), (5, 7)]
@@ -662,9 +663,12 @@ def test_resident_forward_ignores_a_host_copy_that_disagrees_with_the_device_met
     vhm = alo_hip.value_head_major(value, mask)
     want = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=False)
     S, Lq = vhm.shape[2], offsets.shape[1]
-    for wrong in ([0, 2000, 2400, 2600], [0, 2000, 2500, 2630], [0, 100, 200, 2664]):   # true starts: 0, 2000, 2500, 2630
+    # true shapes: (40, 50), (20, 25), (10, 13), (5, 7); every wrong copy has the same total S = 2665
+    for wrong in ([(40, 50), (20, 25), (13, 10), (5, 7)], [(40, 50), (20, 25), (10, 13), (7, 5)], [(50, 40), (25, 20), (10, 13), (5, 7)],
+                  [(40, 50), (25, 20), (5, 26), (35, 1)]):
+        assert sum(h * w for h, w in wrong) == S
         out = torch.full_like(want, float("nan"))
-        hint = (ctypes.c_int32 * 4)(*wrong)
+        hint = (ctypes.c_int32 * 8)(*[v for hw in wrong for v in hw])
         rc = alo_hip.lib().alo_msda_forward_fused_hm_resident(
             *(ctypes.c_void_p(t.data_ptr()) for t in (vhm, shapes, start, offsets, logits)), 8 * 16 * 2, 8 * 16,
             ctypes.c_void_p(ref.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, S, 8, 32, 4, Lq, 4, 2, alo_hip.ALO_BF16, hint,
