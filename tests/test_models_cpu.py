@@ -158,6 +158,26 @@ def test_detr_r50_cpu_plumbing():
     assert len(boxes) == 2 and isinstance(boxes[0], aloscene.BoundingBoxes2D) and boxes[0].shape[1] == 4
 
 
+def test_detr_r50_config0_at_its_own_size():
+    """BASELINE configs[0] as stated: alonet.detr.DetrR50 inference on ONE 640x480 aloscene.Frame through the PyTorch CPU path
+    (reference: alonet/detr/detr_r50.py:55-75): forward + inference(), output surface of the reference."""
+    from alonet.detr import DetrR50
+
+    torch.manual_seed(0)
+    model = DetrR50(num_classes=91, aux_loss=False).eval()
+    frame = aloscene.Frame(torch.rand(3, 480, 640) * 255, normalization="255").norm_resnet()
+    frames = aloscene.Frame.batch_list([frame])
+    assert tuple(frames.shape) == (1, 3, 480, 640) and not bool(frames.mask.as_tensor().any())
+    with torch.no_grad():
+        out = model(frames)
+        again = model(frames)
+    assert out["pred_logits"].shape == (1, 100, 92) and out["pred_boxes"].shape == (1, 100, 4)
+    assert torch.isfinite(out["pred_logits"]).all() and torch.equal(out["pred_logits"], again["pred_logits"])
+    assert float(out["pred_boxes"].min()) >= 0.0 and float(out["pred_boxes"].max()) <= 1.0     # sigmoid boxes, xcyc-relative
+    boxes = model.inference(out, threshold=0.0, background_class=-1)
+    assert len(boxes) == 1 and isinstance(boxes[0], aloscene.BoundingBoxes2D) and boxes[0].shape == (100, 4)
+
+
 def test_panoptic_head_blocks_match_reference(golden):
     from alonet.detr_panoptic import FPNstyleCNN, MHAttentionMap
 
