@@ -723,11 +723,6 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {   // value of lane 
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
 }
 
-#ifdef ALO_RES_TRACE
-#define ALO_T(i) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_[i] += now_ - last_; last_ = now_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define ALO_T(i)
-#endif
 template <int RL>
 __global__ void __launch_bounds__(kResThreads)
 msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* __restrict__ shapes,
@@ -838,16 +833,10 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
         }
         return in;
     };
-#ifdef ALO_RES_TRACE
-    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-    int nruns_ = 0;
-#endif
     RunIn cur = next_run();
     while (cur.run < run_hi) {   // wave-uniform
-        ALO_T(7)
         const bool dead = cur.dead;
         const unsigned qc = cur.qc;
-        ALO_T(0)
 
         // ---- stage 1: the 4 points of level `lane` of this quad's (query, head) pair --------------------------------------------
         unsigned off[4][4];
@@ -872,7 +861,6 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
         // the next run's inputs are requested NOW, into the registers stage 1 has just finished with: they travel under this run's
         // gathers (a run index past the end clamps to the image's last query: the loads stay in bounds)
         const RunIn nxt = next_run();
-        ALO_T(1)
         // A rows are exchanged inside the wave only: LDS operations of one wave execute in order, the fence keeps the compiler
         // from moving the reads below above the writes
         ALO_WAVE_LDS_ORDER();
@@ -990,19 +978,9 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
             for (int i = 0; i < 8; ++i) o[i] = (acc[i][0] + acc[i][1]) + acc[i][2];
             store_vec<bf16_t, float, 8>(out_b + (qc * (unsigned)dm.M * 32u + lane_out), o);
         }
-        ALO_T(6)
-#ifdef ALO_RES_TRACE
-        ++nruns_;
-#endif
         cur = nxt;
         ALO_WAVE_LDS_ORDER();
     }
-#ifdef ALO_RES_TRACE
-    if (lid == 0 && (blockIdx.x == 3 || blockIdx.x == 100) && wave < 2)
-        printf("blk %d wave %d runs %d | next_run %llu | stage1 %llu | issue+table %llu | resident %llu | consume0 %llu | consume1 %llu | store %llu | loop %llu (cycles per run)\n",
-               (int)blockIdx.x, wave, nruns_, tr_[0] / nruns_, tr_[1] / nruns_, tr_[2] / nruns_, tr_[3] / nruns_, tr_[4] / nruns_, tr_[5] / nruns_,
-               tr_[6] / nruns_, tr_[7] / nruns_);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
