@@ -308,6 +308,30 @@ def test_deformable_detr_r50_bf16_vs_fp32_max_abs():
     assert dl <= BF16_MODEL_LOGIT_TOL and db <= BF16_MODEL_BOX_TOL
 
 
+def test_detector_runs_the_resident_forward_and_it_changes_no_bit():
+    """DeformableDETR-R50, bf16 inference: the encoder's self-attention takes alo_msda_forward_fused_hm_resident (coarse pyramid levels
+    in LDS) — and the model's outputs are bit-identical to a run with the plain head-major kernel forced."""
+    import alo_hip
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=False, device=torch.device(DEV)).eval().to(torch.bfloat16)
+    frames = aloscene.Frame.batch_list(_frames([(512, 672), (480, 640)], seed=3)).to(DEV).to(torch.bfloat16)
+    with alo_hip.LaunchTimer() as timer, torch.no_grad():
+        out = model(frames)
+    tags = timer.summary()
+    assert any(k.startswith("msda_fwd_fused_resident") for k in tags), tags.keys()      # the encoder (Lq = S)
+    assert any(k.startswith("msda_fwd_fused/Lq=300") for k in tags), tags.keys()        # the decoder stays on the plain kernel
+    plain = alo_hip.msda_forward_fused_hm
+    alo_hip.msda_forward_fused_hm = lambda *a, **k: plain(*a, **dict(k, resident=False))
+    try:
+        with alo_hip.LaunchTimer() as timer2, torch.no_grad():
+            ref = model(frames)
+    finally:
+        alo_hip.msda_forward_fused_hm = plain
+    assert not any(k.startswith("msda_fwd_fused_resident") for k in timer2.summary())
+    assert torch.equal(out["pred_logits"], ref["pred_logits"]) and torch.equal(out["pred_boxes"], ref["pred_boxes"])
+
+
 # ---- BASELINE configs[3] / configs[4] at their per-GPU size -------------------------------------------------------------------
 def test_config4_training_step_at_per_gpu_size():
     """configs[3]: global batch 32 on 8 GPUs = 4 frames of 1333x800 per GPU, fp32: three full training steps

@@ -585,6 +585,8 @@ def test_tiled_backward_survives_a_host_hint_that_disagrees_with_the_device_shap
 
 # ---- coarse levels resident in LDS (alo_msda_forward_fused_hm_resident) ---------------------------------------------------------------
 RESIDENT_CASES = [  # (N, shapes, Lq or None = S, ref_dim)                        which route
+    (2, [(96, 128), (48, 64), (24, 32), (12, 16)], None, 2),   # a 1024 x 768 frame's pyramid: levels 2-3 = 960 rows resident
+    (1, [(150, 200), (75, 100), (38, 50), (19, 25)], 9000, 2),  # 1600 x 1200: level 2 (1900 rows) does not fit, level 3 (475) does
     (2, [(40, 50), (20, 25), (10, 13), (5, 7)], None, 2),      # levels 2-3 resident (165 rows), 3 workgroups per slab, ragged tail run
     (1, [(40, 50), (20, 25), (10, 13), (5, 7)], 1000, 4),      # free queries with box reference points
     (3, [(64, 80), (37, 37), (37, 37), (10, 10)], 2500, 2),    # levels 2-3 = 1469 rows: too many -> level 3 alone resident
