@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_PKG_ROOT, "libalo_hotpath.so")
 CSRC_DIR = os.path.join(_PKG_ROOT, "csrc")
 
 ALO_F32, ALO_F64, ALO_BF16 = 0, 1, 2
+RESIDENT_AUTO, RESIDENT_ALWAYS = 0, 1   # ALO_RESIDENT_* of include/alo_hotpath.h
 _DTYPE_CODE = {torch.float32: ALO_F32, torch.float64: ALO_F64, torch.bfloat16: ALO_BF16}
 
 _lib = None
@@ -67,9 +68,9 @@ def _declare(lib):
     lib.alo_msda_forward_fused_hm_rows.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [vp]
     lib.alo_msda_forward_fused_hm.argtypes = [vp] * 7 + [ip] * 9 + [vp]
     lib.alo_msda_forward_fused_hm_resident.restype = ip
-    lib.alo_msda_forward_fused_hm_resident.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [c.POINTER(c.c_int32), vp]
+    lib.alo_msda_forward_fused_hm_resident.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [c.POINTER(c.c_int32), ip, vp]
     lib.alo_msda_resident_levels.restype = ip
-    lib.alo_msda_resident_levels.argtypes = [c.POINTER(c.c_int32)] + [ip] * 5
+    lib.alo_msda_resident_levels.argtypes = [c.POINTER(c.c_int32)] + [ip] * 6
     lib.alo_value_head_major.restype = ip
     lib.alo_value_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
     lib.alo_bias_act_nchw.restype = ip
@@ -375,9 +376,10 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     buffer (a merged projection): only their per-query blocks have to be dense.
     ``resident`` (default): when a host copy of ``spatial_shapes`` rides on the tensor (``_alo_shapes``, set by
     DeformableTransformer) and D = 32, large launches keep the coarse pyramid levels in LDS
-    (``alo_msda_forward_fused_hm_resident``: same products, fp32 accumulation order of the levels unchanged; the library falls
-    back to the plain head-major kernel by itself for small launches).  ``resident=False`` always runs the plain kernel, whose
-    output is bit-identical to ``msda_forward_fused``."""
+    (``alo_msda_forward_fused_hm_resident``: same products, fp32 accumulation order of the levels unchanged; the library takes
+    the plain head-major kernel by itself where that one is faster — launches with less than one 16-query run per wave of the
+    chip).  ``resident="always"`` takes the resident kernel wherever it can run (ALO_RESIDENT_ALWAYS), ``resident=False`` always
+    runs the plain kernel, whose output is bit-identical to ``msda_forward_fused``."""
     if not value_hm.is_cuda:
         raise RuntimeError("Not implemented on the CPU")
     N, M, S, D = value_hm.shape
@@ -408,19 +410,21 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     if host is not None and D == 32 and len(host) == L and sum(int(h) * int(w) for h, w in host) == S:
         starts = (ctypes.c_int32 * (2 * L))(*[int(v) for hw in host for v in hw])
 
+    policy = RESIDENT_ALWAYS if resident == "always" else RESIDENT_AUTO
+
     def launch():
         if starts is not None:
             _check(lib().alo_msda_forward_fused_hm_resident(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
                                                             _ptr(sampling_offsets), _ptr(attn_logits), off_rs, log_rs,
                                                             _ptr(reference_points), _ptr(out), N, S, M, D, L, Lq, P, ref_dim,
-                                                            _DTYPE_CODE[value_hm.dtype], starts, _stream(value_hm.device)))
+                                                            _DTYPE_CODE[value_hm.dtype], starts, policy, _stream(value_hm.device)))
             return
         _check(lib().alo_msda_forward_fused_hm_rows(_ptr(value_hm), _ptr(spatial_shapes), _ptr(level_start_index),
                                                     _ptr(sampling_offsets), _ptr(attn_logits), off_rs, log_rs,
                                                     _ptr(reference_points), _ptr(out), N, S, M, D, L, Lq, P, ref_dim,
                                                     _DTYPE_CODE[value_hm.dtype], _stream(value_hm.device)))
 
-    tag = "msda_fwd_fused_resident" if starts is not None and lib().alo_msda_resident_levels(starts, N, S, M, L, Lq) else "msda_fwd_fused"
+    tag = "msda_fwd_fused_resident" if starts is not None and lib().alo_msda_resident_levels(starts, N, S, M, L, Lq, policy) else "msda_fwd_fused"
     with torch.cuda.device(value_hm.device), _timed(f"{tag}/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
         launch()
     return out

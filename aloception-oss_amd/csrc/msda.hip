@@ -692,9 +692,11 @@ msda_fwd_bf16_mfma_kernel(const bf16_t* __restrict__ value, const int32_t* __res
 //     address from a 2 KB table the sample's owner writes over the (by then consumed) A rows of the buffer-path samples.
 //   * corners outside the map aim at an all-zero LDS row (resident levels) or past the slab (buffer bounds check): no branches,
 //     and no byte outside the sampled footprint is ever read (NaN-safe like the other kernels).
-//   * RL = first resident level (2: levels 2-3, 3: level 3 only).  `res_row0` comes from the HOST's copy of the level starts;
-//     the kernel compares it with the device copy and, should they disagree, serves every level through the buffer path: the
-//     hint steers speed, never results.
+//   * RL = 2 is the first resident level.  `res_row0` comes from the HOST's copy of the level starts; the kernel compares it
+//     with the device copy and, should they disagree, serves every level through the buffer path: the hint steers speed, never
+//     results.  (A level-3-only variant for pyramids whose level 2 does not fit was built and measured 10-20 % SLOWER than the
+//     plain head-major kernel at 1600 x 1200 — a quarter of the samples does not pay for the 12-wave / 168-register shape — and
+//     was removed; such launches take the plain kernel.)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kResWaves = 12;                            // 3 waves per SIMD: <= 168 registers
 constexpr int kResThreads = 64 * kResWaves;
@@ -709,9 +711,9 @@ constexpr int kResMaxImage = kResLdsTotal - kResWaves * kResWaveLds - kResFixed;
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 struct ResDims {
-    int res_row0;       // first resident row of a slab (host copy of level_start_index[RL])
+    int res_row0;       // first resident row of a slab (host copy of level_start_index[2])
     int res_rows;       // S - res_row0
-    int h[2], w[2];     // host copy of the shapes of the resident levels RL, RL + 1 (h[1] = 0 when only one level is resident)
+    int h[2], w[2];     // host copy of the shapes of the resident levels 2 and 3
     int image_bytes;    // LDS bytes of the resident image = sum over resident levels of H * (W * 64 + kResRowPad)
     int wps;            // workgroups per (image, head) slab
     int runs_per_slab;  // ceil(Lq / 16)
@@ -723,7 +725,6 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {   // value of lane 
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, false);
 }
 
-template <int RL>
 __global__ void __launch_bounds__(kResThreads)
 msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* __restrict__ shapes,
                               const int32_t* __restrict__ lstart, const void* __restrict__ loc_,
@@ -731,6 +732,7 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
                               const Dims dm, const ResDims rd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Ld = Loader<bf16_t, float, 8>;
+    constexpr int RL = 2;   // first resident level
 
     const unsigned lb = xcd_contiguous_block(blockIdx.x, dm.nblocks);
     const int slab = (int)(lb / (unsigned)rd.wps), part = (int)(lb % (unsigned)rd.wps);
@@ -753,7 +755,7 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
 
     // the host's view of the resident levels must be the device's; otherwise nothing is treated as resident (wave-uniform)
     bool res_ok = rd.res_row0 == lstart[RL] && shapes[2 * RL] == rd.h[0] && shapes[2 * RL + 1] == rd.w[0];
-    if (RL == 2) res_ok = res_ok && lstart[3] == rd.res_row0 + rd.h[0] * rd.w[0] && shapes[6] == rd.h[1] && shapes[7] == rd.w[1];
+    res_ok = res_ok && lstart[3] == rd.res_row0 + rd.h[0] * rd.w[0] && shapes[6] == rd.h[1] && shapes[7] == rd.w[1];
     res_ok = res_ok && rd.res_row0 + rd.h[0] * rd.w[0] + rd.h[1] * rd.w[1] == dm.S;
 
     // ---- the slab's coarse rows -> LDS (one coalesced pass), zero row ---------------------------------------------------------
@@ -929,7 +931,6 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
         };
         // Order of the sum: levels 0, 1, 2, 3, as in the other wave kernels (same products, same order: bit-identical outputs).
         if (res_ok) {   // wave-uniform
-            static_assert(RL == 2 || RL == 3, "first resident level");
             {
                 u32x4 raw[4][4];
                 ALO_RES_ISSUE(0, raw)
@@ -942,12 +943,6 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
                 ALO_RES_CONSUME(1, raw)
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (RL == 3) {
-                u32x4 raw[4][4];
-                ALO_RES_ISSUE(2, raw)
-                ALO_RES_CONSUME(2, raw)
-                __builtin_amdgcn_sched_barrier(0);
-            }
             ALO_WAVE_LDS_ORDER();
             if (lane >= RL) {
 #pragma unroll
@@ -1652,9 +1647,10 @@ int validate(const void* value, const int32_t* shapes, const int32_t* lstart, co
 using namespace alo;
 
 namespace {
-// Which levels msda_fwd_bf16_resident_kernel keeps in LDS for a launch, from the HOST's copy of the shapes: 2 (levels 2 and 3),
-// 3 (level 3 alone) or 0 (none: the plain head-major kernel serves the launch).  Fills `rd` when it returns non-zero.
-int resident_plan(const int32_t* host_shapes, int N, int S, int M, int L, int Lq, ResDims* rd) {
+// Whether msda_fwd_bf16_resident_kernel serves a launch (levels 2 and 3 of every slab resident in LDS), from the HOST's copy of the
+// shapes: returns 2 (the first resident level) or 0 (the plain head-major kernel serves the launch).  Fills `rd` when non-zero.
+// policy ALO_RESIDENT_AUTO: only where the resident kernel is the faster one; ALO_RESIDENT_ALWAYS: wherever it can run.
+int resident_plan(const int32_t* host_shapes, int N, int S, int M, int L, int Lq, int policy, ResDims* rd) {
     if (L != 4) return 0;
     long start[5] = {0, 0, 0, 0, 0};
     for (int l = 0; l < 4; ++l) {
@@ -1663,35 +1659,37 @@ int resident_plan(const int32_t* host_shapes, int N, int S, int M, int L, int Lq
         start[l + 1] = start[l] + h * w;
     }
     if (start[4] != S) return 0;
+    long bytes = 0;
+    for (int l = 2; l < 4; ++l) bytes += (long)host_shapes[2 * l] * (host_shapes[2 * l + 1] * 64L + kResRowPad);
+    if (bytes > kResMaxImage) return 0;
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (cus < 1) cus = 256;
     const long slabs = (long)N * M;
     rd->runs_per_slab = (Lq + 15) / 16;
+    // Measured over frame sizes 256 x 320 ... 1333 x 800 and N = 1 ... 8 (tools/exp/res_sweep.py, HIP-graph replay): the resident kernel
+    // beats the plain one as soon as every wave of the chip gets a run (>= CUs x 12 runs in the launch; 0.77-0.86 of the plain kernel's
+    // time from there on, 1.2-1.6 x below), and splitting a slab over more workgroups — down to ONE run per wave — is never slower than
+    // fewer, longer workgroups: the copy of the coarse rows is cheap next to an idle CU.
+    if (policy != ALO_RESIDENT_ALWAYS && slabs * rd->runs_per_slab < (long)cus * kResWaves) return 0;
     long wps = slabs >= cus ? 1 : (cus + slabs - 1) / slabs;
-    const long wps_cap = rd->runs_per_slab / (4 * kResWaves);   // >= 4 runs per wave, or the resident copy does not pay
+    const long wps_cap = rd->runs_per_slab / kResWaves;   // at least one run per wave
     if (wps > wps_cap) wps = wps_cap;
     if (wps < 1 || slabs * wps >= 0x7fffffffL) return 0;
-    for (int rl = 2; rl < 4; ++rl) {
-        long bytes = 0;
-        for (int l = rl; l < 4; ++l) bytes += (long)host_shapes[2 * l] * (host_shapes[2 * l + 1] * 64L + kResRowPad);
-        if (bytes > kResMaxImage) continue;
-        rd->res_row0 = (int)start[rl];
-        rd->res_rows = (int)(S - start[rl]);
-        rd->h[0] = host_shapes[2 * rl]; rd->w[0] = host_shapes[2 * rl + 1];
-        rd->h[1] = rl == 2 ? host_shapes[6] : 0; rd->w[1] = rl == 2 ? host_shapes[7] : 1;
-        rd->image_bytes = (int)bytes;
-        rd->wps = (int)wps;
-        rd->runs_per_wg = (int)((rd->runs_per_slab + wps - 1) / wps);
-        return rl;
-    }
-    return 0;
+    rd->res_row0 = (int)start[2];
+    rd->res_rows = (int)(S - start[2]);
+    rd->h[0] = host_shapes[4]; rd->w[0] = host_shapes[5];
+    rd->h[1] = host_shapes[6]; rd->w[1] = host_shapes[7];
+    rd->image_bytes = (int)bytes;
+    rd->wps = (int)wps;
+    rd->runs_per_wg = (int)((rd->runs_per_slab + wps - 1) / wps);
+    return 2;
 }
 
 int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index, const void* loc,
                  const void* attn, const void* ref, int ref_dim, void* out, int N, int S, int M, int D, int L, int Lq,
                  int P, int value_dtype, int loc_dtype, void* stream_, bool head_major = false, long loc_row_elems = 0,
-                 long attn_row_elems = 0, const int32_t* host_shapes = nullptr) {
+                 long attn_row_elems = 0, const int32_t* host_shapes = nullptr, int resident_policy = ALO_RESIDENT_AUTO) {
     size_t elem = 0;
     if (int rc = validate(value, spatial_shapes, level_start_index, loc, attn, N, S, M, D, L, Lq, P, value_dtype,
                           loc_dtype, &elem))
@@ -1720,7 +1718,7 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
         dm.blocks_per_batch = (int)((runs + dm.iters_per_block - 1) / dm.iters_per_block);
         dm.nblocks = (unsigned)(dm.blocks_per_batch * N);
         ResDims rd;
-        const int rl = host_shapes && D == 32 ? resident_plan(host_shapes, N, S, M, L, Lq, &rd) : 0;
+        const int rl = host_shapes && D == 32 ? resident_plan(host_shapes, N, S, M, L, Lq, resident_policy, &rd) : 0;
         const bool offs32 = (double)Lq * dm.loc_row_elems < 4.0e9 && (double)Lq * dm.attn_row_elems < 4.0e9 &&
                             (double)Lq * M * 32 < 4.0e9 && (double)Lq * 4 * ref_dim < 4.0e9;   // 32-bit element offsets per image
         if (rl && offs32) {
@@ -1728,10 +1726,9 @@ int forward_impl(const void* value, const int32_t* spatial_shapes, const int32_t
             dm.nblocks = (unsigned)((long)N * M * rd.wps);
             void* rargs[] = {&value, &spatial_shapes, &level_start_index, &loc, &attn, &ref, &out, &dm, &rd};
             const size_t lds = (size_t)rd.image_bytes + kResFixed + (size_t)kResWaves * kResWaveLds;
-            static unsigned long long attr_done[2] = {0, 0};   // one bit per device
-            const void* fn = rl == 2 ? reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<2>)
-                                     : reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel<3>);
-            hipError_t ea = ensure_dynamic_lds(fn, kResLdsTotal, &attr_done[rl - 2]);
+            static unsigned long long attr_done = 0;   // one bit per device
+            const void* fn = reinterpret_cast<const void*>(msda_fwd_bf16_resident_kernel);
+            hipError_t ea = ensure_dynamic_lds(fn, kResLdsTotal, &attr_done);
             if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(ea));
             hipError_t el = hipLaunchKernel(fn, dim3(dm.nblocks), dim3(kResThreads), rargs, lds, stream);
             if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hm_resident: %s", hipGetErrorString(el));
@@ -1809,9 +1806,11 @@ extern "C" int alo_msda_forward_fused_hm_resident(const void* value_hm, const in
                                                   const void* attn_logits, long offsets_row_elems, long logits_row_elems,
                                                   const void* reference_points, void* out, int N, int S, int M, int D, int L,
                                                   int Lq, int P, int ref_dim, int value_dtype, const int32_t* host_spatial_shapes,
-                                                  void* stream_) {
+                                                  int policy, void* stream_) {
     ALO_REQUIRE(reference_points, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_resident: reference_points is null");
     ALO_REQUIRE(host_spatial_shapes, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hm_resident: host_spatial_shapes is null");
+    ALO_REQUIRE(policy == ALO_RESIDENT_AUTO || policy == ALO_RESIDENT_ALWAYS, ALO_ERR_INVALID_ARGUMENT,
+                "alo_msda_forward_fused_hm_resident: policy must be ALO_RESIDENT_AUTO or ALO_RESIDENT_ALWAYS, got %d", policy);
     ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
                 "alo_msda_forward_fused_hm_resident: last dim of reference_points must be 2 or 4, got %d", ref_dim);
     ALO_REQUIRE(offsets_row_elems >= (long)M * L * P * 2 && logits_row_elems >= (long)M * L * P && offsets_row_elems % 8 == 0 &&
@@ -1820,12 +1819,12 @@ extern "C" int alo_msda_forward_fused_hm_resident(const void* value_hm, const in
                 "alo_msda_forward_fused_hm_resident: row strides must cover a query's M*L*P*2 offsets / M*L*P logits and keep 16-byte alignment");
     return forward_impl(value_hm, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
                         ref_dim, out, N, S, M, D, L, Lq, P, value_dtype, ALO_F32, stream_, true, offsets_row_elems,
-                        logits_row_elems, host_spatial_shapes);
+                        logits_row_elems, host_spatial_shapes, policy);
 }
 
-extern "C" int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq) {
+extern "C" int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq, int policy) {
     ResDims rd;
-    return host_spatial_shapes ? resident_plan(host_spatial_shapes, N, S, M, L, Lq, &rd) : 0;
+    return host_spatial_shapes ? resident_plan(host_spatial_shapes, N, S, M, L, Lq, policy, &rd) : 0;
 }
 
 namespace {

@@ -686,7 +686,7 @@ def main():
                    "launch": "HIP graph of the forward replayed per step on the resident batch (inference() eager)" if det["graph"] else "eager",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": None if enc is None else {
-            "bound": "hbm", "kernel": "msda_fwd_bf16_resident_kernel<2> (fused prologue, head-major value, pyramid levels 2-3 resident in LDS; "
+            "bound": "hbm", "kernel": "msda_fwd_bf16_resident_kernel (fused prologue, head-major value, pyramid levels 2-3 resident in LDS; "
                                       "encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
             # the in-step HIP-event average (what rocprofv3's per-kernel average of the same run agrees with); the back-to-back figure
             # below is the kernel without the dispatch gaps either side of a launch

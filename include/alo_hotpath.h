@@ -125,20 +125,25 @@ int alo_msda_forward_fused_hm_rows(const void* value_hm, const int32_t* spatial_
 /*
  * Same as alo_msda_forward_fused_hm_rows, with the COARSE pyramid levels of every (image, head) slab kept resident in LDS (extension;
  * csrc/msda.hip: msda_fwd_bf16_resident_kernel).  `host_spatial_shapes` is a HOST copy of spatial_shapes (L x 2 int32, [H, W] per
- * level): it decides which levels may be resident (levels 2-3 when their rows fit in a CU's LDS next to the waves' work areas,
- * level 3 alone otherwise), fixes the layout of the LDS image and sizes the grid; the kernel compares it with the device copy and
- * serves every level through the ordinary buffer path if the two disagree, so a stale host copy costs time, never correctness.
- * D must be 32.  Falls back to the plain head-major kernel by itself when nothing fits or the launch is too small to amortise the
- * resident copy (few queries per CU, e.g. the decoder's 300): callers may use it unconditionally.  Results are bit-identical to
- * alo_msda_forward_fused_hm (same products, same order of the sum).
- * alo_msda_resident_levels reports what a launch of these dimensions would keep resident: 2, 3, or 0 (plain kernel).
+ * level): it decides whether levels 2-3 may be resident (their rows must fit in a CU's LDS next to the waves' work areas: about
+ * 1 400 pixels, i.e. frames up to ~1333 x 800 at strides 8-64), fixes the layout of the LDS image and sizes the grid; the kernel
+ * compares it with the device copy and serves every level through the ordinary buffer path if the two disagree, so a stale host copy
+ * costs time, never correctness.  D must be 32.
+ * `policy`: ALO_RESIDENT_AUTO takes the resident kernel only where it is the faster one — launches with at least one 16-query run
+ * per wave of the chip (N * M * ceil(Lq / 16) >= CUs * 12; measured 0.77-0.86 of the plain kernel's time above that, 1.2-1.6 x
+ * below) — and the plain head-major kernel otherwise (small frames, the decoder's 300 queries): callers may use it unconditionally.
+ * ALO_RESIDENT_ALWAYS takes the resident kernel wherever it can run (tests; callers that know better).  Results are bit-identical
+ * to alo_msda_forward_fused_hm either way (same products, same order of the sum).
+ * alo_msda_resident_levels reports what a launch of these dimensions would do under `policy`: 2 (levels 2-3 resident) or 0 (plain).
  */
+#define ALO_RESIDENT_AUTO 0
+#define ALO_RESIDENT_ALWAYS 1
 int alo_msda_forward_fused_hm_resident(const void* value_hm, const int32_t* spatial_shapes, const int32_t* level_start_index,
                                        const void* sampling_offsets, const void* attn_logits, long offsets_row_elems,
                                        long logits_row_elems, const void* reference_points, void* out, int N, int S, int M, int D,
                                        int L, int Lq, int P, int ref_dim, int value_dtype, const int32_t* host_spatial_shapes,
-                                       void* stream);
-int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq);
+                                       int policy, void* stream);
+int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq, int policy);
 
 /*
  * value (N, S, M, D) -> out (N, M, S, D), rows of padded pixels zeroed (padding_mask (N, S) uint8/bool, nullable):

@@ -586,10 +586,9 @@ def test_tiled_backward_survives_a_host_hint_that_disagrees_with_the_device_shap
 # ---- coarse levels resident in LDS (alo_msda_forward_fused_hm_resident) ---------------------------------------------------------------
 RESIDENT_CASES = [  # (N, shapes, Lq or None = S, ref_dim)                        which route
     (2, [(96, 128), (48, 64), (24, 32), (12, 16)], None, 2),   # a 1024 x 768 frame's pyramid: levels 2-3 = 960 rows resident
-    (1, [(150, 200), (75, 100), (38, 50), (19, 25)], 9000, 2),  # 1600 x 1200: level 2 (1900 rows) does not fit, level 3 (475) does
     (2, [(40, 50), (20, 25), (10, 13), (5, 7)], None, 2),      # levels 2-3 resident (165 rows), 3 workgroups per slab, ragged tail run
     (1, [(40, 50), (20, 25), (10, 13), (5, 7)], 1000, 4),      # free queries with box reference points
-    (3, [(64, 80), (37, 37), (37, 37), (10, 10)], 2500, 2),    # levels 2-3 = 1469 rows: too many -> level 3 alone resident
+    (3, [(64, 80), (37, 37), (35, 37), (10, 10)], 2500, 2),    # levels 2-3 = 1395 rows: just fits (90 032 bytes of LDS for the image)
     (1, [(30, 40), (15, 20), (8, 10), (4, 5)], None, 2),       # N * M = 8 slabs: many workgroups per slab
 ]
 
@@ -621,7 +620,7 @@ def test_resident_forward_is_bit_identical_to_the_plain_head_major_kernel(case):
     value, mask, offsets, logits, ref, shapes, start = _resident_case(N, shapes_l, Lq, ref_dim, 41 + N)
     vhm = alo_hip.value_head_major(value, mask)
     with alo_hip.LaunchTimer() as timer:
-        got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+        got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident="always")   # small launches too
     assert any(k.startswith("msda_fwd_fused_resident") for k in timer.summary()), timer.summary().keys()
     want = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=False)
     assert torch.equal(got, want)
@@ -641,7 +640,7 @@ def test_resident_forward_with_nan_outside_the_sampled_footprint():
     offsets.zero_()                      # every query samples exactly its reference point on every level
     ref[:] = 0.25                        # ... which lies in the interior of every level
     vhm = alo_hip.value_head_major(value, None)
-    clean = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    clean = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident="always")
     poisoned = vhm.clone()
     st = level_start(shapes_l)
     for lvl, (h, w) in enumerate(shapes_l):
@@ -650,7 +649,9 @@ def test_resident_forward_with_nan_outside_the_sampled_footprint():
         keep[y:y + 2, x:x + 2] = True
         rows = torch.nonzero(~keep.view(-1)).view(-1) + int(st[lvl])
         poisoned[:, :, rows] = float("nan")
-    got = alo_hip.msda_forward_fused_hm(poisoned, shapes, start, offsets, logits, ref)
+    with alo_hip.LaunchTimer() as timer:
+        got = alo_hip.msda_forward_fused_hm(poisoned, shapes, start, offsets, logits, ref, resident="always")
+    assert any(k.startswith("msda_fwd_fused_resident") for k in timer.summary())
     assert torch.isfinite(got.float()).all() and torch.equal(got, clean)
 
 
@@ -674,7 +675,34 @@ def test_resident_forward_ignores_a_host_copy_that_disagrees_with_the_device_met
         rc = alo_hip.lib().alo_msda_forward_fused_hm_resident(
             *(ctypes.c_void_p(t.data_ptr()) for t in (vhm, shapes, start, offsets, logits)), 8 * 16 * 2, 8 * 16,
             ctypes.c_void_p(ref.data_ptr()), ctypes.c_void_p(out.data_ptr()), N, S, 8, 32, 4, Lq, 4, 2, alo_hip.ALO_BF16, hint,
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            alo_hip.RESIDENT_ALWAYS, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, alo_hip.lib().alo_last_error()
         torch.cuda.synchronize()
         assert torch.equal(out, want), wrong
+
+
+def test_resident_policy_auto_takes_the_kernel_that_is_faster_at_the_launch_size():
+    """ALO_RESIDENT_AUTO: the resident kernel from one 16-query run per wave of the chip upwards (N * M * ceil(Lq / 16) >= CUs * 12),
+    the plain head-major kernel below (tools/exp/res_sweep.py: 1.2-1.6 x slower there), and never when levels 2-3 do not fit in LDS;
+    ALO_RESIDENT_ALWAYS wherever the levels fit.  Same bits in every case."""
+    import ctypes
+
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    small, big, huge = [(32, 40), (16, 20), (8, 10), (4, 5)], [(64, 84), (32, 42), (16, 21), (8, 11)], [(150, 200), (75, 100), (38, 50), (19, 25)]
+    for N, shapes_l, Lq, auto, always in ((1, small, None, 0, 2), (8, big, None, 2, 2), (1, huge, 6000, 0, 0)):
+        S = sum(h * w for h, w in shapes_l)
+        host = (ctypes.c_int32 * 8)(*[v for hw in shapes_l for v in hw])
+        lq = S if Lq is None else Lq
+        runs = N * 8 * ((lq + 15) // 16)
+        assert (runs >= cus * 12) == bool(auto) or shapes_l is huge
+        assert alo_hip.lib().alo_msda_resident_levels(host, N, S, 8, 4, lq, alo_hip.RESIDENT_AUTO) == auto
+        assert alo_hip.lib().alo_msda_resident_levels(host, N, S, 8, 4, lq, alo_hip.RESIDENT_ALWAYS) == always
+        value, mask, offsets, logits, ref, shapes, start = _resident_case(N, shapes_l, Lq, 2, 5)
+        vhm = alo_hip.value_head_major(value, mask)
+        outs = []
+        for mode, expect in ((True, auto), ("always", always), (False, 0)):
+            with alo_hip.LaunchTimer() as timer:
+                outs.append(alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=mode))
+            assert any(k.startswith("msda_fwd_fused_resident") for k in timer.summary()) == bool(expect), (N, shapes_l, mode)
+        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+

@@ -16,7 +16,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_
   [ -n "$c" ] && cp $c $OUT/pmc_pass_$i.csv && python $ROOT/tools/pmc_parse.py $c > $OUT/pmc_pass_$i.txt
 done
 python $ROOT/tools/pmc_parse.py --traffic-json $OUT/msda_fwd_traffic.json --kernel msda_fwd_bf16_resident_kernel --alg-bytes 324278016 \
-  --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kbench.py --which msda_fused_hm: msda_fwd_bf16_resident_kernel<2>, N=8, Lq=S=22223 (tools/profile_r3_fwd.sh, round 3)" \
+  --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kbench.py --which msda_fused_hm: msda_fwd_bf16_resident_kernel, N=8, Lq=S=22223 (tools/profile_r3_fwd.sh, round 3)" \
   $OUT/pmc_pass_1.csv $OUT/pmc_pass_2.csv
 cat $OUT/pmc_pass_*.txt | grep -v "^value_head" | head -80
 head -12 $OUT/r03_detr_kernel_stats.csv
