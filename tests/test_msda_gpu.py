@@ -508,6 +508,59 @@ def test_tiled_backward_on_encoder_like_locations(spread):
     assert ok.mean() > 0.98 and np.abs((gl - rgl) * ok).max() <= 1e-4 * max(1.0, np.abs(rgl).max())
 
 
+def _touched_pixels(loc, shapes_l):
+    """(N, S) bool: the pixels some valid sample's in-range corner lands on (cuh:285-291 validity, :38-78 corner guards), any head."""
+    N, Lq = loc.shape[:2]
+    st = level_start(np.asarray(shapes_l, np.int32))
+    S = sum(h * w for h, w in shapes_l)
+    hit = np.zeros((N, S), bool)
+    for lvl, (h, w) in enumerate(shapes_l):
+        x = loc[:, :, :, lvl, :, 0].astype(np.float32) * np.float32(w) - np.float32(0.5)
+        y = loc[:, :, :, lvl, :, 1].astype(np.float32) * np.float32(h) - np.float32(0.5)
+        valid = (y > -1) & (x > -1) & (y < h) & (x < w)
+        x0, y0 = np.floor(x).astype(np.int64), np.floor(y).astype(np.int64)
+        n_idx = np.broadcast_to(np.arange(N)[:, None, None, None], x.shape)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                yy, xx = y0 + dy, x0 + dx
+                ok = valid & (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+                hit[n_idx[ok], int(st[lvl]) + yy[ok] * w + xx[ok]] = True
+    return hit
+
+
+def test_tiled_backward_with_nan_outside_the_sampled_footprint():
+    """The window-dense backward reads every value row of a tile's bounding box, touched or not (they go straight into the matrix
+    operand); a row no sample touches must still not reach any gradient — the reference's guarded loads never see it.  NaN in
+    every untouched pixel (inside the windows too): grad_sampling_loc / grad_attn_weight bit-equal to the clean run, grad_value
+    equal up to the order of the atomic sums and exactly zero on the untouched pixels."""
+    shapes_l = [(21, 30), (11, 15), (6, 8), (3, 4)]
+    rng = np.random.default_rng(9)
+    N, M = 2, 8
+    loc = _encoder_like_loc(N, shapes_l, rng, spread_px=3.0)
+    # snap every sample into the cell between pixels 3k and 3k + 1 (both axes): columns / rows 3k + 2 are never a corner, so 5 of 9
+    # pixels stay untouched although they lie inside the tiles' windows
+    for lvl, (h, w) in enumerate(shapes_l):
+        for axis, size in ((0, w), (1, h)):
+            px = loc[:, :, :, lvl, :, axis].astype(np.float64) * size - 0.5
+            px = 3.0 * np.floor(px / 3.0) + 0.25 + 0.5 * rng.random(px.shape)
+            loc[:, :, :, lvl, :, axis] = ((px + 0.5) / size).astype(np.float32)
+    S = loc.shape[1]
+    value = rng.standard_normal((N, S, M, 32)).astype(np.float32)
+    attn = rng.random((N, S, M, 4, 4)).astype(np.float32)
+    go = rng.standard_normal((N, S, M * 32)).astype(np.float32)
+    shapes = np.asarray(shapes_l, np.int32)
+    c = dict(value=value, shapes=shapes, level_start=level_start(shapes), loc=loc, attn=attn, grad_out=go)
+    gv, gl, ga = (x.cpu().numpy() for x in hip_backward(c, torch.float32))
+    hit = _touched_pixels(loc, shapes_l)
+    assert 0.05 < hit.mean() < 0.9
+    poisoned = value.copy()
+    poisoned[~hit] = np.nan
+    pv, pl, pa = (x.cpu().numpy() for x in hip_backward(dict(c, value=poisoned), torch.float32))
+    assert np.isfinite(pv).all() and np.isfinite(pl).all() and np.isfinite(pa).all()
+    assert np.array_equal(pl, gl) and np.array_equal(pa, ga)
+    assert np.abs(pv - gv).max() <= 1e-5 * max(1.0, np.abs(gv).max()) and np.all(pv[~hit] == 0)
+
+
 def test_backward_is_linear_in_grad_out_at_batch4():
     """Config-4 per-GPU batch (N = 4): grad(2 g1 + g2) == 2 grad(g1) + grad(g2) on all three gradients."""
     rng = np.random.default_rng(22)
