@@ -280,7 +280,21 @@ class DeformableDETR(nn.Module):
                 out[f"bb_lvl{lvl}_src_outputs"] = src
                 out[f"bb_lvl{lvl}_mask_outputs"] = mask
                 out[f"bb_lvl{lvl}_pos_outputs"] = pos[lvl]
+        if not torch.is_grad_enabled() and out["pred_logits"].is_cuda:
+            # inference(): scores, labels and boxes of the last level in ONE fp32 tensor, made while the forward's launches are still
+            # in flight (inside the HIP graph when the forward is replayed) — inference() then needs a single device-to-host copy
+            # instead of six small launches and four copies behind the forward (0.24 -> 0.1 ms of an 9.2 ms step)
+            out["_alo_detections"] = self._pack_detections(out["pred_logits"], out["pred_boxes"], self.activation_fn)
         return out
+
+    @staticmethod
+    def _pack_detections(logits, boxes, activation_fn):
+        """-> (packed (B, Q, 6) fp32 = [score, label, cx, cy, w, h], logits, boxes, their version counters): exactly the values
+        inference() derives (reference deformable_detr.py:508-530: softmax / sigmoid, max over the classes)."""
+        probs = F.softmax(logits.float(), -1) if activation_fn == "softmax" else logits.float().sigmoid()
+        scores, labels = probs.max(-1)
+        packed = torch.cat([scores.unsqueeze(-1), labels.unsqueeze(-1).to(torch.float32), boxes.float()], -1)
+        return packed, logits, boxes, logits._version, boxes._version, activation_fn
 
     # ---- post-processing ----------------------------------------------------------------------------------------------
     def get_outs_labels(self, m_outputs=None, activation_fn=None):
@@ -316,6 +330,22 @@ class DeformableDETR(nn.Module):
         """Forward outputs -> one ``aloscene.BoundingBoxes2D`` (relative xcyc, with ``Labels`` + scores) per image."""
         logits, boxes_all = forward_out["pred_logits"], forward_out["pred_boxes"]
         activation_fn = forward_out.get("activation_fn") or self.activation_fn
+        ready = forward_out.get("_alo_detections")
+        if (ready is not None and ready[1] is logits and ready[2] is boxes_all and ready[3] == logits._version
+                and ready[4] == boxes_all._version and ready[5] == activation_fn):
+            # the forward already packed (score, label, box) of THESE tensors (same objects, untouched since): one copy to the host,
+            # one selection for the whole batch, then views per image
+            host = ready[0].cpu()
+            if filters is None:
+                filters = self.get_outs_filter(outs_scores=host[..., 0], outs_labels=host[..., 1].long(), threshold=threshold,
+                                               activation_fn=activation_fn, **kwargs)
+            keep_all = (filters if torch.is_tensor(filters) else torch.stack(list(filters))).cpu()   # host already unless the caller's
+            counts = keep_all.sum(1).tolist()
+            sel = host[keep_all]                                                                        # (kept, 6)
+            scores, labels, boxes = sel[:, 0].contiguous(), sel[:, 1].contiguous(), sel[:, 2:].contiguous()
+            return [aloscene.BoundingBoxes2D(b, boxes_format="xcyc", absolute=False, names=("N", None),
+                                             labels=aloscene.Labels(lab, encoding="id", scores=sc, names=("N",)))
+                    for sc, lab, b in zip(scores.split(counts), labels.split(counts), boxes.split(counts))]
         probs = F.softmax(logits.float(), -1) if activation_fn == "softmax" else logits.float().sigmoid()
         scores_all, labels_all = probs.max(-1)
         if filters is None:

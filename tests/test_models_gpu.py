@@ -78,6 +78,46 @@ def test_deformable_detr_r50_end_to_end_hip_vs_torch_branch():
     assert torch.allclose(out_list["pred_boxes"], out["pred_boxes"], atol=1e-5)
 
 
+def _same_detections(a, b):
+    return len(a) == len(b) and all(torch.equal(x.as_tensor(), y.as_tensor()) and torch.equal(x.labels.as_tensor(), y.labels.as_tensor())
+                                    and torch.equal(x.labels.scores, y.labels.scores) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inference_from_the_packed_detections_equals_the_step_by_step_path(dtype):
+    """The forward leaves (score, label, box) of its last level packed in one fp32 tensor (`_alo_detections`) so that inference()
+    needs one device-to-host copy; the products must be those of the reference's chain (softmax / sigmoid, max, threshold,
+    deformable_detr.py:508-555) on `pred_logits` / `pred_boxes` — and a caller who edits those tensors gets the chain, not the pack."""
+    torch.manual_seed(1)
+    model = DeformableDetrR50(num_classes=91, aux_loss=False, device=torch.device(DEV)).eval().to(dtype)
+    frames = aloscene.Frame.batch_list(_frames([(192, 256), (160, 224)], seed=2)).to(DEV).to(dtype)
+    with torch.no_grad():
+        out = model(frames)
+    assert "_alo_detections" in out
+    plain = {k: v for k, v in out.items() if k != "_alo_detections"}
+    for kwargs in ({}, {"threshold": 0.0}, {"threshold": 0.05}):
+        fast, slow = model.inference(out, **kwargs), model.inference(plain, **kwargs)
+        assert _same_detections(fast, slow), kwargs
+    assert sum(len(b) for b in model.inference(out, threshold=0.0)) == 600
+    keep = [torch.arange(300, device=DEV) % 7 == i for i in range(2)]          # caller-made filters, on the device
+    assert _same_detections(model.inference(out, filters=keep), model.inference(plain, filters=keep))
+    # the same through a HIP graph: the pack is part of the replayed forward
+    from alonet.common import GraphedForward
+    graphed = GraphedForward(model)
+    g_out = graphed(frames)
+    assert "_alo_detections" in g_out
+    assert _same_detections(model.inference(g_out, threshold=0.05),
+                            model.inference({k: v for k, v in g_out.items() if k != "_alo_detections"}, threshold=0.05))
+    g_out = graphed(frames)   # a replay refills the same buffers, the pack included
+    assert _same_detections(model.inference(g_out), model.inference({k: v for k, v in g_out.items() if k != "_alo_detections"}))
+    # edited logits (in place, or another tensor under the same key): the pack no longer describes them
+    edited = dict(out)
+    edited["pred_logits"] = out["pred_logits"] + 3.0
+    assert _same_detections(model.inference(edited), model.inference({k: v for k, v in edited.items() if k != "_alo_detections"}))
+    out["pred_logits"].add_(3.0)
+    assert _same_detections(model.inference(out), model.inference(edited))
+
+
 def test_deformable_detr_r50_bf16_runs_and_tracks_fp32():
     torch.manual_seed(0)
     model = DeformableDetrR50(num_classes=91, aux_loss=False, device=torch.device(DEV)).eval()
