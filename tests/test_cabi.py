@@ -85,3 +85,32 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(alo_hip, "LIB_PATH", str(tmp_path / "libalo_hotpath.so"))
     with pytest.raises(alo_hip.HotpathUnavailable, match="no CPU fallback"):
         alo_hip.lib()
+
+
+def test_resident_forward_plan_is_host_logic():
+    """alo_msda_resident_levels: which launches the LDS-resident forward serves (csrc/msda.hip resident_plan; 256 CUs assumed when no
+    device answers).  AUTO = at least one 16-query run per wave of the chip and levels 2-3 within the LDS image; ALWAYS = they fit."""
+    lib = alo_hip.lib()
+
+    def plan(shapes, N, Lq, policy):
+        host = (ctypes.c_int32 * 8)(*[v for hw in shapes for v in hw])
+        S = sum(h * w for h, w in shapes)
+        return lib.alo_msda_resident_levels(host, N, S, 8, 4, S if Lq is None else Lq, policy)
+
+    detr = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    assert plan(detr, 8, None, alo_hip.RESIDENT_AUTO) == 2 and plan(detr, 1, None, alo_hip.RESIDENT_AUTO) == 2
+    assert plan(detr, 8, 300, alo_hip.RESIDENT_AUTO) == 0           # the decoder's 300 queries: 64 x 19 runs < 256 x 12
+    assert plan(detr, 8, 300, alo_hip.RESIDENT_ALWAYS) == 2          # ... possible all the same (19 runs per slab >= 12 waves)
+    assert plan(detr, 8, 100, alo_hip.RESIDENT_ALWAYS) == 0          # 7 runs per slab: not even one per wave
+    small = [(32, 40), (16, 20), (8, 10), (4, 5)]
+    assert plan(small, 1, None, alo_hip.RESIDENT_AUTO) == 0 and plan(small, 1, None, alo_hip.RESIDENT_ALWAYS) == 2
+    assert plan(small, 4, None, alo_hip.RESIDENT_AUTO) == 2          # 32 x 107 = 3424 runs >= 3072
+    big = [(150, 200), (75, 100), (38, 50), (19, 25)]                # level 2 alone is 1900 pixels: does not fit
+    assert plan(big, 8, None, alo_hip.RESIDENT_AUTO) == 0 and plan(big, 8, None, alo_hip.RESIDENT_ALWAYS) == 0
+    assert plan([(64, 80), (37, 37), (35, 37), (10, 10)], 3, 2500, alo_hip.RESIDENT_ALWAYS) == 2   # 89 640 of 90 032 bytes
+    assert plan([(64, 80), (37, 37), (36, 37), (10, 10)], 3, 2500, alo_hip.RESIDENT_ALWAYS) == 0   # 92 016 bytes
+    # a host copy whose pixel count is not S, or another level count: nothing resident
+    host = (ctypes.c_int32 * 8)(*[v for hw in detr for v in hw])
+    assert lib.alo_msda_resident_levels(host, 8, 22222, 8, 4, 22222, alo_hip.RESIDENT_ALWAYS) == 0
+    assert lib.alo_msda_resident_levels(host, 8, 22223, 8, 3, 22223, alo_hip.RESIDENT_ALWAYS) == 0
+    assert lib.alo_msda_resident_levels(None, 8, 22223, 8, 4, 22223, alo_hip.RESIDENT_ALWAYS) == 0
