@@ -30,7 +30,8 @@ def dev(a, dtype=None):
 
 
 def random_pyramid(rng):
-    h, w = int(rng.integers(6, 70)), int(rng.integers(6, 90))
+    big = rng.random() < 0.08   # now and then a pyramid of detection size (windows spanning several passes, AUTO-resident launches)
+    h, w = (int(rng.integers(70, 130)), int(rng.integers(90, 180))) if big else (int(rng.integers(6, 70)), int(rng.integers(6, 90)))
     out = []
     for _ in range(4):
         out.append((h, w))
@@ -82,6 +83,8 @@ def run_case(c):
     res = alo_hip.msda_forward_fused_hm(vhm, shapes, start, ob, lb, ref, resident="always")
     if not torch.equal(plain, res):
         return "resident != plain"
+    if not torch.equal(plain, alo_hip.msda_forward_fused_hm(vhm, shapes, start, ob, lb, ref)):
+        return "resident (auto) != plain"
     attn = torch.softmax(lb.float(), -1).view(N, Lq, 8, 4, 4)
     normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1).float()
     loc = ref[:, :, None, :, None, :] + ob.float() / normalizer[None, None, None, :, None, :]
