@@ -280,21 +280,35 @@ class DeformableDETR(nn.Module):
                 out[f"bb_lvl{lvl}_src_outputs"] = src
                 out[f"bb_lvl{lvl}_mask_outputs"] = mask
                 out[f"bb_lvl{lvl}_pos_outputs"] = pos[lvl]
-        if not torch.is_grad_enabled() and out["pred_logits"].is_cuda:
+        if not torch.is_grad_enabled() and out["pred_logits"].is_cuda and not out["pred_logits"].is_inference():
             # inference(): scores, labels and boxes of the last level in ONE fp32 tensor, made while the forward's launches are still
             # in flight (inside the HIP graph when the forward is replayed) — inference() then needs a single device-to-host copy
-            # instead of six small launches and four copies behind the forward (0.24 -> 0.1 ms of an 9.2 ms step)
-            out["_alo_detections"] = self._pack_detections(out["pred_logits"], out["pred_boxes"], self.activation_fn)
+            # instead of six small launches and four copies behind the forward (0.24 -> 0.1 ms of an 9.2 ms step).  The pack rides
+            # on the ``pred_logits`` tensor OBJECT: the output dictionary has exactly the reference's keys.  (Inference tensors —
+            # ``torch.inference_mode()`` — carry no version counter to tie the pack to; they take inference()'s step-by-step chain.)
+            self._pack_detections(out["pred_logits"], out["pred_boxes"], self.activation_fn)
         return out
 
     @staticmethod
     def _pack_detections(logits, boxes, activation_fn):
-        """-> (packed (B, Q, 6) fp32 = [score, label, cx, cy, w, h], logits, boxes, their version counters): exactly the values
-        inference() derives (reference deformable_detr.py:508-530: softmax / sigmoid, max over the classes)."""
+        """Attach ``logits._alo_detections = (packed (B, Q, 6) fp32 = [score, label, cx, cy, w, h], boxes, version counters of both,
+        activation)``: exactly the values inference() derives (reference deformable_detr.py:508-530: softmax / sigmoid, max over
+        the classes)."""
         probs = F.softmax(logits.float(), -1) if activation_fn == "softmax" else logits.float().sigmoid()
         scores, labels = probs.max(-1)
         packed = torch.cat([scores.unsqueeze(-1), labels.unsqueeze(-1).to(torch.float32), boxes.float()], -1)
-        return packed, logits, boxes, logits._version, boxes._version, activation_fn
+        logits._alo_detections = (packed, boxes, logits._version, boxes._version, activation_fn)
+
+    @staticmethod
+    def _packed_detections(logits, boxes, activation_fn):
+        """The pack the forward left on ``logits`` if it still describes THESE tensors (same objects, untouched since), else None."""
+        ready = getattr(logits, "_alo_detections", None)
+        if ready is None or logits.is_inference() or boxes.is_inference():
+            return None
+        packed, of_boxes, v_logits, v_boxes, of_activation = ready
+        if of_boxes is boxes and v_logits == logits._version and v_boxes == boxes._version and of_activation == activation_fn:
+            return packed
+        return None
 
     # ---- post-processing ----------------------------------------------------------------------------------------------
     def get_outs_labels(self, m_outputs=None, activation_fn=None):
@@ -330,12 +344,11 @@ class DeformableDETR(nn.Module):
         """Forward outputs -> one ``aloscene.BoundingBoxes2D`` (relative xcyc, with ``Labels`` + scores) per image."""
         logits, boxes_all = forward_out["pred_logits"], forward_out["pred_boxes"]
         activation_fn = forward_out.get("activation_fn") or self.activation_fn
-        ready = forward_out.get("_alo_detections")
-        if (ready is not None and ready[1] is logits and ready[2] is boxes_all and ready[3] == logits._version
-                and ready[4] == boxes_all._version and ready[5] == activation_fn):
-            # the forward already packed (score, label, box) of THESE tensors (same objects, untouched since): one copy to the host,
-            # one selection for the whole batch, then views per image
-            host = ready[0].cpu()
+        packed = self._packed_detections(logits, boxes_all, activation_fn)
+        if packed is not None:
+            # the forward already packed (score, label, box) of THESE tensors: one copy to the host, one selection for the whole
+            # batch, then views per image
+            host = packed.cpu()
             if filters is None:
                 filters = self.get_outs_filter(outs_scores=host[..., 0], outs_labels=host[..., 1].long(), threshold=threshold,
                                                activation_fn=activation_fn, **kwargs)

@@ -37,6 +37,20 @@ class Frame(SpatialAugmentedTensor):
         std = torch.tensor(mean_std[1], device=self.device, dtype=torch.float32).view(shape)
         return mean, std
 
+    def _pad_fill(self, shape):
+        """Padding of ``batch_list`` / ``pad`` (reference frame.py:555-600): a BLACK pixel in the frame's own normalisation —
+        0 for "01" / "255", -1 for "minmax_sym", ``(0 - mean) / std`` for a mean/std state such as "resnet"."""
+        fill = torch.zeros(shape, dtype=self.dtype, device=self.device)
+        if self.normalization == "minmax_sym":
+            return fill - 1
+        if self.normalization not in ("01", "255") and self.mean_std is not None:
+            view = [1] * len(shape)
+            view[self.names.index("C") + (len(shape) - self.dim())] = 3
+            mean = torch.tensor(self.mean_std[0], device=self.device).view(view)
+            std = torch.tensor(self.mean_std[1], device=self.device).view(view)
+            return (fill - mean) / std
+        return fill
+
     def _restate(self, data, normalization, mean_std=None):
         out = data.as_subclass(Frame)._inherit(self)
         out._props["normalization"] = normalization

@@ -142,6 +142,10 @@ class SpatialAugmentedTensor(AugmentedTensor):
     def append_mask(self, mask):
         self._children["mask"] = mask
 
+    def _pad_fill(self, shape):
+        """A plain tensor of ``shape`` holding what padding this tensor writes (zeros here; ``Frame`` overrides it)."""
+        return torch.zeros(shape, dtype=self.dtype, device=self.device)
+
     def batch(self, dim=0):
         """Add a leading "B" dimension (no-op when the tensor already has one)."""
         if "B" in self.names:
@@ -156,10 +160,12 @@ class SpatialAugmentedTensor(AugmentedTensor):
 
     @staticmethod
     def batch_list(tensors):
-        """Stack spatial tensors of possibly different sizes into one zero-padded batch.
+        """Stack spatial tensors of possibly different sizes into one padded batch.
 
-        The result has size (max H, max W) and a ``mask`` child (a ``Mask`` with a single channel) holding 1 on the
-        padded area and 0 on real pixels — reference: spatial_augmented_tensor.py:322-419.
+        The result has size (max H, max W) and a ``mask`` child (a ``Mask`` with a single channel, float32) holding 1 on the
+        padded area and 0 on real pixels — reference: spatial_augmented_tensor.py:322-419.  The padding carries the value
+        the tensor's own ``pad`` would write (``_pad_fill``): 0 for plain tensors, and for a ``Frame`` the value of a black
+        pixel in its normalisation (frame.py:555-600; pinned on the reference's Frame by G16).
         """
         from .mask import Mask
 
@@ -175,7 +181,7 @@ class SpatialAugmentedTensor(AugmentedTensor):
         shape[0], shape[ih], shape[iw] = len(batched), max_h, max_w
         mshape = list(shape)
         mshape[ic] = 1
-        data = torch.zeros(shape, dtype=first.dtype, device=first.device)
+        data = first._pad_fill(shape)
         mask = torch.ones(mshape, dtype=torch.float32, device=first.device)
         for b, t in enumerate(batched):
             region = [slice(None)] * len(shape)

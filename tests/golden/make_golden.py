@@ -30,6 +30,8 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
   g13_criterion.npz      (make_golden_criterion.py) the reference's DetrCriterion / DeformableCriterion + Hungarian matchers on a
                          seeded batch: matched indices per decoder level, every loss term, totals, monitoring metrics
   g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
+  g14 / g14b / g15 / g16 (make_golden_models.py) the reference's DeformableDETR / Detr / PanopticHead forward + inference() over a
+                         stub convolution pyramid, and the real aloscene.Frame's norm_* / batch_list
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
 """
@@ -436,6 +438,12 @@ def main():
         import subprocess
 
         subprocess.check_call([sys.executable, os.path.join(OUT, "make_golden_criterion.py")])
+    models = [a for a in sys.argv[1:] if a in ("g14", "g14b", "g15", "g16")]
+    if len(sys.argv) == 1 or models:
+        # model-level fixtures (the reference's DeformableDETR / Detr / PanopticHead / Frame): own interpreter, real aloscene
+        import subprocess
+
+        subprocess.check_call([sys.executable, os.path.join(OUT, "make_golden_models.py")] + models)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total fixture bytes: {total}")
 

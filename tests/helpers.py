@@ -56,3 +56,54 @@ def formula_state_dict(state_dict, seed=0):
             val = noise * (1.0 / fan_in) ** 0.5
         out[key] = val.to(ref.dtype)
     return out
+
+
+def stub_pyramid(channels=(8, 12, 16, 24)):
+    """A seeded four-stage convolution pyramid (strides 4 / 8 / 16 / 32, ceil sizes like a ResNet's) in the role of the ResNet
+    body: ``forward(x) -> OrderedDict {"0": stride 4, ..., "3": stride 32}``.  The model-level fixtures (G14 / G15,
+    tests/golden/make_golden_models.py) put the SAME module under the reference's ``BackboneBase`` / ``Joiner`` and under this
+    repository's, so everything above the convolution stack is compared with the reference: mask resize, positional encodings,
+    projections, transformer, heads, ``inference()``."""
+    from collections import OrderedDict
+
+    import torch.nn.functional as F
+    from torch import nn
+
+    class StubPyramid(nn.Module):
+        def __init__(self):
+            super().__init__()
+            c0, c1, c2, c3 = channels
+            self.layer1 = nn.Sequential(nn.Conv2d(3, c0, 3, stride=2, padding=1), nn.ReLU(), nn.Conv2d(c0, c0, 3, stride=2, padding=1))
+            self.layer2 = nn.Conv2d(c0, c1, 3, stride=2, padding=1)
+            self.layer3 = nn.Conv2d(c1, c2, 3, stride=2, padding=1)
+            self.layer4 = nn.Conv2d(c2, c3, 3, stride=2, padding=1)
+
+        def forward(self, x):
+            out = OrderedDict()
+            for i, name in enumerate(("layer1", "layer2", "layer3", "layer4")):
+                x = F.relu(getattr(self, name)(x))
+                out[str(i)] = x
+            return out
+
+    return StubPyramid()
+
+
+def tied_formula_state_dict(model, seed=0, scale=None):
+    """``formula_state_dict`` of ``model`` where keys that alias ONE parameter (Deformable-DETR's shared detection heads:
+    ``class_embed.0 … .5`` are the same module) all carry the values of the alphabetically first alias, so the loaded weights do not depend on the
+    order in which ``load_state_dict`` walks the aliases.  ``scale``: {key suffix: factor} applied on top (G15 widens
+    ``query_embed.weight`` so that the queries of the vanilla DETR decoder do not come out as near-copies of each other)."""
+    sd = formula_state_dict(model.state_dict(), seed)
+    for suffix, factor in (scale or {}).items():
+        for key in sd:
+            if key.endswith(suffix):
+                sd[key] = sd[key] * factor
+    groups = {}
+    for key, ref in model.state_dict(keep_vars=True).items():
+        if ref.numel():
+            groups.setdefault((ref.data_ptr(), tuple(ref.shape)), []).append(key)
+    for keys in groups.values():
+        owner = min(keys)                      # independent of the order in which either implementation registers its modules
+        for key in keys:
+            sd[key] = sd[owner].clone()
+    return sd
