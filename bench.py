@@ -113,6 +113,28 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs a child process would see, WITHOUT creating a HIP context in this one: the entries of HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when one is set, else the KFD topology nodes that have SIMDs (CPU nodes have none).
+    None when neither source exists (the ranks then find out themselves)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val is not None:
+            return len([v for v in val.split(",") if v.strip() != ""])
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(nodes):
+        return None
+    count = 0
+    for node in os.listdir(nodes):
+        try:
+            with open(os.path.join(nodes, node, "properties")) as f:
+                props = dict(line.split(None, 1) for line in f if " " in line)
+            count += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            continue
+    return count
+
+
 def self_launch(a):
     """``python bench.py --gpus N`` (N > 1) outside a torch.distributed environment: spawn the N ranks ourselves — one process
     per GPU through ``torch.distributed.run`` on 127.0.0.1 (RCCL for the fences on the GPU, gloo in --selftest / --share-gpu) —
@@ -122,8 +144,11 @@ def self_launch(a):
     import socket
     import subprocess
 
-    if not a.selftest and not a.share_gpu and torch.cuda.is_available() and torch.cuda.device_count() < a.gpus:
-        raise SystemExit(f"--gpus {a.gpus}: this node exposes {torch.cuda.device_count()} device(s); one rank per GPU is needed")
+    # The parent never touches the HIP runtime: a context on GPU 0 here would outlive every step of rank 0 and sit in its memory
+    # and on its queues for the whole run.  The device count comes from the driver's sysfs topology (or the visibility variables).
+    have = visible_gpu_count()
+    if not a.selftest and not a.share_gpu and have is not None and have < a.gpus:
+        raise SystemExit(f"--gpus {a.gpus}: this node exposes {have} device(s); one rank per GPU is needed")
     with socket.socket() as sk:   # a free rendezvous port (the driver may run several benches on one host back to back)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -326,9 +351,13 @@ def micro_benchmarks(reps):
         return {"ms": round(r["ms"], 4), "alg_bytes": r["alg_bytes"], "GBps": round(r["GBps"], 1),
                 "hbm_frac": round(r["GBps"] / HBM_PEAK_GBPS, 4)}
 
-    for r in kbench.bench_msda_fused_hm(8, reps):   # the bench's own kernel (bf16, fused prologue, head-major) on ring locations
-        if r["kernel"].startswith("msda_fwd"):
-            out["msda_fwd_fused_hm[ring] bf16 N=8"] = entry(r)
+    # the bench's own kernel (bf16, fused prologue, head-major value; LDS-resident coarse levels) and the plain head-major kernel
+    # beside it, on all three distributions: the resident kernel's gain rests on ~190 consecutive queries sharing one slab's rows
+    for kind in ("ring", "survey", "uniform"):
+        for resident in (True, False):
+            r = kbench.bench_msda_fused_hm(8, reps, resident=resident, kind=kind)[1]
+            out[f"msda_fwd_fused_hm[{kind}] bf16 N=8" + ("" if resident else " plain")] = entry(r)
+        torch.cuda.empty_cache()
     for kind, tag in (("encoder", "ring"), ("survey", "survey"), ("uniform", "uniform")):
         for dt, dn in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
             out[f"msda_fwd[{tag}] {dn} N=8"] = entry(kbench.bench_msda_fwd(8, S, kind, dt, reps))
@@ -660,9 +689,10 @@ def main():
             panoptic = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             torch.cuda.empty_cache()
 
-    # ---- SURVEY 8(d) kernel micro-benchmarks (rank 0 only: they are per-kernel figures, not part of the scaling metric) --------
+    # ---- SURVEY 8(d) kernel micro-benchmarks: per-kernel figures, not part of the scaling metric — measured by the N = 1 run only
+    # (at N > 1 every other rank would sit idle, or tear its communicator down, while rank 0 runs them)
     micro = None
-    if rank == 0 and a.micro_reps > 0:
+    if world == 1 and a.micro_reps > 0:
         try:
             micro = micro_benchmarks(a.micro_reps)
         except Exception as exc:
@@ -670,12 +700,23 @@ def main():
             micro = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         torch.cuda.empty_cache()
 
+    if dist.is_initialized():
+        fence(world)   # every rank has finished every leg: the communicator is torn down together, after rank 0's line
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
         return
 
-    enc = next((v for k, v in kernels.items() if k.startswith("msda_fwd") and k.endswith("Lq=22223")), None)
+    enc_key = next((k for k in kernels if k.startswith("msda_fwd") and k.endswith("Lq=22223")), None)
+    enc = kernels.get(enc_key)
+    # which kernel the library dispatched is in the launch tag (alo_msda_resident_levels decides per launch: small launches and
+    # pyramids whose level 2 does not fit in LDS take the plain head-major kernel)
+    if enc_key and enc_key.startswith("msda_fwd_fused_resident"):
+        enc_kernel = "msda_fwd_bf16_resident_kernel (fused prologue, head-major value, pyramid levels 2-3 resident in LDS"
+    elif enc_key and enc_key.startswith("msda_fwd_fused"):
+        enc_kernel = "msda_fwd_bf16_mfma_kernel<4, fused, head-major> (fused prologue, head-major value, every level through the L1"
+    else:
+        enc_kernel = "msda_fwd_kernel<%s> (generic" % a.dtype
     line = {
         "metric": "frames/sec (whole node) DeformableDETR-R50 inference",
         "value": round(det_fps, 3), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -686,8 +727,7 @@ def main():
                    "launch": "HIP graph of the forward replayed per step on the resident batch (inference() eager)" if det["graph"] else "eager",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": None if enc is None else {
-            "bound": "hbm", "kernel": "msda_fwd_bf16_resident_kernel (fused prologue, head-major value, pyramid levels 2-3 resident in LDS; "
-                                      "encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch,
+            "bound": "hbm", "kernel": enc_kernel + "; encoder call, N=%d, Lq=S=22223, M=8, D=32, L=P=4)" % a.batch, "launch_tag": enc_key,
             # the in-step HIP-event average (what rocprofv3's per-kernel average of the same run agrees with); the back-to-back figure
             # below is the kernel without the dispatch gaps either side of a launch
             "achieved": round(enc["alg_bytes"] / (enc["ms_avg"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,

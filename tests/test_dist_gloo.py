@@ -56,3 +56,45 @@ def test_mismatched_world_size_is_refused():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(_plain_env(), WORLD_SIZE="1", RANK="0"))
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_one_and_two_rank_lines_carry_the_same_keys():
+    """A scaling curve is built from the per-N lines: N = 1 (no process group at all) and N = 2 must be the same record."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8",
+                          "--selftest"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(_plain_env(), OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    r1 = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    r2 = run_selftest(2, 29613)
+    assert set(r1) == set(r2) and r1["n_gpus"] == 1 and r2["n_gpus"] == 2
+    assert r1["unit"] == r2["unit"] and r1["scaling"] == r2["scaling"] == "weak"
+
+
+def test_device_count_is_read_without_a_hip_context(tmp_path, monkeypatch):
+    """self_launch sizes the job from the visibility variables / the KFD topology, never from torch.cuda in the parent."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3")
+    assert bench.visible_gpu_count() == 4
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    import inspect
+    assert "torch.cuda" not in inspect.getsource(bench.self_launch) and "torch.cuda" not in inspect.getsource(bench.visible_gpu_count)
+
+
+def test_scale_script_builds_the_curve_from_per_n_lines(tmp_path):
+    """tools/scale.sh --selftest: runs the launcher for N = 1, 2 and writes ONE json with per-N frames/s and efficiency vs N = 1."""
+    out_path = tmp_path / "scale.json"
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale.sh"), "--gpus", "1,2", "--out", str(out_path), "--",
+                          "--selftest", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env=dict(_plain_env(), OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-2000:] + out.stdout[-2000:]
+    rec = json.loads(out_path.read_text())
+    assert [p["n_gpus"] for p in rec["points"]] == [1, 2]
+    assert rec["points"][0]["efficiency"] == 1.0
+    # rank r sleeps 10 (r + 1) ms per step: two ranks deliver 2 x 8 frames in 20 ms against 8 in 10 ms -> efficiency ~0.5
+    assert 0.35 < rec["points"][1]["efficiency"] < 0.65

@@ -113,9 +113,11 @@ def bench_msda_fwd(N, Lq, kind, dtype, reps):
                 alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
-def fused_inputs(N, dtype, seed=0):
-    """Raw module tensors for the fused-prologue entry point, encoder-like: offsets = the init ring (+ jitter) in
-    pixels, reference points = every pixel's own centre on every level."""
+def fused_inputs(N, dtype, seed=0, kind="ring"):
+    """Raw module tensors for the fused-prologue entry point, encoder-like (reference points = every pixel's own centre on every
+    level).  ``kind`` = where the samples fall: "ring" = the module's initial offsets (head direction x 1..4 px, + sub-pixel
+    jitter: what bench.py's random-init model produces); "survey" = SURVEY 8(d)'s micro-benchmark inputs, loc = own centre +
+    U(-0.05, 0.05) of the map (+-8 x +-5 px on level 0); "uniform" = loc ~ U(0, 1) over the whole map (worst case)."""
     shapes, start, S = detr_geometry()
     gen = torch.Generator(device=DEV).manual_seed(seed)
     value = torch.randn(N, S, 8, 32, generator=gen, device=DEV).to(dtype)
@@ -129,7 +131,14 @@ def fused_inputs(N, dtype, seed=0):
     ring = ring / ring.abs().max(-1, keepdim=True)[0]
     steps = torch.arange(1, 5, device=DEV, dtype=torch.float32)
     off = (ring[:, None, None, :] * steps[None, None, :, None]).expand(8, 4, 4, 2)
-    offsets = off[None, None].expand(N, S, 8, 4, 4, 2) + (torch.rand(N, S, 8, 4, 4, 2, generator=gen, device=DEV) - 0.5)
+    if kind == "ring":
+        offsets = off[None, None].expand(N, S, 8, 4, 4, 2) + (torch.rand(N, S, 8, 4, 4, 2, generator=gen, device=DEV) - 0.5)
+    else:
+        wh = torch.tensor([[w, h] for h, w in DETR_SHAPES], device=DEV, dtype=torch.float32)[None, None, None, :, None, :]
+        span = 0.1 if kind == "survey" else 1.0
+        offsets = (torch.rand(N, S, 8, 4, 4, 2, generator=gen, device=DEV) - 0.5) * span * wh     # pixels: loc = ref + offset / (W, H)
+        if kind == "uniform":
+            ref = torch.full_like(ref, 0.5)
     logits = torch.randn(N, S, 8, 16, generator=gen, device=DEV)
     return value, shapes, start, offsets.to(dtype).contiguous(), logits.to(dtype), ref
 
@@ -144,9 +153,9 @@ def bench_msda_fused(N, dtype, reps):
                 alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
-def bench_msda_fused_hm(N, reps, resident=True):
+def bench_msda_fused_hm(N, reps, resident=True, kind="ring"):
     """Head-major path: the re-layout (+ padding mask) pass and the gather, separately."""
-    value, shapes, start, offsets, logits, ref = fused_inputs(N, torch.bfloat16)
+    value, shapes, start, offsets, logits, ref = fused_inputs(N, torch.bfloat16, kind=kind)
     S = value.shape[1]
     mask = torch.zeros(N, S, dtype=torch.bool, device=DEV)
     t0 = time_launches(lambda: alo_hip.value_head_major(value, mask), reps)
@@ -155,7 +164,7 @@ def bench_msda_fused_hm(N, reps, resident=True):
     nbytes = 2 * (N * S * 256 * 2 + N * S * 8 * 16 * 3) + ref.numel() * 4
     return [dict(kernel="value_head_major[+mask]", N=N, dtype="bfloat16", ms=t0 * 1e3, alg_bytes=4 * value.numel(),
                  GBps=4 * value.numel() / t0 / 1e9),
-            dict(kernel="msda_fwd_fused_hm[encoder]" + ("" if resident else "[plain]"), N=N, Lq=S, dtype="bfloat16", ms=t * 1e3, alg_bytes=nbytes,
+            dict(kernel=f"msda_fwd_fused_hm[{'encoder' if kind == 'ring' else kind}]" + ("" if resident else "[plain]"), N=N, Lq=S, dtype="bfloat16", ms=t * 1e3, alg_bytes=nbytes,
                  GBps=nbytes / t / 1e9)]
 
 
@@ -260,6 +269,9 @@ def main():
             res = bench_msda_fused_hm(a.N, a.reps)
         elif w == "msda_fused_hm_plain":   # the plain head-major kernel (no LDS-resident levels), for A/B
             res = bench_msda_fused_hm(a.N, a.reps, resident=False)
+        elif w in ("msda_fused_hm_survey", "msda_fused_hm_uniform"):   # the headline kernel away from the init-time ring
+            kind = w.rsplit("_", 1)[1]
+            res = bench_msda_fused_hm(a.N, a.reps, kind=kind)[1:] + bench_msda_fused_hm(a.N, a.reps, resident=False, kind=kind)[1:]
         elif w == "msda_rand":
             res = [bench_msda_fwd(a.N, S, "uniform", dt, a.reps) for dt in dts]
         elif w == "msda_dec":

@@ -1,0 +1,113 @@
+// dev micro-benchmark: the stock-library yardstick for the all-pairs correlation (round-3 verdict, missing item 6).
+// The same problem alo_corr_build solves at BASELINE configs[2] — B = 4 x [14400 x K] . [K x 14400], fp16 operands, fp32
+// accumulate, fp32 output (3.3 GB written) — handed to the system hipBLASLt (ROCm 7.2) as a strided-batched GEMM:
+//   K = 768: the three split products hi.hi + hi.lo + lo.hi as ONE contraction over the concatenated terms (what
+//            corr_gemm3_kernel executes: same matrix flops, same operand bytes, same output bytes, no pyramid epilogue);
+//   K = 256: a single fp16 product — NOT fp32-accurate, the floor any 16-bit formulation of the volume could reach.
+// Every algorithm the heuristic returns (up to 32) is timed; the best one is the yardstick.
+//   hipcc -O2 --offload-arch=gfx950 tools/micro/hipblaslt_corr.cpp -lhipblaslt -o tools/micro/hipblaslt_corr && tools/micro/hipblaslt_corr
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                                  \
+    do {                                                                                       \
+        auto e_ = (x);                                                                         \
+        if (e_ != 0) {                                                                         \
+            std::fprintf(stderr, "%s failed (%d) at line %d\n", #x, (int)e_, __LINE__);       \
+            std::exit(1);                                                                      \
+        }                                                                                      \
+    } while (0)
+
+__global__ void fill(_Float16* p, size_t n, unsigned seed) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (_Float16)(((int)(h & 0xffff) - 32768) / 16384.0f);   // ~U(-2, 2): real data, not zeros (power!)
+    }
+}
+
+static double run(hipblasLtHandle_t lt, int B, int M, int N, int K, void* A, void* Bm, void* C, void* ws, size_t ws_bytes, hipStream_t st) {
+    hipblasLtMatmulDesc_t desc;
+    hipblasLtMatrixLayout_t la, lb, lc;
+    CK(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+    CK(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)));
+    CK(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)));
+    // both feature maps are stored pixel-major with the K channels contiguous: column-major (K x pixels), leading dimension K
+    CK(hipblasLtMatrixLayoutCreate(&la, HIP_R_16F, K, M, K));
+    CK(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16F, K, N, K));
+    CK(hipblasLtMatrixLayoutCreate(&lc, HIP_R_32F, M, N, M));
+    int32_t batch = B;
+    int64_t sa = (int64_t)K * M, sb = (int64_t)K * N, sc = (int64_t)M * N;
+    for (auto [l, s] : {std::pair{la, sa}, std::pair{lb, sb}, std::pair{lc, sc}}) {
+        CK(hipblasLtMatrixLayoutSetAttribute(l, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &batch, sizeof(batch)));
+        CK(hipblasLtMatrixLayoutSetAttribute(l, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s, sizeof(s)));
+    }
+    hipblasLtMatmulPreference_t pref;
+    CK(hipblasLtMatmulPreferenceCreate(&pref));
+    CK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes)));
+    std::vector<hipblasLtMatmulHeuristicResult_t> res(32);
+    int found = 0;
+    CK(hipblasLtMatmulAlgoGetHeuristic(lt, desc, la, lb, lc, lc, pref, (int)res.size(), res.data(), &found));
+    float alpha = 1.0f / 16.0f, beta = 0.0f;   // 1 / sqrt(256): the volume's scale rides in alpha
+    double best = 1e30;
+    int best_i = -1;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < found; ++i) {
+        if (res[i].state != HIPBLAS_STATUS_SUCCESS) continue;
+        auto launch = [&]() {
+            return hipblasLtMatmul(lt, desc, &alpha, A, la, Bm, lb, &beta, C, lc, C, lc, &res[i].algo, ws, ws_bytes, st);
+        };
+        if (launch() != HIPBLAS_STATUS_SUCCESS) continue;
+        for (int w = 0; w < 6; ++w) launch();        // ~0.1 s of work for the first candidates: clocks up
+        CK(hipStreamSynchronize(st));
+        const int reps = 10;
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        std::printf("  K=%d algo %2d: %.3f ms\n", K, i, ms);
+        if (ms < best) { best = ms; best_i = i; }
+    }
+    double flops = 2.0 * B * (double)M * N * K;
+    std::printf("{\"kernel\": \"hipblaslt_corr\", \"B\": %d, \"M\": %d, \"N\": %d, \"K\": %d, \"in\": \"f16\", \"out\": \"f32\", \"algos_tried\": %d, "
+                "\"best_algo\": %d, \"ms\": %.4f, \"TFLOPs_exec\": %.1f, \"write_GBps\": %.1f}\n",
+                B, M, N, K, found, best_i, best, flops / best / 1e9, 4.0 * B * M * N / best / 1e6);
+    hipblasLtMatmulPreferenceDestroy(pref);
+    hipblasLtMatrixLayoutDestroy(la);
+    hipblasLtMatrixLayoutDestroy(lb);
+    hipblasLtMatrixLayoutDestroy(lc);
+    hipblasLtMatmulDescDestroy(desc);
+    return best;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? std::atoi(argv[1]) : 4, HW = argc > 2 ? std::atoi(argv[2]) : 14400;
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipblasLtHandle_t lt;
+    CK(hipblasLtCreate(&lt));
+    const size_t ws_bytes = 256u << 20;
+    void *A, *Bm, *C, *ws;
+    const size_t n_in = (size_t)B * HW * 768;
+    CK(hipMalloc(&A, n_in * 2));
+    CK(hipMalloc(&Bm, n_in * 2));
+    CK(hipMalloc(&C, (size_t)B * HW * HW * 4));
+    CK(hipMalloc(&ws, ws_bytes));
+    fill<<<(n_in + 255) / 256, 256, 0, st>>>((_Float16*)A, n_in, 1u);
+    fill<<<(n_in + 255) / 256, 256, 0, st>>>((_Float16*)Bm, n_in, 2u);
+    CK(hipStreamSynchronize(st));
+    run(lt, B, HW, HW, 768, A, Bm, C, ws, ws_bytes, st);
+    run(lt, B, HW, HW, 256, A, Bm, C, ws, ws_bytes, st);
+    return 0;
+}
