@@ -25,6 +25,12 @@ _DTYPE_CODE = {torch.float32: ALO_F32, torch.float64: ALO_F64, torch.bfloat16: A
 _lib = None
 
 
+def tensor_version(t):
+    """``t._version`` for the ``(version, data_ptr)`` cache keys of this package; a constant for inference tensors
+    (``torch.inference_mode()``), which carry no version counter and raise when asked for one (round-3 advisor finding)."""
+    return -1 if t.is_inference() else t._version
+
+
 class HotpathUnavailable(RuntimeError):
     """libalo_hotpath.so cannot be loaded (not built, or built for another ABI)."""
 
@@ -405,7 +411,7 @@ def msda_forward_fused_hm(value_hm, spatial_shapes, level_start_index, sampling_
     host = getattr(spatial_shapes, "_alo_shapes", None) if resident else None
     if host is None and resident:
         hit = getattr(spatial_shapes, "_alo_shapes_read", None)
-        host = hit[1] if hit is not None and hit[0] == spatial_shapes._version else None
+        host = hit[1] if hit is not None and hit[0] == tensor_version(spatial_shapes) else None
     starts = None
     if host is not None and D == 32 and len(host) == L and sum(int(h) * int(w) for h, w in host) == S:
         starts = (ctypes.c_int32 * (2 * L))(*[int(v) for hw in host for v in hw])
@@ -439,10 +445,10 @@ def _host_spatial_shapes(spatial_shapes):
     if host is not None:
         return host
     hit = getattr(spatial_shapes, "_alo_shapes_read", None)
-    if hit is not None and hit[0] == spatial_shapes._version:
+    if hit is not None and hit[0] == tensor_version(spatial_shapes):
         return hit[1]
     host = [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
-    spatial_shapes._alo_shapes_read = (spatial_shapes._version, host)
+    spatial_shapes._alo_shapes_read = (tensor_version(spatial_shapes), host)
     return host
 
 
@@ -560,7 +566,7 @@ def corr_lookup_conv1x1(levels, coords, weight, bias=None, radius=4, relu=True):
             raise RuntimeError(f"corr_pyramid[{lvl}] must be a contiguous (B*H*W,1,h,w) tensor")
     cout = weight.shape[0]
     # per-level regrouping with zero padding to a multiple of 8 entries; cached on the weight tensor per version
-    tag = (weight._version, weight.data_ptr(), L, radius)
+    tag = (tensor_version(weight), weight.data_ptr(), L, radius)
     hit = getattr(weight, "_alo_packed", None)
     if hit is None or hit[0] != tag:
         kp = lib().alo_corr_lookup_conv1x1_kpad(radius)
@@ -863,7 +869,7 @@ def ffn256_supported(x, w1, w2):
 def pack_mfma_b(weight):
     """(N, K) bf16 weight -> MFMA B-fragment order.  The packed copy rides on the weight tensor object itself, tagged
     with the version counter it was made from: packed once per weight update, gone with the tensor."""
-    tag = (weight._version, weight.data_ptr())
+    tag = (tensor_version(weight), weight.data_ptr())
     hit = getattr(weight, "_alo_packed", None)
     if hit is None or hit[0] != tag:
         w = weight.detach().contiguous()
@@ -911,7 +917,7 @@ def conv3x3(x, weight, bias=None, relu=False, stride=1):
                            "Cout % 64 == 0, stride 1 or 2, no autograd")
     n, cin, h, w_ = x.shape
     cout = weight.shape[0]
-    tag = (weight._version, weight.data_ptr())
+    tag = (tensor_version(weight), weight.data_ptr())
     hit = getattr(weight, "_alo_packed", None)
     if hit is None or hit[0] != tag:
         # (Cout, ky, kx, Cin) row-major = the channels-last memory of the weight; pack it as a (Cout, 9 Cin) matrix
@@ -945,7 +951,7 @@ def stem_conv_pool(x, weight, bias=None):
     if not stem_conv_pool_supported(x, weight):
         raise RuntimeError("stem_conv_pool: needs a bf16 CUDA (N, 3, H, W) image, a (64, 3, 7, 7) bf16 weight, no autograd")
     n, _, h, w_ = x.shape
-    tag = (weight._version, weight.data_ptr())
+    tag = (tensor_version(weight), weight.data_ptr())
     hit = getattr(weight, "_alo_packed", None)
     if hit is None or hit[0] != tag:
         # (64, 7 tap rows x 24): per tap row the 7 taps x 3 channels interleaved as the image rows are, then 3 zero columns

@@ -76,7 +76,7 @@ class MSDeformAttn(nn.Module):
     def _merged_query_projection(self):
         """[sampling_offsets; attention_weights] as one (3*M*L*P, C) weight + bias, rebuilt when either parameter changes."""
         so, aw = self.sampling_offsets, self.attention_weights
-        key = (so.weight._version, so.bias._version, aw.weight._version, aw.bias._version, so.weight.data_ptr(), aw.weight.data_ptr(),
+        key = (alo_hip.tensor_version(so.weight), alo_hip.tensor_version(so.bias), alo_hip.tensor_version(aw.weight), alo_hip.tensor_version(aw.bias), so.weight.data_ptr(), aw.weight.data_ptr(),
                so.weight.dtype, so.weight.device)
         hit = self.__dict__.get("_alo_merged")
         if hit is None or hit[0] != key:

@@ -40,7 +40,7 @@ class FrozenBatchNorm2d(nn.Module):
 def _weight_2d(weight):
     """(Cout, Cin, 1, 1) -> (Cout, Cin), the SAME view object every call: the packed copy the streaming kernels make rides on it."""
     w2 = weight.__dict__.get("_alo_2d") if hasattr(weight, "__dict__") else None
-    if w2 is None or w2._version != weight._version or w2.data_ptr() != weight.data_ptr():
+    if w2 is None or alo_hip.tensor_version(w2) != alo_hip.tensor_version(weight) or w2.data_ptr() != weight.data_ptr():
         w2 = weight.reshape(weight.shape[0], -1)
         try:
             weight._alo_2d = w2
@@ -71,8 +71,8 @@ def folded_conv_bn(conv, bn):
     """``(w', b')`` with ``bn(conv(x)) == conv'(x)``: ``w' = w * scale[:, None, None, None]`` (channels-last), ``b' = shift``.
     In eval mode the folded tensors are cached (keyed on the parameter versions); in training mode they are rebuilt every
     call so autograd still reaches ``conv.weight``."""
-    key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.dtype, bn.weight.data_ptr(), bn.weight._version,
-           bn.running_var._version, bn.running_mean._version, bn.bias._version)
+    key = (conv.weight.data_ptr(), alo_hip.tensor_version(conv.weight), conv.weight.dtype, bn.weight.data_ptr(), alo_hip.tensor_version(bn.weight),
+           alo_hip.tensor_version(bn.running_var), alo_hip.tensor_version(bn.running_mean), alo_hip.tensor_version(bn.bias))
     cached = conv.__dict__.get("_folded")
     if conv.training or torch.is_grad_enabled() and conv.weight.requires_grad or cached is None or cached[0] != key:
         scale, shift = bn.scale_shift()

@@ -48,7 +48,7 @@ class FPNstyleCNN(nn.Module):
 
     def _padded_weights(self, lay):
         w, b = lay.weight, lay.bias
-        key = (w._version, w.data_ptr(), None if b is None else b._version)
+        key = (alo_hip.tensor_version(w), w.data_ptr(), None if b is None else alo_hip.tensor_version(b))
         hit = lay.__dict__.get("_alo_padded")
         if hit is None or hit[0] != key:
             cout, cin = w.shape[:2]

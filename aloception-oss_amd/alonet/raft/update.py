@@ -28,7 +28,7 @@ def _conv_act(conv, x, relu=True):
 
 def _cached(module, name, key_tensors, build):
     """Derived inference-time tensors (merged / rescaled weights) cached on the module, keyed on parameter versions."""
-    key = tuple((t.data_ptr(), t._version) for t in key_tensors)
+    key = tuple((t.data_ptr(), alo_hip.tensor_version(t)) for t in key_tensors)
     hit = module.__dict__.get(name)
     if hit is None or hit[0] != key:
         with torch.no_grad():

@@ -291,3 +291,28 @@ def test_add_layernorm_support_gate_and_cache_invalidation():
     lin.__dict__["_alo_merged"] = ("key", None)
     alo_hip.invalidate_caches(lin)
     assert not hasattr(lin.weight, "_alo_packed") and "_alo_merged" not in lin.__dict__
+
+
+def test_cache_keys_do_not_read_version_counters_of_inference_tensors():
+    """`torch.inference_mode()` tensors raise on `_version`; every (version, data_ptr) cache key of the package goes through
+    alo_hip.tensor_version (round-3 advisor finding: DeformableDETR.forward crashed under Lightning's default predict mode)."""
+    import torch
+
+    import alo_hip
+
+    normal = torch.zeros(3)
+    assert alo_hip.tensor_version(normal) == normal._version
+    normal.add_(1)
+    assert alo_hip.tensor_version(normal) == normal._version == 1
+    with torch.inference_mode():
+        inf = torch.zeros(3)
+    assert inf.is_inference() and alo_hip.tensor_version(inf) == -1
+    import glob
+    import os
+
+    pkg = os.path.dirname(os.path.dirname(alo_hip.__file__))
+    for path in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        src = open(path).read().replace("else t._version", "").replace("``(tensor._version, data_ptr)``", "")
+        if path.endswith(os.path.join("deformable_detr", "deformable_detr.py")):
+            continue   # its two reads are guarded by is_inference() (the packed detections)
+        assert "._version" not in src, path
