@@ -209,6 +209,21 @@ class LaunchTimer:
         torch.cuda.synchronize()
         return start.elapsed_time(stop) / reps
 
+    def replay_samples(self, tag, reps=7):
+        """Durations (ms) of ``reps`` re-launches of the last launch recorded under ``tag``, each one timed by its own event
+        pair with the next already queued behind it (so a sample is the kernel sequence itself, not the dispatch gap): for
+        launches that happen once per step (the correlation build) a median and a minimum instead of a single reading."""
+        fn = self.relaunch[tag]
+        fn()
+        torch.cuda.synchronize()
+        events = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        events[0].record()
+        for i in range(reps):
+            fn()
+            events[i + 1].record()
+        torch.cuda.synchronize()
+        return [events[i].elapsed_time(events[i + 1]) for i in range(reps)]
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
@@ -515,10 +530,13 @@ def corr_build(fmap1, fmap2, num_levels=4):
     ws = torch.empty((max(nbytes, 4) // 4,), dtype=torch.float32, device=fmap1.device)
     ptrs = (ctypes.c_void_p * num_levels)(*[t.data_ptr() for t in levels])
     ncols = sum(h * w for h, w in shapes)
-    with torch.cuda.device(fmap1.device), _timed("corr_build", 4.0 * (2 * B * C * H * W + B * H * W * ncols),
-                                                 2.0 * B * (H * W) * (H * W) * C):
+    def launch():   # keeps fmaps, levels and workspace alive for LaunchTimer.replay_samples
         _check(lib().alo_corr_build(_ptr(fmap1), _ptr(fmap2), ptrs, _ptr(ws), nbytes, B, C, H, W, num_levels,
                                     _stream(fmap1.device)))
+
+    with torch.cuda.device(fmap1.device), _timed("corr_build", 4.0 * (2 * B * C * H * W + B * H * W * ncols),
+                                                 2.0 * B * (H * W) * (H * W) * C, relaunch=launch if _timer else None):
+        launch()
     # ws may be released now: the caching allocator keeps the block bound to this stream until the kernels retire
     return levels
 

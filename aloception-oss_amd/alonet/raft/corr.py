@@ -122,7 +122,8 @@ class CorrBlock:
     def lookup_conv1x1(self, coords, weight, bias, relu=True):
         """``act(conv1x1(self(coords)))`` without materialising the window features (the motion encoder's ``convc1``);
         None when the fused kernel does not cover the configuration or a gradient is wanted (the caller then convolves
-        ``self(coords)``)."""
+        ``self(coords)``).  A C-ABI extra (``alo_corr_lookup_conv1x1``), NOT used by ``RAFT.forward``: measured 0.23 ms against
+        0.20 ms for lookup + convolution, so the model keeps the two-kernel form."""
         if _needs_grad(coords, weight, bias, *self.corr_pyramid):
             return None
         if not alo_hip.corr_lookup_conv1x1_supported(self.corr_pyramid, weight, self.radius):

@@ -20,33 +20,6 @@ from .update import BasicUpdateBlock
 from .utils.utils import coords_grid, upflow8
 
 
-class DeferredLookup:
-    """``corr_fn(coords)`` not yet evaluated: what RAFT hands its update block at inference when the correlation block can fuse
-    the lookup with the consumer's 1x1 convolution.  ``materialize()`` is the plain lookup."""
-
-    def __init__(self, corr_fn, coords):
-        self.corr_fn, self.coords = corr_fn, coords
-
-    def materialize(self):
-        return self.corr_fn(self.coords)
-
-    def conv1x1(self, conv, relu=True):
-        """``act(conv(lookup))`` for a 1x1 ``nn.Conv2d``; falls back to lookup + convolution when the fused kernel does not apply."""
-        out = None
-        if conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1:
-            out = self.corr_fn.lookup_conv1x1(self.coords, conv.weight, conv.bias, relu)
-        if out is None:
-            out = conv(self.materialize())
-            out = F.relu(out) if relu else out
-        return out
-
-
-def _deferred_lookup_ok(corr_fn, update_block, net):
-    return (hasattr(corr_fn, "lookup_conv1x1") and getattr(update_block, "accepts_deferred_lookup", False)
-            and net.is_cuda and net.dtype == torch.float32 and not torch.is_grad_enabled()
-            and (net.shape[-1] * net.shape[-2]) % 4 == 0)
-
-
 class RAFTBase(nn.Module):
     """Sub-classes define ``hidden_dim, context_dim, corr_levels, corr_radius, out_plane`` (class attributes)."""
 
@@ -126,12 +99,7 @@ class RAFTBase(nn.Module):
         for _ in range(iters):
             coords1 = coords1.detach()
             flow = coords1 - coords0
-            if _deferred_lookup_ok(corr_fn, self.update_block, net):
-                # inference with the HIP CorrBlock: hand the motion encoder the lookup itself, so that it can fuse it with its
-                # first 1x1 convolution (the (B, 324, H/8, W/8) window features are then never written)
-                corr = DeferredLookup(corr_fn, coords1)
-            else:
-                corr = corr_fn(coords1).to(net.dtype)
+            corr = corr_fn(coords1).to(net.dtype)
             net, up_mask, delta_flow = self.update_block(net, inp, corr, flow.to(net.dtype))
             coords1 = coords1 + delta_flow.float()
             m_outputs.append({"flow": coords1 - coords0, "hidden_state": net, "up_mask": up_mask,

@@ -136,11 +136,6 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - out_planes, 3, padding=1)
 
     def forward(self, flow, corr):
-        if hasattr(corr, "conv1x1"):   # a deferred lookup (RAFT inference on the HIP CorrBlock): lookup + convc1 + ReLU in one kernel
-            cor = _conv_act(self.convc2, corr.conv1x1(self.convc1, relu=True))
-            flo = _conv_act(self.convf2, _conv_act(self.convf1, flow))
-            out = _conv_act(self.conv, torch.cat([cor, flo], dim=1))
-            return torch.cat([out, flow], dim=1)
         if _fusable(flow, corr, self.convc1.weight):
             cor = _conv_act(self.convc2, _conv_act(self.convc1, corr))
             flo = _conv_act(self.convf2, _conv_act(self.convf1, flow))
@@ -166,13 +161,6 @@ class SmallUpdateBlock(nn.Module):
 
 
 class BasicUpdateBlock(nn.Module):
-    # The motion encoder can take RAFT's correlation lookup un-evaluated and run it fused with convc1 (raft.DeferredLookup ->
-    # alo_corr_lookup_conv1x1).  Measured on MI355X at B = 4, 90x160 (tools/lkbench.py): fused 0.25 ms against 0.20 ms for
-    # lookup (0.085) + MIOpen 1x1 convolution + bias/ReLU pass (0.12) — the 75 MB of window features written by the lookup are
-    # re-read from the 256 MB Infinity Cache, so the un-fused pair is already "fused" as far as HBM is concerned, and the
-    # per-level lookup kernel runs 4x as many independent workgroups as the fused one can.  Off until the fused kernel wins.
-    accepts_deferred_lookup = False
-
     def __init__(self, corr_levels, corr_radius, hidden_dim=128, input_dim=128, out_planes=2):
         super().__init__()
         self.encoder = BasicMotionEncoder(corr_levels, corr_radius, out_planes=out_planes)
