@@ -28,6 +28,11 @@ class GraphedForward:
         self.adopt_inputs = adopt_inputs
         self._graphs = {}
         self._epoch = 0
+        # every wrapper of this model, so that one wrapper's capture does not re-derive (free) the tensors another one's live
+        # graphs replay on
+        import weakref
+
+        model.__dict__.setdefault("_alo_graph_wrappers", weakref.WeakSet()).add(self)
 
     def reset(self):
         """Forget every captured graph (the next call captures again)."""
@@ -45,8 +50,13 @@ class GraphedForward:
         # dropping them under a live graph would leave it replaying on freed memory.  Weight surgery later on goes through
         # alo_hip.invalidate_caches(model) (load_weights calls it), which bumps the model's cache epoch: __call__ then drops
         # every graph and captures again.
-        if not self._graphs:
+        others_live = any(w._graphs and w._epoch == alo_hip.cache_epoch(self.model)
+                          for w in self.model.__dict__.get("_alo_graph_wrappers", ()) if w is not self)
+        if not self._graphs and not others_live:
             alo_hip.invalidate_caches(self.model)  # weights edited through .data since the last forward: re-derive before pinning
+        # (with another wrapper's graphs alive on the current epoch the derived tensors are kept: re-deriving them would bump the
+        # epoch, that wrapper would re-capture on its next call and invalidate this one in turn — a re-capture on every alternation)
+        if not self._graphs:
             self._epoch = alo_hip.cache_epoch(self.model)
         device = frames[0].device
         static_in = tuple(frames) if self.adopt_inputs else tuple(f.clone() for f in frames)

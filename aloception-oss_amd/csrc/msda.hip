@@ -707,7 +707,8 @@ static_assert(kResTable <= 8 * kResSampleStride, "the table must fit in the A ro
 constexpr int kResLdsTotal = 160 * 1024;
 constexpr int kResRowPad = 8;                            // bytes appended to every image row of a resident level (see below)
 constexpr int kResFixed = 64 /* zero row */ + 16;
-constexpr int kResMaxImage = kResLdsTotal - kResWaves * kResWaveLds - kResFixed;   // 90 032 bytes for the resident image
+constexpr int kResMaxImage = kResLdsTotal - kResWaves * kResWaveLds - kResFixed;
+static_assert(kResFixed % 16 == 0 && kResWaveLds % 16 == 0, "work areas behind the (16-byte rounded) image stay 16-byte aligned");   // 90 032 bytes for the resident image
 typedef short v4i16_t __attribute__((ext_vector_type(4)));
 
 struct ResDims {
@@ -1203,7 +1204,8 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
     // host only sized the grid.  A tile index past the device-side tile count has no queries (query_of() returns -1).
     int lq = 0, t0q = 0, twq = 1;
     bool no_tile = false;
-    if (td.pyramid) {
+    bool pyramid = td.pyramid != 0;
+    if (pyramid) {
         int t0 = 0;
         lq = -1;
 #pragma unroll
@@ -1212,14 +1214,19 @@ msda_bwd_tiled_kernel(const float* __restrict__ value, const int32_t* __restrict
             if (lq < 0 && st < t0 + th * tw) { lq = l; t0q = t0; twq = tw; }
             t0 += th * tw;
         }
+        // A host copy that UNDER-counts the device's tiles (same S, other shapes: (5, 8) against (2, 20)) would leave the last
+        // device tiles without a workgroup, i.e. queries whose grad_loc / grad_attn rows are never written.  Every workgroup sees
+        // the same two numbers, so the whole launch then groups the queries 16 in a row instead (the host's grid always holds
+        // ceil(Lq / 16) super-tiles: sum ceil(h/4) ceil(w/4) >= S / 16): slower windows, same results.
+        if (t0 > td.n_super) { pyramid = false; lq = 0; t0q = 0; twq = 1; }
         no_tile = lq < 0;
         if (no_tile) lq = 0;
     }
-    const int trow = td.pyramid ? (st - t0q) / twq : 0;
-    const int tcol = td.pyramid ? (st - t0q) - trow * twq : 0;
+    const int trow = pyramid ? (st - t0q) / twq : 0;
+    const int tcol = pyramid ? (st - t0q) - trow * twq : 0;
     const int Hq = no_tile ? 0 : shapes[2 * lq], Wq = shapes[2 * lq + 1], Sq = lstart[lq];
     auto query_of = [&](int i) -> int {   // slot i of the tile -> query index, -1 past the edge
-        if (td.pyramid) {
+        if (pyramid) {
             const int qy = trow * 4 + (i >> 2), qx = tcol * 4 + (i & 3);
             return (qy < Hq && qx < Wq) ? Sq + qy * Wq + qx : -1;
         }
@@ -1661,6 +1668,9 @@ int resident_plan(const int32_t* host_shapes, int N, int S, int M, int L, int Lq
     if (start[4] != S) return 0;
     long bytes = 0;
     for (int l = 2; l < 4; ++l) bytes += (long)host_shapes[2 * l] * (host_shapes[2 * l + 1] * 64L + kResRowPad);
+    // the zero row and the waves' work areas follow the image: keep them 16-byte aligned (the image itself is only 8-byte
+    // granular when H2 + H3 is odd, and the kernel writes its tables with 16-byte stores)
+    bytes = (bytes + 15) & ~15L;
     if (bytes > kResMaxImage) return 0;
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -258,6 +258,30 @@ def test_graphed_forward_replays_the_eager_forward_bit_for_bit():
     assert len(graphed._graphs) == 1
 
 
+def test_two_graphed_wrappers_of_one_model_do_not_invalidate_each_other():
+    """Round-3 advisor finding: the cache epoch is per model but "no graph alive" was judged per wrapper, so the first capture of a
+    second GraphedForward re-derived (freed) the tensors baked into the first one's live graphs, which then re-captured and
+    invalidated the second in turn — a capture on every alternating call.  Both wrappers keep their graphs now."""
+    from alonet.common import GraphedForward
+
+    torch.manual_seed(0)
+    model = DeformableDetrR50(num_classes=91, aux_loss=False, device=torch.device(DEV)).eval().to(torch.bfloat16)
+    frames = aloscene.Frame.batch_list(_frames([(192, 256), (192, 256)], seed=4)).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in model(frames).items() if k in ("pred_logits", "pred_boxes")}
+    a, b = GraphedForward(model), GraphedForward(model)
+    a(frames)
+    graph_a = next(iter(a._graphs.values()))[1]
+    b(frames)
+    graph_b = next(iter(b._graphs.values()))[1]
+    for _ in range(3):
+        for w, g in ((a, graph_a), (b, graph_b)):
+            got = w(frames)
+            assert next(iter(w._graphs.values()))[1] is g          # replayed, not captured again
+            for key in want:
+                assert torch.equal(got[key], want[key]), key
+
+
 def test_graphed_forward_two_shapes_and_weight_surgery_keep_every_graph_valid():
     """Round-2 advisor finding: capturing a second key used to drop the derived weight tensors (packed / folded / merged copies)
     the FIRST graph had baked in.  Two input shapes are captured, memory is churned, both graphs must still replay the eager

@@ -440,6 +440,31 @@ def test_bench_kernel_direct_vs_oracle_full_size_batch8():
     assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)
 
 
+@pytest.mark.parametrize("kind", ["survey", "uniform"])
+def test_bench_kernel_full_size_on_the_wider_sampling_distributions(kind):
+    """The kernel bench.py times, at N = 8, S = Lq = 22223, AWAY from the init-time ring the benchmark's random-init model samples:
+    SURVEY 8(d)'s micro-benchmark locations (own pixel centre + U(-0.05, 0.05) of the map: +-8 x +-5 px on level 0) and locations
+    uniform over the whole map (no locality between neighbouring queries: where the resident kernel's ~190-consecutive-queries
+    locality is gone).  Resident == plain head-major kernel bit for bit, and a strided query subset + the tail within half a bf16
+    ulp of the float64 oracle (tools/kbench.py generates the same inputs for the `micro` entries of the bench line)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kbench
+
+    value, shapes, start, offsets, logits, ref = kbench.fused_inputs(8, torch.bfloat16, seed=5, kind=kind)
+    mask = torch.zeros(value.shape[:2], dtype=torch.bool, device=DEV)
+    mask[:, ::17] = True
+    vhm = alo_hip.value_head_major(value, mask)
+    with alo_hip.LaunchTimer() as timer:
+        got = alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref)
+    assert "msda_fwd_fused_resident/Lq=22223" in timer.summary(), timer.summary().keys()
+    assert torch.equal(got, alo_hip.msda_forward_fused_hm(vhm, shapes, start, offsets, logits, ref, resident=False))
+    for qsel in (slice(0, None, 53), slice(22223 - 40, None)):
+        exact = _oracle_on_queries(value, mask, offsets, logits, ref, shapes, start, qsel)
+        err = np.abs(got[:, qsel].double().cpu().numpy() - exact)
+        assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)
+
+
 # ---- backward at the config-4 encoder size -------------------------------------------------------------------------------
 def _away_from_pixel_edges(loc, shapes_l, eps=1e-3):
     """grad_sampling_loc is the derivative of a piecewise-bilinear function: it JUMPS where a coordinate crosses an integer.
@@ -634,6 +659,44 @@ def test_tiled_backward_survives_a_host_hint_that_disagrees_with_the_device_shap
     assert torch.isfinite(outs[1][1]).all() and torch.isfinite(outs[1][2]).all()   # every query was served
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-4 * outs[0][0].abs().max().item()   # atomics: order-dependent bits
+
+
+def test_tiled_backward_with_a_host_hint_that_under_counts_the_device_tiles():
+    """Round-3 advisor finding: a host copy with the same S but FEWER 4x4 tiles than the device shapes have ((5, 8) -> 4 tiles,
+    (2, 20) -> 5) sized a grid that left the device's last tiles — their queries' grad_loc / grad_attn rows — unserved, silently.
+    The kernel now compares the two counts and, on an under-count, groups the whole launch 16 queries in a row (the host's grid
+    always holds ceil(Lq / 16) groups): every query served, results those of the oracle."""
+    import ctypes
+
+    rng = np.random.default_rng(16)
+    shapes_l = [(20, 28), (10, 14), (2, 20), (3, 4)]
+    under = [(20, 28), (10, 14), (5, 8), (3, 4)]       # same S; level 2: 2 x 2 = 4 tiles instead of 1 x 5 = 5
+    assert sum(h * w for h, w in shapes_l) == sum(h * w for h, w in under)
+    tiles = lambda sh: sum(-(-h // 4) * -(-w // 4) for h, w in sh)   # noqa: E731
+    assert tiles(under) < tiles(shapes_l)
+    loc = _encoder_like_loc(1, shapes_l, rng, spread_px=2.0)
+    S = loc.shape[1]
+    value_np = rng.standard_normal((1, S, 8, 32)).astype(np.float32)
+    attn_np = rng.random((1, S, 8, 4, 4)).astype(np.float32)
+    attn_np /= attn_np.reshape(1, S, 8, 16).sum(-1)[..., None, None]
+    go_np = rng.standard_normal((1, S, 256)).astype(np.float32)
+    value, attn, go, tl = dev(value_np), dev(attn_np), dev(go_np), dev(loc)
+    shapes = np.asarray(shapes_l, np.int32)
+    sh, st = dev(shapes), dev(level_start(shapes))
+    gv, gl, ga = torch.empty_like(value), torch.full_like(tl, float("nan")), torch.full_like(attn, float("nan"))
+    hint = (ctypes.c_int32 * 8)(*[int(v) for hw in under for v in hw])
+    rc = alo_hip.lib().alo_msda_backward_hinted(
+        *(ctypes.c_void_p(t.data_ptr()) for t in (value, sh, st, tl, attn, go, gv, gl, ga)), 1, S, 8, 32, 4, S, 4,
+        alo_hip.ALO_F32, alo_hip.ALO_F32, hint, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(gl).all() and torch.isfinite(ga).all()          # no query was left out
+    rgv, rgl, rga = O.msda_backward(value_np.astype(np.float64), shapes, level_start(shapes), loc.astype(np.float64),
+                                    attn_np.astype(np.float64), go_np.astype(np.float64))
+    assert np.abs(gv.cpu().numpy() - rgv).max() <= 2e-4 * max(1.0, np.abs(rgv).max())
+    assert np.abs(ga.cpu().numpy() - rga).max() <= 1e-4 * max(1.0, np.abs(rga).max())
+    ok = _away_from_pixel_edges(loc, shapes_l)
+    assert np.abs((gl.cpu().numpy() - rgl) * ok).max() <= 1e-4 * max(1.0, np.abs(rgl).max())
 
 
 # ---- coarse levels resident in LDS (alo_msda_forward_fused_hm_resident) ---------------------------------------------------------------
