@@ -32,7 +32,7 @@ class GraphedForward:
         # graphs replay on
         import weakref
 
-        model.__dict__.setdefault("_alo_graph_wrappers", weakref.WeakSet()).add(self)
+        model.__dict__.setdefault("_graph_wrappers_alo", weakref.WeakSet()).add(self)
 
     def reset(self):
         """Forget every captured graph (the next call captures again)."""
@@ -51,7 +51,7 @@ class GraphedForward:
         # alo_hip.invalidate_caches(model) (load_weights calls it), which bumps the model's cache epoch: __call__ then drops
         # every graph and captures again.
         others_live = any(w._graphs and w._epoch == alo_hip.cache_epoch(self.model)
-                          for w in self.model.__dict__.get("_alo_graph_wrappers", ()) if w is not self)
+                          for w in self.model.__dict__.get("_graph_wrappers_alo", ()) if w is not self)
         if not self._graphs and not others_live:
             alo_hip.invalidate_caches(self.model)  # weights edited through .data since the last forward: re-derive before pinning
         # (with another wrapper's graphs alive on the current epoch the derived tensors are kept: re-deriving them would bump the
