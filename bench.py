@@ -92,6 +92,8 @@ def parse():
     ap.add_argument("--micro-reps", type=int, default=10,
                     help="launches per SURVEY 8(d) kernel micro-benchmark (MSDA forward / backward on three sampling distributions); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two live rocprofv3 --pmc passes that fill roofline.traffic (N = 1 only; about half a minute)")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the bounded CPU sample (~13 s on 32 threads)")
     ap.add_argument("--train-steps", type=int, default=5,
                     help="also time K training steps of DeformableDETR-R50 (BASELINE configs[3]: fp32, 4 frames per GPU, "
@@ -398,6 +400,52 @@ def offline_traffic(a):
         return None
     with open(path) as f:
         return json.load(f)
+
+
+def live_traffic(a):
+    """``roofline.traffic`` collected IN this run: FETCH_SIZE and WRITE_SIZE of the dominant kernel from two ``rocprofv3 --pmc``
+    passes (the two counters do not fit one pass; ``--kernel-trace`` only beside them) over ``tools/kbench.py --which msda_fused_hm``
+    — the same kernel, shape and sampling locations as the in-model encoder call — corrected with the gfx950 calibration of
+    tools/micro/fetch_calib.hip (tools/pmc_parse.py: coalesced streams are counted at half, 64-byte row gathers in full).  Rank 0 at
+    N = 1 only, after the timed legs; any failure (no rocprofv3, counters unavailable) leaves ``traffic`` null and the committed
+    offline collection rides along as before."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if a.dtype != "bf16" or a.batch != 8:
+        return None
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_parse
+
+    N, Lq, M = a.batch, 22223, 8
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    wps = max(1, min(-(-cus // (N * M)), (Lq + 15) // 16 // 12)) if N * M < cus else 1
+    # what the kernel reads as coalesced streams: bf16 offsets + logits, fp32 reference points, the coarse rows copied into LDS
+    stream_bytes = 2.0 * N * Lq * M * 16 * 3 + 4.0 * N * Lq * 4 * 2 + 64.0 * (1050 + 273) * N * M * wps
+    csvs, work = [], tempfile.mkdtemp(prefix="alo_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "kbench.py"), "--which", "msda_fused_hm", "--reps", "3", "--N", str(N)]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, capture_output=True, check=True)
+            found = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not found:
+                return None
+            csvs.append(found[0])
+        return pmc_parse.traffic(csvs, "msda_fwd_bf16_resident_kernel", 324278016.0, stream_bytes,
+                                 "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/kbench.py --which msda_fused_hm, "
+                                 "launched by bench.py after its timed legs")
+    except (Exception, SystemExit) as exc:   # noqa: BLE001  (a measurement extra must never cost the line)
+        print(f"[bench] live PMC collection failed ({type(exc).__name__}: {exc}); roofline.traffic stays null", file=sys.stderr, flush=True)
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def kernel_report(summary):
@@ -755,8 +803,8 @@ def main():
             # below is the kernel without the dispatch gaps either side of a launch
             "achieved": round(enc["alg_bytes"] / (enc["ms_avg"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(enc["alg_bytes"] / (enc["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            # PMC counters cannot be read from inside the timed process: `traffic` (in-run) stays null; the offline rocprofv3
-            # --pmc collection of the same kernel and shape (tools/pmc.sh, committed under profiles/) rides along, labelled
+            # PMC counters cannot be read from inside the timed process: at N = 1 two rocprofv3 --pmc passes over the same kernel and
+            # shape run AFTER the timed legs and fill `traffic` (live_traffic below); the committed offline collection rides along
             "traffic": None,
             "traffic_offline": offline_traffic(a),
             "alg_bytes_per_launch": enc["alg_bytes"],
@@ -778,6 +826,11 @@ def main():
         line["train"] = train
     if panoptic is not None:
         line["panoptic"] = panoptic
+    if world == 1 and not a.no_pmc and line["roofline"] is not None and (enc_key or "").startswith("msda_fwd_fused_resident"):
+        live = live_traffic(a)
+        if live is not None:
+            line["roofline"]["traffic"] = live["bytes"]          # per launch, like `achieved`; calibrated lower bound
+            line["roofline"]["traffic_detail"] = live
     if world == 1 and not a.no_cpu_baseline:
         line["plumbing"] = plumbing_config0()
         line["cpu_baseline"] = cpu_baseline(a.cpu_frames)

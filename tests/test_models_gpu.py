@@ -488,7 +488,7 @@ def test_bench_gpu_branch_with_two_ranks():
     # started PLAINLY, the way the driver starts it (no torch.distributed environment): bench.py spawns its own two ranks
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
            "--raft-steps", "1", "--raft-warmup", "1", "--raft-batch", "1", "--train-steps", "0", "--panoptic-steps", "1",
-           "--eager-steps", "2", "--fp32-steps", "0", "--micro-reps", "0", "--no-cpu-baseline", "--share-gpu"]
+           "--eager-steps", "2", "--fp32-steps", "0", "--micro-reps", "0", "--no-cpu-baseline", "--no-pmc", "--share-gpu"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, OMP_NUM_THREADS="4"))
     assert out.returncode == 0, out.stderr[-3000:]
@@ -512,7 +512,7 @@ def test_bench_rccl_code_path_on_one_rank():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2",
-           "--no-raft", "--train-steps", "2", "--train-batch", "1", "--panoptic-steps", "0", "--no-cpu-baseline", "--force-dist",
+           "--no-raft", "--train-steps", "2", "--train-batch", "1", "--panoptic-steps", "0", "--no-cpu-baseline", "--no-pmc", "--force-dist",
            "--eager-steps", "0", "--fp32-steps", "2", "--micro-reps", "0"]
     env = dict(os.environ, OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)

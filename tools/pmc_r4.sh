@@ -29,7 +29,7 @@ for which in msda_bwd msda_survey msda_bwd_rand; do
   one "backward $which" "FETCH_SIZE" $which f32
   one "backward $which" "TCC_ATOMIC_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" $which f32
 done
-python $ROOT/tools/pmc_parse.py --traffic-json $OUT/msda_fwd_traffic.json --kernel msda_fwd_bf16_resident_kernel --alg-bytes 324278016 \
+python $ROOT/tools/pmc_parse.py --traffic-json $OUT/msda_fwd_traffic.json --kernel msda_fwd_bf16_resident_kernel --alg-bytes 324278016 --stream-bytes 163900000 \
   --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kbench.py --which msda_fused_hm: msda_fwd_bf16_resident_kernel, N=8, Lq=S=22223, ring locations (tools/pmc_r4.sh, round 4)" \
   $OUT/pmc_fwd_ring_fetch.csv $OUT/pmc_fwd_ring_write.csv
 cat $OUT/pmc_by_distribution.txt

@@ -14,8 +14,8 @@ stats() {  # name, bench args
   [ -n "$f" ] && cp $f $OUT/r04_$1_kernel_stats.csv
 }
 # MIOpen's find database warm (RAFT / training convolutions): the first process of a shape benchmarks candidates
-python $ROOT/bench.py --steps 2 --warmup 1 --raft-steps 1 --raft-warmup 1 --no-cpu-baseline --train-steps 1 --panoptic-steps 1 --micro-reps 0 --fp32-steps 0 --eager-steps 0 > /dev/null 2>&1
-COMMON="--no-cpu-baseline --micro-reps 0 --fp32-steps 0 --eager-steps 0 --panoptic-steps 0"
+python $ROOT/bench.py --steps 2 --warmup 1 --raft-steps 1 --raft-warmup 1 --no-cpu-baseline --train-steps 1 --panoptic-steps 1 --micro-reps 0 --fp32-steps 0 --eager-steps 0 --no-pmc > /dev/null 2>&1
+COMMON="--no-pmc --no-cpu-baseline --micro-reps 0 --fp32-steps 0 --eager-steps 0 --panoptic-steps 0"
 stats detr "--no-raft --train-steps 0 --no-graph --steps 40 $COMMON"
 stats raft "--steps 1 --warmup 1 --raft-steps 5 --raft-warmup 2 --train-steps 0 $COMMON"
 stats train "--steps 1 --warmup 1 --no-raft --train-steps 5 $COMMON"
@@ -36,7 +36,7 @@ BWD=msda_bwd,msda_survey,msda_bwd_rand
 pmc bwd_write "WRITE_SIZE" $BWD f32
 pmc bwd_fetch "FETCH_SIZE" $BWD f32
 pmc bwd_tcc "TCC_ATOMIC_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" $BWD f32
-python $ROOT/tools/pmc_parse.py --traffic-json $OUT/msda_fwd_traffic.json --kernel msda_fwd_bf16_resident_kernel --alg-bytes 324278016 \
+python $ROOT/tools/pmc_parse.py --traffic-json $OUT/msda_fwd_traffic.json --kernel msda_fwd_bf16_resident_kernel --alg-bytes 324278016 --stream-bytes 163900000 \
   --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/kbench.py --which msda_fused_hm,...: msda_fwd_bf16_resident_kernel, N=8, Lq=S=22223 (tools/profile_r4.sh, round 4; the mean covers the ring / survey / uniform launches of the pass)" \
   $OUT/pmc_fwd_fetch.csv $OUT/pmc_fwd_write.csv
 cd $ROOT
