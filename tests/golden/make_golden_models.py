@@ -316,6 +316,14 @@ def g16(ns):
     pair = A.Frame.batch_list([A.Frame(r, normalization="255", names=("C", "H", "W")).norm_minmax_sym() for r in raw[:2]])
     assert pair.normalization == "minmax_sym"
     save["pair.values"], save["pair.mask"] = _np(pair.as_tensor()), _np(pair.mask.as_tensor())
+    # FrozenBatchNorm2d of the reference's backbone (detr/backbone.py:50-93: eps added before the rsqrt), formula buffers, and the
+    # folded form this repository convolves with (conv followed by the frozen norm == conv with scaled weights + shift)
+    from helpers import formula_state_dict
+
+    fbn = ns.detr_bb.FrozenBatchNorm2d(6)
+    fbn.load_state_dict(formula_state_dict(fbn.state_dict()))
+    xg = torch.randn(2, 6, 5, 7, generator=gen)
+    save["fbn.x"], save["fbn.out"] = _np(xg), _np(fbn(xg))
     np.savez_compressed(os.path.join(OUT, "g16_frame_io.npz"), **save)
     print("g16 batch", tuple(batch.shape), "mask sum per frame", [int(m.sum()) for m in batch.mask.as_tensor()])
 

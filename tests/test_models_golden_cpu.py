@@ -170,6 +170,26 @@ def test_g16_batch_list_pads_like_the_reference(golden):
     np.testing.assert_array_equal(pair.mask.as_tensor().numpy(), g["pair.mask"])
 
 
+def test_g16_frozen_batch_norm_and_its_folded_form_match_the_reference(golden):
+    """The reference's FrozenBatchNorm2d (detr/backbone.py:50-93) on formula buffers vs this repository's module, and vs the folded
+    convolution the inference path actually runs (conv weights scaled, shift as bias)."""
+    from alonet.detr.backbone import FrozenBatchNorm2d, folded_conv_bn
+    from helpers import formula_state_dict
+
+    g = golden("g16_frame_io.npz")
+    fbn = FrozenBatchNorm2d(6)
+    fbn.load_state_dict(formula_state_dict(fbn.state_dict()))
+    x = t(g["fbn.x"])
+    np.testing.assert_allclose(fbn(x).numpy(), g["fbn.out"], rtol=0, atol=2e-6)
+    conv = torch.nn.Conv2d(6, 6, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.eye(6).view(6, 6, 1, 1))          # identity convolution: the folded pair must reproduce the norm alone
+    with torch.no_grad():
+        w, b = folded_conv_bn(conv.eval(), fbn)
+        folded = torch.nn.functional.conv2d(x, w.float(), b.float())
+    np.testing.assert_allclose(folded.numpy(), g["fbn.out"], rtol=0, atol=5e-6)
+
+
 # ---- G14: DeformableDETR --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["plain", "refine", "softmax"])
 def test_g14_deformable_detr_forward_and_inference_match_the_reference(golden, tag):
