@@ -99,6 +99,10 @@ def _declare(lib):
     lib.alo_groupnorm_rows_workspace_bytes.argtypes = [ip, ip, ip]
     lib.alo_groupnorm_rows.restype = ip
     lib.alo_groupnorm_rows.argtypes = [vp] * 5 + [ip] * 4 + [c.c_float, c.c_long, ip, vp]
+    lib.alo_groupnorm_rows_act.restype = ip
+    lib.alo_groupnorm_rows_act.argtypes = [vp] * 5 + [ip] * 4 + [c.c_float, c.c_long, ip, ip, vp]
+    lib.alo_upsample_add_nhwc.restype = ip
+    lib.alo_upsample_add_nhwc.argtypes = [vp] * 3 + [ip] * 8 + [vp]
     lib.alo_linear_packed.restype = ip
     lib.alo_linear_packed.argtypes = [vp] * 5 + [c.c_long, ip, ip, ip, ip, vp]
     lib.alo_mask_pyramid.restype = ip
@@ -992,12 +996,60 @@ def stem_conv_pool(x, weight, bias=None):
     return y
 
 
-def groupnorm_rows_supported(x, weight, groups):
-    """bf16 CUDA channels-last rows (B, HW, C); C / 8 and ``groups`` divide 256; whole 8-channel slices per group."""
+def groupnorm_rows_supported(x, weight, groups, narrow=False):
+    """bf16 CUDA channels-last rows (B, HW, C); C / 8 and ``groups`` divide 256; whole 8-channel slices per group — or, with
+    ``narrow`` (``groupnorm_nhwc``), 2 or 4 channels per group."""
     c_ = x.shape[-1]
+    cpg = c_ // groups if groups and c_ % groups == 0 else 0
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and weight is not None and weight.dtype == torch.bfloat16
-            and c_ % 8 == 0 and 256 % (c_ // 8) == 0 and c_ % groups == 0 and (c_ // groups) % 8 == 0 and 256 % groups == 0
+            and c_ % 8 == 0 and 256 % (c_ // 8) == 0 and cpg > 0 and (cpg % 8 == 0 or (narrow and cpg in (2, 4))) and 256 % groups == 0
             and not torch.is_grad_enabled())
+
+
+def groupnorm_nhwc_supported(x, norm):
+    """``groupnorm_nhwc`` covers: bf16 CUDA (N, C, H, W) channels-last maps, affine GroupNorm with 2, 4 or a multiple of 8 channels
+    per group, no autograd."""
+    return (x.dim() == 4 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and norm.affine
+            and groupnorm_rows_supported(x.new_empty((1, 1, x.shape[1])), norm.weight, norm.num_groups, narrow=True))
+
+
+def groupnorm_nhwc(x, norm, relu=False):
+    """``relu?(norm(x))`` for a channels-last bf16 map (N, C, H, W) and an ``nn.GroupNorm``; channels-last result.  ATen's GroupNorm
+    works on NCHW: on a channels-last activation it costs a layout copy before and (for the next convolution) after."""
+    if not groupnorm_nhwc_supported(x, norm):
+        raise RuntimeError("groupnorm_nhwc: needs a channels-last bf16 CUDA map and 2, 4 or 8k channels per group, no autograd")
+    n, c_, h, w_ = x.shape
+    rows = x.permute(0, 2, 3, 1)            # (N, H, W, C) view of the same memory
+    out = torch.empty_like(x)               # preserves channels-last
+    if n and h * w_:
+        nbytes = lib().alo_groupnorm_rows_workspace_bytes(n, h * w_, norm.num_groups)
+        ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _timed(f"groupnorm_nhwc/C={c_}", 6.0 * x.numel()):
+            _check(lib().alo_groupnorm_rows_act(_ptr(rows), _ptr(norm.weight.contiguous()), _ptr(norm.bias.contiguous()), _ptr(out),
+                                                _ptr(ws), n, h * w_, c_, norm.num_groups, float(norm.eps), h * w_ * c_,
+                                                1 if relu else 0, ALO_BF16, _stream(x.device)))
+    return out
+
+
+def upsample_add_supported(x_low, fpn):
+    return (x_low.dim() == 4 and fpn.dim() == 4 and x_low.is_cuda and x_low.dtype == torch.bfloat16 and fpn.dtype == torch.bfloat16
+            and x_low.shape[1] == fpn.shape[1] and x_low.shape[1] % 8 == 0 and fpn.shape[0] > 0 and x_low.shape[0] % fpn.shape[0] == 0
+            and x_low.is_contiguous(memory_format=torch.channels_last) and fpn.is_contiguous(memory_format=torch.channels_last)
+            and not torch.is_grad_enabled())
+
+
+def upsample_add(x_low, fpn):
+    """``fpn.repeat_interleave(Q, 0) + F.interpolate(x_low, size=fpn.shape[-2:], mode="nearest")`` in one pass (Q = x_low.shape[0]
+    // fpn.shape[0]); channels-last bf16 in and out, bit-identical to the stock ops."""
+    if not upsample_add_supported(x_low, fpn):
+        raise RuntimeError("upsample_add: needs channels-last bf16 CUDA maps with C % 8 == 0 and x_low.shape[0] a multiple of fpn.shape[0]")
+    bq, c_, h, w_ = x_low.shape
+    b_, _, H, W = fpn.shape
+    out = torch.empty((bq, c_, H, W), dtype=x_low.dtype, device=x_low.device, memory_format=torch.channels_last)
+    if out.numel():
+        with torch.cuda.device(x_low.device), _timed(f"upsample_add/C={c_}", 2.0 * (out.numel() + x_low.numel() + fpn.numel())):
+            _check(lib().alo_upsample_add_nhwc(_ptr(x_low), _ptr(fpn), _ptr(out), bq, bq // b_, c_, h, w_, H, W, ALO_BF16, _stream(x_low.device)))
+    return out
 
 
 def groupnorm_rows(x, weight, bias, groups, eps=1e-5, out=None):

@@ -75,12 +75,21 @@ class FPNstyleCNN(nn.Module):
             (y.shape[0], self._pad64(y.shape[1]), h, w), dtype=y.dtype, device=y.device).contiguous(memory_format=torch.channels_last)
         yp[:, :y.shape[1]] = y
         w2, b2 = self._padded_weights(self.lay2)
-        return F.relu_(self.gn2(alo_hip.conv3x3(yp, w2, b2)[:, :self.lay2.out_channels]))
+        return self._norm_relu(self.gn2, alo_hip.conv3x3(yp, w2, b2)[:, :self.lay2.out_channels])
+
+    @staticmethod
+    def _norm_relu(gn, y, fast=True):
+        """relu(gn(y)); channels-last in and out on the GroupNorm kernel of this library when it covers the layer (2, 4 or 8k
+        channels per group) — ATen's works on NCHW, a layout copy either side on a channels-last activation."""
+        if fast and alo_hip.groupnorm_nhwc_supported(y, gn):
+            return alo_hip.groupnorm_nhwc(y, gn, relu=True)
+        return F.relu(gn(y))
 
     def forward(self, x, bbox_mask, fpns):
         """x (B,C,H,W), bbox_mask (B,Q,heads,H,W), fpns: three (B,c_i,h_i,w_i) maps, coarse to fine -> (B*Q,1,h,w)."""
-        if (x.is_cuda and x.dtype == torch.bfloat16 and self.lay1.weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()
-                and bbox_mask.dtype == x.dtype and bbox_mask.numel() > 0):
+        fast = (x.is_cuda and x.dtype == torch.bfloat16 and self.lay1.weight.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and bbox_mask.dtype == x.dtype and bbox_mask.numel() > 0)
+        if fast:
             x = self._wide_layers_fast(x, bbox_mask)
         else:
             x = torch.cat([_expand(x, bbox_mask.shape[1]), bbox_mask.flatten(0, 1)], 1)
@@ -90,8 +99,14 @@ class FPNstyleCNN(nn.Module):
                                       (self.adapter2, self.lay4, self.gn4, fpns[1]),
                                       (self.adapter3, self.lay5, self.gn5, fpns[2])):
             cur = adapter(fpn)
-            if cur.size(0) != x.size(0):
-                cur = _expand(cur, x.size(0) // cur.size(0))
-            x = cur + F.interpolate(x, size=cur.shape[-2:], mode="nearest")
-            x = F.relu(gn(lay(x)))
+            if fast and cur.size(0) and x.size(0) % cur.size(0) == 0 and cur.shape[1] % 8 == 0:
+                # inference: the per-query copy of the adapter output, the up-sampled copy of x and the add are ONE pass over the
+                # stage's largest tensor (B*Q maps at this level's resolution: 547 MB at stride 4 for 8 frames x 16 queries), and the
+                # GroupNorm + ReLU behind the convolution stays channels-last
+                x = alo_hip.upsample_add(x.contiguous(memory_format=torch.channels_last), cur.contiguous(memory_format=torch.channels_last))
+            else:
+                if cur.size(0) != x.size(0):
+                    cur = _expand(cur, x.size(0) // cur.size(0))
+                x = cur + F.interpolate(x, size=cur.shape[-2:], mode="nearest")
+            x = self._norm_relu(gn, lay(x), fast)
         return self.out_lay(x)

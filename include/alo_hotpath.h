@@ -356,6 +356,23 @@ int alo_stem_conv_pool(const void* x, const void* w_packed, const void* bias, vo
 size_t alo_groupnorm_rows_workspace_bytes(int B, int HW, int groups);
 int alo_groupnorm_rows(const void* x, const void* weight, const void* bias, void* y, void* workspace, int B, int HW, int C,
                        int groups, float eps, long y_batch_stride, int dtype, void* stream);
+/*
+ * alo_groupnorm_rows_act: the same with 2 or 4 channels per group as well (a thread's 8 channels then span several groups) and an
+ * optional ReLU in the normalise pass: the GroupNorm(8, 32) / GroupNorm(8, 16) + ReLU of PanopticHead's mask decoder over B*Q maps of
+ * up to 200 x 334 pixels (alonet/detr_panoptic/nn/FPNstyle.py:24-36,60-84), channels-last in and out — ATen's GroupNorm takes NCHW,
+ * i.e. a layout copy either side of every one of them.
+ */
+int alo_groupnorm_rows_act(const void* x, const void* weight, const void* bias, void* y, void* workspace, int B, int HW, int C,
+                           int groups, float eps, long y_batch_stride, int relu, int dtype, void* stream);
+
+/*
+ * alo_upsample_add_nhwc: out (BQ, H, W, C) = fpn[bq / Q] (B, H, W, C) + nearest-up-sampled x_low (BQ, h, w, C), channels-last bf16:
+ * `_expand(adapter(fpn), Q) + F.interpolate(x, size=(H, W), mode="nearest")` of the mask decoder's FPN steps (FPNstyle.py:60-84) in
+ * one pass — without the per-query copy of the adapter output, the up-sampled copy and the add.  Index arithmetic of ATen's nearest
+ * kernel (scale = float(in) / out, src = min(int(floorf(dst * scale)), in - 1)); fp32 add, one rounding: bit-identical to the stock ops.
+ */
+int alo_upsample_add_nhwc(const void* x_low, const void* fpn, void* out, int BQ, int Q, int C, int h, int w, int H, int W, int dtype,
+                          void* stream);
 
 /*
  * alo_mask_pyramid: the padding mask of every level, flattened, and the valid ratios, from the (B, H, W) frame mask:

@@ -350,6 +350,42 @@ def test_groupnorm_rows_matches_group_norm(B, HW, C, groups):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W,groups", [(3, 16, 21, 34, 8), (2, 32, 13, 17, 8), (5, 64, 9, 11, 8), (2, 128, 7, 5, 8), (1, 16, 300, 301, 8),
+                                            (4, 32, 1, 3, 16)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_groupnorm_nhwc_with_narrow_groups_matches_group_norm(N, C, H, W, groups, relu):
+    """alo_groupnorm_rows_act (2, 4, 8 or 16 channels per group, optional ReLU) on channels-last maps against F.group_norm in fp32 on
+    the same bf16 values: the GroupNorm(8, 16..128) + ReLU layers of PanopticHead's mask decoder (FPNstyle.py:24-36)."""
+    g = torch.Generator(device="cuda").manual_seed(N * C + H * W)
+    x = (torch.randn(N, C, H, W, device="cuda", generator=g) * 2 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    norm = torch.nn.GroupNorm(groups, C).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, device="cuda", generator=g))
+        norm.bias.copy_(torch.randn(C, device="cuda", generator=g))
+        ref = F.group_norm(x.float(), groups, norm.weight.float(), norm.bias.float(), norm.eps)
+        ref = F.relu(ref) if relu else ref
+        assert alo_hip.groupnorm_nhwc_supported(x, norm)
+        out = alo_hip.groupnorm_nhwc(x, norm, relu=relu)
+    assert out.shape == x.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert (out.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item()) + 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,C,h,w,H,W", [(2, 3, 32, 5, 7, 10, 13), (1, 16, 64, 25, 42, 50, 84), (3, 1, 8, 4, 4, 9, 7), (2, 5, 128, 3, 4, 3, 4),
+                                           (1, 2, 16, 100, 167, 200, 334)])
+def test_upsample_add_is_the_stock_expand_interpolate_add_bit_for_bit(B, Q, C, h, w, H, W):
+    """alo_upsample_add_nhwc == `_expand(fpn, Q) + F.interpolate(x, size=(H, W), mode="nearest")` of the mask decoder's FPN steps
+    (FPNstyle.py:60-84), odd ratios included: same source pixels as ATen's nearest kernel, fp32 add, one rounding."""
+    g = torch.Generator(device="cuda").manual_seed(B * Q + C + H)
+    x = torch.randn(B * Q, C, h, w, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    fpn = torch.randn(B, C, H, W, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        want = fpn.unsqueeze(1).repeat(1, Q, 1, 1, 1).flatten(0, 1) + F.interpolate(x, size=(H, W), mode="nearest")
+        got = alo_hip.upsample_add(x, fpn)
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N", [(1000, 512, 128), (77, 1024, 256), (130, 2048, 512), (64, 512, 2048), (1, 768, 384)])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
 def test_linear_packed_matches_fp32_linear(M, K, N, relu, res):
