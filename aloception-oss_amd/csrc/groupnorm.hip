@@ -103,6 +103,7 @@ groupnorm_apply_kernel(const bf16_t* __restrict__ X, const float* __restrict__ w
     unpack8(*reinterpret_cast<const u32x4*>(beta + cg * 8), be);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { ga[i] *= rstd; be[i] -= mean * ga[i]; }   // y = x * ga + be
+    const bool relu = dm.relu != 0;   // alo_groupnorm_rows_act: y = relu(y), NaN kept as torch's relu keeps it
     const int row_begin = blockIdx.x * kGnRows;
     const int row_end = row_begin + kGnRows < dm.HW ? row_begin + kGnRows : dm.HW;
     const bf16_t* xb = X + ((size_t)b * dm.HW) * dm.C + cg * 8;
@@ -110,11 +111,16 @@ groupnorm_apply_kernel(const bf16_t* __restrict__ X, const float* __restrict__ w
     for (int r = row_begin + r0; r < row_end; r += rpp) {
         float v[8];
         unpack8(*reinterpret_cast<const u32x4*>(xb + (size_t)r * dm.C), v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = fmaf(v[i], ga[i], be[i]);
+            if (relu) v[i] = v[i] < 0.f ? 0.f : v[i];
+        }
         u32x4 o;
-        o.x = pack_bf16x2(fmaf(v[0], ga[0], be[0]), fmaf(v[1], ga[1], be[1]));
-        o.y = pack_bf16x2(fmaf(v[2], ga[2], be[2]), fmaf(v[3], ga[3], be[3]));
-        o.z = pack_bf16x2(fmaf(v[4], ga[4], be[4]), fmaf(v[5], ga[5], be[5]));
-        o.w = pack_bf16x2(fmaf(v[6], ga[6], be[6]), fmaf(v[7], ga[7], be[7]));
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]);
+        o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<u32x4*>(yb + (size_t)r * dm.C) = o;
     }
 }
@@ -210,7 +216,7 @@ groupnorm_apply_small_kernel(const bf16_t* __restrict__ X, const float* __restri
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             v[i] = fmaf(v[i], ga[i], be[i]);
-            if (relu) v[i] = fmaxf(v[i], 0.f);
+            if (relu) v[i] = v[i] < 0.f ? 0.f : v[i];   // NaN kept, as torch's relu keeps it
         }
         u32x4 o;
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
