@@ -101,6 +101,8 @@ def _declare(lib):
     lib.alo_groupnorm_rows.argtypes = [vp] * 5 + [ip] * 4 + [c.c_float, c.c_long, ip, vp]
     lib.alo_groupnorm_rows_act.restype = ip
     lib.alo_groupnorm_rows_act.argtypes = [vp] * 5 + [ip] * 4 + [c.c_float, c.c_long, ip, ip, vp]
+    lib.alo_conv3x3_small_nhwc.restype = ip
+    lib.alo_conv3x3_small_nhwc.argtypes = [vp] * 4 + [ip] * 6 + [vp]
     lib.alo_upsample_add_nhwc.restype = ip
     lib.alo_upsample_add_nhwc.argtypes = [vp] * 3 + [ip] * 8 + [vp]
     lib.alo_linear_packed.restype = ip
@@ -1029,6 +1031,51 @@ def groupnorm_nhwc(x, norm, relu=False):
                                                 _ptr(ws), n, h * w_, c_, norm.num_groups, float(norm.eps), h * w_ * c_,
                                                 1 if relu else 0, ALO_BF16, _stream(x.device)))
     return out
+
+
+def conv3x3_small_supported(x, conv):
+    """``conv3x3_small`` covers: an ``nn.Conv2d`` 3x3 / stride 1 / padding 1 with Cin in (16, 32, 64) and Cout = 1 or 4k <= 32 on a
+    channels-last bf16 CUDA map, no autograd."""
+    w = conv.weight
+    return (isinstance(conv, torch.nn.Conv2d) and x.dim() == 4 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and w.shape[1] == x.shape[1] and x.shape[1] in (16, 32, 64)
+            and (w.shape[0] == 1 or (w.shape[0] % 4 == 0 and w.shape[0] <= 32))
+            and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_grad_enabled())
+
+
+def _small_conv_operands(conv):
+    """(w_frag, bias32) of alo_conv3x3_small_nhwc, cached on the module per weight / bias version."""
+    w, b = conv.weight, conv.bias
+    key = (tensor_version(w), w.data_ptr(), None if b is None else (tensor_version(b), b.data_ptr()))
+    hit = conv.__dict__.get("_alo_small_frag")
+    if hit is None or hit[0] != key:
+        cout, cin = w.shape[:2]
+        with torch.no_grad():
+            full = torch.zeros((32, 3, 3, cin), dtype=w.dtype, device=w.device)
+            full[:cout] = w.detach().permute(0, 2, 3, 1)                                   # (m, ky, kx, c)
+            frag = full.view(32, 9, cin // 16, 2, 8).permute(1, 2, 3, 0, 4).contiguous()   # (tap, cs, kg, m, 8) = [k-step][lane][8]
+            bias32 = torch.zeros(32, dtype=torch.float32, device=w.device)
+            if b is not None:
+                bias32[:cout] = b.detach().float()
+        hit = (key, frag, bias32)
+        conv.__dict__["_alo_small_frag"] = hit
+    return hit[1], hit[2]
+
+
+def conv3x3_small(x, conv):
+    """``conv(x)`` for the few-channel 3x3 convolutions of the mask decoder (channels-last bf16 in and out)."""
+    if not conv3x3_small_supported(x, conv):
+        raise RuntimeError("conv3x3_small: needs a channels-last bf16 CUDA map, a 3x3 / stride 1 / padding 1 convolution with Cin in "
+                           "(16, 32, 64) and Cout = 1 or 4k <= 32, no autograd")
+    n, cin, h, w_ = x.shape
+    cout = conv.weight.shape[0]
+    frag, bias32 = _small_conv_operands(conv)
+    y = torch.empty((n, cout, h, w_), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if y.numel():
+        with torch.cuda.device(x.device), _timed(f"conv3x3_small/C={cin}->{cout}", 2.0 * (x.numel() + y.numel()), 2.0 * 9 * cin * cout * n * h * w_):
+            _check(lib().alo_conv3x3_small_nhwc(_ptr(x), _ptr(frag), _ptr(bias32), _ptr(y), n, h, w_, cin, cout, ALO_BF16, _stream(x.device)))
+    return y
 
 
 def upsample_add_supported(x_low, fpn):

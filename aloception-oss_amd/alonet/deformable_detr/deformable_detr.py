@@ -133,7 +133,11 @@ class DeformableDETR(nn.Module):
         frame_masks = frames.mask.as_tensor()
         # the stride-4 positional encoding is only ever an output (bb_lvl0_pos_outputs), never an input of the transformer;
         # at inference the others are produced by the transformer itself, flattened, in one pass (alo_pos_sine_flat)
-        lazy_pos = (not self.return_bb_outputs and "is_tracing" not in kwargs and not self.training
+        # PanopticHead switches return_bb_outputs on for the backbone FEATURES (and the last level's mask); unless it hands the
+        # detector's outputs on to its caller (return_detr_outputs) nobody reads the per-level positional encodings / other masks,
+        # and the detector may keep its inference fast path (`_alo_lean_bb_outputs`, set by PanopticHead)
+        lean = getattr(self, "_alo_lean_bb_outputs", False)
+        lazy_pos = ((not self.return_bb_outputs or lean) and "is_tracing" not in kwargs and not self.training
                     and isinstance(self.backbone[1], PositionEmbeddingSine) and self.backbone[1].num_pos_feats % 4 == 0
                     and alo_hip.fusable(frames.as_tensor(), self.transformer.level_embed))
         skip = tuple(range(len(self.backbone.num_channels))) if lazy_pos else (() if self.return_bb_outputs else (0,))

@@ -76,7 +76,14 @@ class PanopticHead(nn.Module):
         return out
 
     def detr_forward(self, frames, **kwargs):
-        return self.detr(frames, **kwargs)
+        # The head reads the backbone features, the last level's mask, the decoder and encoder outputs — not the per-level positional
+        # encodings or the other levels' masks.  Unless the detector's outputs are handed on to the caller (return_detr_outputs) a
+        # Deformable-DETR detector may therefore keep its fused inference path for THIS call (deformable_detr.py forward).
+        self.detr._alo_lean_bb_outputs = not self.return_detr_outputs
+        try:
+            return self.detr(frames, **kwargs)
+        finally:
+            self.detr._alo_lean_bb_outputs = False
 
     @torch.no_grad()
     def inference(self, forward_out, maskth=0.5, filters=None, frame_size=None, **kwargs):

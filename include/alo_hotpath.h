@@ -324,6 +324,16 @@ int alo_conv1x1_nhwc(const void* x, const void* weight, int weight_is_packed, co
                      int H, int W, int Cin, int Cout, int stride, int relu, int dtype, void* stream);
 
 /*
+ * alo_conv3x3_small_nhwc: y (N, H, W, Cout) = conv3x3(x (N, H, W, Cin), stride 1, padding 1) + bias for FEW channels — Cin in
+ * {16, 32, 64}, Cout = 1 or a multiple of 4 up to 32 — bf16 with fp32 accumulation: lay4 / lay5 / out_lay of PanopticHead's mask
+ * decoder over B*Q maps (alonet/detr_panoptic/nn/FPNstyle.py:28-33,76-84).  w_frag = the weight in the MFMA row operand's fragment
+ * order, [9 * Cin / 16 k-steps][64 lanes][8] bf16 with lane = 32 kg + m holding w[m][16 cs + 8 kg .. + 8][ky][kx] for k-step
+ * (3 ky + kx) * (Cin / 16) + cs (rows m >= Cout are zero); bias32 = 32 fp32 values (zero-padded).
+ */
+int alo_conv3x3_small_nhwc(const void* x, const void* w_frag, const void* bias32, void* y, int N, int H, int W, int Cin, int Cout,
+                           int dtype, void* stream);
+
+/*
  * alo_conv3x3_nhwc: y (N, Ho, Wo, Cout) = act(conv3x3(x (N, H, W, Cin), stride 1 or 2, padding 1) + bias), bf16 with fp32
  * accumulation: Bottleneck.conv2 + the folded FrozenBatchNorm2d + ReLU of the ResNet backbone (alonet/detr/backbone.py:19-47,
  * 84-92; torchvision Bottleneck), an implicit GEMM on MFMA.  Ho = (H - 1) / stride + 1.  w_packed = alo_pack_mfma_b of the

@@ -371,6 +371,33 @@ def test_groupnorm_nhwc_with_narrow_groups_matches_group_norm(N, C, H, W, groups
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(3, 32, 16, 21, 34), (2, 64, 32, 13, 17), (2, 16, 1, 9, 50), (1, 16, 4, 8, 16), (5, 32, 32, 1, 1),
+                                            (2, 64, 8, 7, 3), (1, 32, 16, 200, 334)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_conv3x3_small_matches_fp32_convolution(N, Cin, Cout, H, W, bias):
+    """alo_conv3x3_small_nhwc (few-channel 3x3 convolutions of the mask decoder: FPNstyle.py lay4 / lay5 / out_lay) against F.conv2d in
+    fp32 on the same bf16 operands: one rounding of difference; tiles that hang over the map's edges, 1 x 1 maps, Cout = 1."""
+    g = torch.Generator(device="cuda").manual_seed(N * Cin + Cout + H * W)
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=bias).cuda().to(torch.bfloat16).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (9 * Cin) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(Cout, device="cuda", generator=g))
+        assert alo_hip.conv3x3_small_supported(x, conv)
+        ref = F.conv2d(x.float(), conv.weight.float(), conv.bias.float() if bias else None, padding=1)
+        out = alo_hip.conv3x3_small(x, conv)
+        again = alo_hip.conv3x3_small(x, conv)          # cached operands
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, again)
+    assert (out.float() - ref).abs().max().item() <= 2.0 ** -8 * max(1.0, ref.abs().max().item()) + 1e-3
+    with torch.no_grad():                               # weights edited in place: the packed copy follows the version counter
+        conv.weight.mul_(2.0)
+        out2 = alo_hip.conv3x3_small(x, conv)
+        ref2 = F.conv2d(x.float(), conv.weight.float(), conv.bias.float() if bias else None, padding=1)
+    assert (out2.float() - ref2).abs().max().item() <= 2.0 ** -8 * max(1.0, ref2.abs().max().item()) + 2e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,Q,C,h,w,H,W", [(2, 3, 32, 5, 7, 10, 13), (1, 16, 64, 25, 42, 50, 84), (3, 1, 8, 4, 4, 9, 7), (2, 5, 128, 3, 4, 3, 4),
                                            (1, 2, 16, 100, 167, 200, 334)])
 def test_upsample_add_is_the_stock_expand_interpolate_add_bit_for_bit(B, Q, C, h, w, H, W):
