@@ -9,6 +9,7 @@ import torch.nn.functional as F
 from torch import nn
 
 import alo_hip
+from alonet.detr.backbone import conv1x1_as_gemm
 
 
 def _expand(tensor, length):
@@ -98,7 +99,13 @@ class FPNstyleCNN(nn.Module):
         for adapter, lay, gn, fpn in ((self.adapter1, self.lay3, self.gn3, fpns[0]),
                                       (self.adapter2, self.lay4, self.gn4, fpns[1]),
                                       (self.adapter3, self.lay5, self.gn5, fpns[2])):
-            cur = adapter(fpn)
+            if (fast and fpn.is_contiguous(memory_format=torch.channels_last) and adapter.kernel_size == (1, 1)
+                    and adapter.stride == (1, 1) and adapter.padding == (0, 0) and adapter.groups == 1 and adapter.out_channels % 4 == 0):
+                # 1x1 adapter over the NHWC rows as a GEMM (bias in its epilogue): no MIOpen kernel — and no MIOpen search on the
+                # first call of a shape — anywhere in the head
+                cur = conv1x1_as_gemm(fpn, adapter.weight, adapter.bias)
+            else:
+                cur = adapter(fpn)
             if fast and cur.size(0) and x.size(0) % cur.size(0) == 0 and cur.shape[1] % 8 == 0:
                 # inference: the per-query copy of the adapter output, the up-sampled copy of x and the add are ONE pass over the
                 # stage's largest tensor (B*Q maps at this level's resolution: 547 MB at stride 4 for 8 frames x 16 queries), and the

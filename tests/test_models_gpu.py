@@ -706,3 +706,27 @@ def test_g15_panoptic_head_over_deformable_detr_on_hip_matches_the_reference(gol
         for b, (bx, mk) in enumerate(zip(boxes, masks)):
             assert np.abs(bx.as_tensor().double().cpu().numpy() - g[f"pan_deformable.inf.boxes{b}"]).max() <= 1e-3
             M.assert_masks_equal_up_to_ties(mk, g, "pan_deformable", b, gap=2e-3)
+
+
+def test_get_mask_queries_single_transfer_form_equals_the_per_image_form():
+    """detr_panoptic/utils.py: on the device the kept decoder rows are gathered after ONE host transfer of the filters; rows, zero
+    padding and the returned filters must be those of the reference's per-image form (utils.py:7-50), NaN in a query that is not
+    kept included."""
+    from alonet.detr_panoptic.utils import get_mask_queries
+
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    dec = torch.randn(2, 4, 9, 16, generator=gen, device=DEV)          # (stages, B, Q, C)
+    dec[-1, 0, 0] = float("nan")                                       # query 0 of image 0 is not kept below
+    filters = [torch.tensor([0, 1, 1, 0, 0, 1, 0, 0, 1], dtype=torch.bool, device=DEV),
+               torch.zeros(9, dtype=torch.bool, device=DEV),
+               torch.ones(9, dtype=torch.bool, device=DEV),
+               torch.tensor([1, 0, 0, 0, 0, 0, 0, 0, 0], dtype=torch.bool, device=DEV)]
+    rows, kept = get_mask_queries(frames=None, m_outputs={"dec_outputs": dec}, model=None, filters=filters)
+    assert kept is filters and rows.shape == (4, 9, 16)
+    last = dec[-1]
+    for b, f in enumerate(filters):
+        n = int(f.sum())
+        assert torch.equal(rows[b, :n], last[b, f]) and bool((rows[b, n:] == 0).all())
+    none_kept = [torch.zeros(9, dtype=torch.bool, device=DEV) for _ in range(4)]
+    rows0, _ = get_mask_queries(frames=None, m_outputs={"dec_outputs": dec}, model=None, filters=none_kept)
+    assert rows0.shape == (4, 0, 16)

@@ -45,3 +45,5 @@ cd $ROOT
 python tools/kbench.py --which $FWD,msda_enc,msda_survey,msda_rand,msda_bwd,msda_bwd_rand,corr_build,corr_lookup --reps 40 2>/dev/null | grep kernel > $OUT/kbench.txt
 python bench.py > $OUT/r04_bench_line.json 2> $OUT/bench.err
 tail -c 600 $OUT/r04_bench_line.json; head -8 $OUT/r04_raft_kernel_stats.csv | cut -c1-150; cat $OUT/hipblaslt_corr.txt
+# the panoptic leg alone (configs[4] per-GPU share) under rocprofv3
+stats panoptic "--steps 2 --warmup 1 --no-raft --train-steps 0 --panoptic-steps 10 --no-pmc --no-cpu-baseline --micro-reps 0 --fp32-steps 0 --eager-steps 0"
