@@ -77,10 +77,6 @@ def _declare(lib):
     lib.alo_msda_forward_fused_hm_resident.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [c.POINTER(c.c_int32), ip, vp]
     lib.alo_msda_resident_levels.restype = ip
     lib.alo_msda_resident_levels.argtypes = [c.POINTER(c.c_int32)] + [ip] * 6
-    lib.alo_value_half_head_major.restype = ip
-    lib.alo_value_half_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
-    lib.alo_msda_forward_fused_hh_f32.restype = ip
-    lib.alo_msda_forward_fused_hh_f32.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 8 + [c.POINTER(c.c_int32), ip, vp]
     lib.alo_value_head_major.restype = ip
     lib.alo_value_head_major.argtypes = [vp] * 3 + [ip] * 5 + [vp]
     lib.alo_bias_act_nchw.restype = ip
@@ -379,84 +375,6 @@ def value_head_major(value, padding_mask=None):
     with torch.cuda.device(value.device), _timed(f"value_head_major/S={S}", 2 * value.element_size() * value.numel()):
         _check(lib().alo_value_head_major(_ptr(value), None if padding_mask is None else _ptr(padding_mask), _ptr(out),
                                           N, S, M, D, _DTYPE_CODE[value.dtype], _stream(value.device)))
-    return out
-
-
-def _host_shape_array(spatial_shapes, L, S):
-    """ctypes copy of a HOST copy of ``spatial_shapes`` that is already at hand (``_alo_shapes`` set by DeformableTransformer, or a
-    previous read) — never a device read — or None."""
-    host = getattr(spatial_shapes, "_alo_shapes", None)
-    if host is None:
-        hit = getattr(spatial_shapes, "_alo_shapes_read", None)
-        host = hit[1] if hit is not None and hit[0] == tensor_version(spatial_shapes) else None
-    if host is None or len(host) != L or sum(int(h) * int(w) for h, w in host) != S:
-        return None
-    return (ctypes.c_int32 * (2 * L))(*[int(v) for hw in host for v in hw])
-
-
-def msda_f32_resident_supported(value, spatial_shapes, Lq, L, P, resident=True):
-    """Whether ``msda_forward_fused_hh_f32`` takes this launch: fp32 CUDA value (N, S, M, 32), L = P = 4, a host copy of the shapes at
-    hand, and a launch the library's policy gives to the LDS-resident kernel (large ones; ``resident="always"``: wherever it fits)."""
-    if not (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.shape[-1] == 32 and L == 4 and P == 4
-            and not torch.is_grad_enabled()):
-        return False
-    N, S, M, _ = value.shape
-    starts = _host_shape_array(spatial_shapes, L, S)
-    policy = RESIDENT_ALWAYS if resident == "always" else RESIDENT_AUTO
-    return starts is not None and lib().alo_msda_resident_levels(starts, N, S, 2 * M, L, Lq, policy) == 2
-
-
-def value_half_head_major(value, padding_mask=None):
-    """(N, S, M, 32) fp32 -> (N, 2 M, S, 16), rows of padded pixels zeroed: the layout of ``msda_forward_fused_hh_f32``."""
-    _require_cuda_contiguous([("value", value)])
-    N, S, M, D = value.shape
-    if value.dtype != torch.float32 or D != 32:
-        raise RuntimeError("value_half_head_major: needs an fp32 (N, S, M, 32) tensor")
-    if padding_mask is not None:
-        if padding_mask.dtype != torch.bool or tuple(padding_mask.shape) != (N, S) or not padding_mask.is_cuda:
-            raise RuntimeError("padding_mask must be a (N, S) bool CUDA tensor")
-        padding_mask = padding_mask.contiguous()
-    out = torch.empty((N, 2 * M, S, 16), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device), _timed(f"value_half_head_major/S={S}", 8.0 * value.numel()):
-        _check(lib().alo_value_half_head_major(_ptr(value), None if padding_mask is None else _ptr(padding_mask), _ptr(out), N, S, M, D,
-                                               ALO_F32, _stream(value.device)))
-    return out
-
-
-def msda_forward_fused_hh_f32(value_hh, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points, resident=True):
-    """The fused forward in fp32 with the coarse pyramid levels of every (image, half head) slab resident in LDS:
-    ``value_hh`` (N, 2 M, S, 16) from ``value_half_head_major``; raw offsets (N, Lq, M, 4, 4, 2), raw logits (N, Lq, M, 16), reference
-    points (N, Lq, 4, 2|4), all fp32.  Only for launches ``msda_f32_resident_supported`` accepts."""
-    N, M2, S, D16 = value_hh.shape
-    M = M2 // 2
-    _, Lq, _, L, P, _ = sampling_offsets.shape
-    reference_points = reference_points.float().contiguous()
-    _require_cuda_contiguous([("value", value_hh), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index)])
-    if value_hh.dtype != torch.float32 or D16 != 16 or sampling_offsets.dtype != torch.float32 or attn_logits.dtype != torch.float32:
-        raise RuntimeError("msda_forward_fused_hh_f32: needs fp32 value (N, 2M, S, 16), offsets and logits")
-    if spatial_shapes.dtype != torch.int32 or level_start_index.dtype != torch.int32:
-        raise RuntimeError("spatial_shapes and level_start_index must be int32 tensors")
-    ref_dim = reference_points.shape[-1]
-    if tuple(reference_points.shape) != (N, Lq, L, ref_dim) or attn_logits.numel() != N * Lq * M * L * P:
-        raise RuntimeError("reference_points must be (N,Lq,L,2|4) and attn_logits (N,Lq,M,L*P)")
-    off_rs, log_rs = _query_rows(sampling_offsets, M * L * P * 2), _query_rows(attn_logits, M * L * P)
-    if off_rs is None or log_rs is None or off_rs % 4 or log_rs % 4 or sampling_offsets.data_ptr() % 16 or attn_logits.data_ptr() % 16:
-        sampling_offsets, attn_logits = sampling_offsets.contiguous(), attn_logits.contiguous()
-        off_rs, log_rs = M * L * P * 2, M * L * P
-    starts = _host_shape_array(spatial_shapes, L, S)
-    if starts is None:
-        raise RuntimeError("msda_forward_fused_hh_f32: needs a host copy of spatial_shapes (spatial_shapes._alo_shapes)")
-    out = torch.empty((N, Lq, M * 32), dtype=torch.float32, device=value_hh.device)
-    nbytes = 4 * (N * S * M * 32 + N * Lq * M * 32 + N * Lq * M * L * P * 3) + 4 * reference_points.numel()
-    policy = RESIDENT_ALWAYS if resident == "always" else RESIDENT_AUTO
-
-    def launch():
-        _check(lib().alo_msda_forward_fused_hh_f32(_ptr(value_hh), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_offsets),
-                                                   _ptr(attn_logits), off_rs, log_rs, _ptr(reference_points), _ptr(out), N, S, M, 32, L, Lq,
-                                                   P, ref_dim, starts, policy, _stream(value_hh.device)))
-
-    with torch.cuda.device(value_hh.device), _timed(f"msda_fwd_fused_resident_f32/Lq={Lq}", nbytes, relaunch=launch if _timer else None):
-        launch()
     return out
 
 

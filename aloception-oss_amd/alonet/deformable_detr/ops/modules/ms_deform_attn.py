@@ -146,14 +146,6 @@ class MSDeformAttn(nn.Module):
                                                    offsets.contiguous(), logits.contiguous(), reference_points)
             return proj(self.output_proj, output)
 
-        if fused and alo_hip.msda_f32_resident_supported(value.view(N, S, M, self.d_model // M), input_spatial_shapes, Lq, L, P):
-            # inference in the reference op's own dtype, DETR-family shape, encoder-size launch: the value goes half-head-major (padding
-            # zeroed in the same pass) and the coarse pyramid levels of every (image, half head) stay in LDS (msda_fwd_f32_resident_kernel)
-            value = alo_hip.value_half_head_major(value.view(N, S, M, self.d_model // M), input_padding_mask)
-            output = alo_hip.msda_forward_fused_hh_f32(value, input_spatial_shapes, input_level_start_index, offsets, logits,
-                                                       reference_points)
-            return proj(self.output_proj, output)
-
         if input_padding_mask is not None:
             if needs_grad:
                 value = value.masked_fill(input_padding_mask[..., None], float(0))

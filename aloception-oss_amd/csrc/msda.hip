@@ -980,220 +980,6 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// forward, fp32 — the reference op's own dtype (ms_deform_attn_cuda.cu:64) — L = P = 4, D = 32, on the LDS-resident structure.
-//
-// What bounds the generic fp32 kernel: not memory — with the coarse levels answered by the buffer range
-// check it still takes 95 % of its time — but the texture path's instruction rate: a 16-byte-per-lane buffer load occupies the address
-// unit for 16 clocks whatever it returns, and an fp32 head row is eight of them.  LDS reads do not go through that unit.  In fp32 a
-// (image, head) slab's levels 2-3 are 169 KB — too much — but HALF a head (16 channels = 64 bytes per pixel) is exactly the bf16
-// kernel's geometry: 84.7 KB.  So the value tensor is re-laid as (N, 2 M, S, 16) ("half-head-major", alo_value_half_head_major) and
-// this kernel is msda_fwd_bf16_resident_kernel's structure on 64-byte fp32 rows: a 12-wave workgroup pinned to a (image, half head)
-// slab keeps levels 2-3 in LDS, its waves take runs of 16 consecutive queries; quads serve pairs, lane J of a quad builds the four
-// samples of level J and the other lanes take its corner addresses by DPP; the weighted sum is v_pk_fma_f32 on the lane's four
-// channels (no matrix pipe, no transposes: fp32 rows are consumed as they arrive).  The descriptor stage runs once per HALF head
-// (twice the bf16 kernel's share); softmax and location arithmetic use the exact exp / divisions of the generic fp32 path.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int kF32WaveLds = 16 * 16 * 16;   // corner weights of a run: 16 samples x 16 pairs x 4 fp32 = 4 KB per wave
-static_assert(kResWaves * kF32WaveLds <= kResWaves * kResWaveLds, "the fp32 kernel fits the LDS plan of the bf16 one");
-
-__device__ __forceinline__ f32x4 lds_read_f32x4(const unsigned char* base, unsigned off) {
-    return *reinterpret_cast<const f32x4*>(base + off);
-}
-
-__global__ void __launch_bounds__(kResThreads)
-msda_fwd_f32_resident_kernel(const float* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
-                             const float* __restrict__ loc_, const float* __restrict__ attn_, const float* __restrict__ ref,
-                             float* __restrict__ out, const Dims dm, const ResDims rd) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RL = 2;
-    const int M2 = 2 * dm.M;   // slabs per image: (head, channel half)
-
-    const unsigned lb = xcd_contiguous_block(blockIdx.x, dm.nblocks);
-    const int slab = (int)(lb / (unsigned)rd.wps), part = (int)(lb % (unsigned)rd.wps);
-    const int b = slab / M2, hm = slab - b * M2;
-    const int m = hm >> 1, half = hm & 1;
-    const int lid = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pl = lid >> 2, lane = lid & 3;
-
-    const float* slab_base = value + ((size_t)b * M2 + hm) * dm.S * 16;
-    const unsigned zero_row = (unsigned)rd.image_bytes;
-    unsigned char* aw = smem + zero_row + kResFixed + wave * kF32WaveLds;
-
-    const unsigned rs0 = (unsigned)rd.w[0] * 64u + kResRowPad, rs1 = (unsigned)rd.w[1] * 64u + kResRowPad;
-    const unsigned lds_lvl1 = (unsigned)rd.h[0] * rs0;
-
-    bool res_ok = rd.res_row0 == lstart[RL] && shapes[2 * RL] == rd.h[0] && shapes[2 * RL + 1] == rd.w[0];
-    res_ok = res_ok && lstart[3] == rd.res_row0 + rd.h[0] * rd.w[0] && shapes[6] == rd.h[1] && shapes[7] == rd.w[1];
-    res_ok = res_ok && rd.res_row0 + rd.h[0] * rd.w[0] + rd.h[1] * rd.w[1] == dm.S;
-
-    {   // the slab's coarse rows -> LDS, 16 bytes per thread and step (plain copy: fp32 rows are consumed as stored)
-        const u32x4* src = reinterpret_cast<const u32x4*>(slab_base + (size_t)rd.res_row0 * 16);
-        const int ngran = rd.res_rows * 4, n0 = rd.h[0] * rd.w[0];
-        for (int g = threadIdx.x; g < ngran; g += kResThreads) {
-            int r = g >> 2;
-            const bool second = r >= n0;
-            r -= second ? n0 : 0;
-            const int wl = second ? rd.w[1] : rd.w[0];
-            const int y = r / wl, x = r - y * wl;
-            const unsigned at = (second ? lds_lvl1 : 0u) + (unsigned)y * (second ? rs1 : rs0) + (unsigned)x * 64u + (unsigned)(g & 3) * 16u;
-            *reinterpret_cast<u32x4*>(smem + at) = src[g];
-        }
-        if (threadIdx.x < 16) reinterpret_cast<unsigned*>(smem + zero_row)[threadIdx.x] = 0u;
-    }
-    __syncthreads();
-
-    const unsigned row_bytes = 64u;
-    const int Lq = dm.pairs_per_batch / dm.M;
-    const float* loc_b = loc_ + (size_t)b * Lq * dm.loc_row_elems;
-    const float* attn_b = attn_ + (size_t)b * Lq * dm.attn_row_elems;
-    const float* ref_b = ref + (size_t)b * Lq * 4 * dm.ref_dim;
-    float* out_b = out + (size_t)b * dm.pairs_per_batch * 32;
-    const unsigned lane_loc = 32u * m + 8u * lane, lane_attn = 16u * m + 4u * lane, lane_out = 32u * m + 16u * half + 4u * lane;
-    const int Hl = shapes[2 * lane], Wl = shapes[2 * lane + 1];
-    const bool lane_res = res_ok && lane >= RL;
-    const unsigned oor = lane_res ? zero_row : kOutOfRange;
-    const float Hf = (float)Hl, Wf = (float)Wl;
-    constexpr float kPxUnits = 64.0f / (float)kResRowPad;
-    const float row_units = lane_res ? kPxUnits * Wf + 1.0f : kPxUnits * Wf;
-    const unsigned w_bytes = (unsigned)Wl * 64u + (lane_res ? (unsigned)kResRowPad : 0u);
-    const unsigned base0 = lane_res ? (lane == RL ? 0u : lds_lvl1) : (unsigned)lstart[lane] * row_bytes;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(slab_base, (unsigned)dm.S * row_bytes);
-    const unsigned coff = (unsigned)lane * 16u;
-    const int run_lo = part * rd.runs_per_wg;
-    const int run_hi = min(run_lo + rd.runs_per_wg, rd.runs_per_slab);
-    unsigned char* aw_wr = aw + (4 * lane) * 256 + pl * 16;   // sample (level `lane`, point i) of pair pl: 16 bytes at (4 lane + i) * 256
-    const unsigned char* aw_rd = aw + pl * 16;
-
-    struct RunIn {
-        int run;
-        bool dead;
-        unsigned qc;
-        f32x4 l0, l1, ar, rv;
-    };
-    int next_index = wave;
-    auto next_run = [&]() -> RunIn {
-        RunIn in;
-        in.run = run_lo + next_index;
-        next_index += kResWaves;
-        const int q = in.run * 16 + pl;
-        in.dead = q >= Lq || in.run >= run_hi;
-        in.qc = (unsigned)min(q, Lq - 1);
-        const float* lp = loc_b + (in.qc * (unsigned)dm.loc_row_elems + lane_loc);
-        in.l0 = *reinterpret_cast<const f32x4*>(lp);
-        in.l1 = *reinterpret_cast<const f32x4*>(lp + 4);
-        in.ar = *reinterpret_cast<const f32x4*>(attn_b + (in.qc * (unsigned)dm.attn_row_elems + lane_attn));
-        const float* rp = ref_b + (in.qc * 4u + (unsigned)lane) * (unsigned)dm.ref_dim;
-        if (dm.ref_dim == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(rp);
-            in.rv = f32x4{v.x, v.y, 0.f, 0.f};
-        } else {
-            in.rv = *reinterpret_cast<const f32x4*>(rp);
-        }
-        return in;
-    };
-    RunIn cur = next_run();
-    while (cur.run < run_hi) {   // wave-uniform
-        const bool dead = cur.dead;
-        const unsigned qc = cur.qc;
-        // ---- stage 1: the 4 points of level `lane` of this quad's (query, head) pair (ms_deform_attn.py:119-133, exact fp32) --------
-        unsigned off[4][4];
-        {
-#pragma clang fp contract(off)
-            float x[4] = {cur.l0[0], cur.l0[2], cur.l1[0], cur.l1[2]}, y[4] = {cur.l0[1], cur.l0[3], cur.l1[1], cur.l1[3]};
-            float a[4] = {cur.ar[0], cur.ar[1], cur.ar[2], cur.ar[3]};
-            const float mx = quad_max(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = expf(a[i] - mx);
-            const float sum = quad_sum((a[0] + a[1]) + (a[2] + a[3]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = a[i] / sum;
-                if (dm.ref_dim == 2) {
-                    x[i] = cur.rv[0] + x[i] / Wf;
-                    y[i] = cur.rv[1] + y[i] / Hf;
-                } else {
-                    x[i] = cur.rv[0] + x[i] / (float)dm.P * cur.rv[2] * 0.5f;
-                    y[i] = cur.rv[1] + y[i] / (float)dm.P * cur.rv[3] * 0.5f;
-                }
-                float w4[4];
-                lean_sample(x[i], y[i], a[i], !dead, Hf, Wf, row_units, kPxUnits, base0, (unsigned)kResRowPad, row_bytes, w_bytes, oor, off[i], w4);
-                *reinterpret_cast<f32x4*>(aw_wr + i * 256) = f32x4{w4[0], w4[1], w4[2], w4[3]};
-            }
-        }
-        const RunIn nxt = next_run();
-        ALO_WAVE_LDS_ORDER();
-
-        // ---- stage 2: 16-byte pieces of the corner rows, v_pk_fma_f32 on this lane's four channels ---------------------------------------
-        f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
-        // two samples (8 corner pieces) in flight per step: four would cost 32 more registers than 12 waves per CU leave
-        auto consume = [&](const u32x4 (&raw)[2][4], int J, int p0) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const f32x4 wv = lds_read_f32x4(aw_rd, (unsigned)((4 * J + p0 + p) * 256));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x2 ww = {wv[k], wv[k]};
-                    acc01 = __builtin_elementwise_fma(ww, f32x2{__uint_as_float(raw[p][k].x), __uint_as_float(raw[p][k].y)}, acc01);
-                    acc23 = __builtin_elementwise_fma(ww, f32x2{__uint_as_float(raw[p][k].z), __uint_as_float(raw[p][k].w)}, acc23);
-                }
-            }
-        };
-#define ALO_F32_BUFFER(J)                                                                                                      \
-        _Pragma("unroll") for (int p0 = 0; p0 < 4; p0 += 2) {                                                                 \
-            u32x4 raw[2][4];                                                                                                   \
-            _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                     \
-            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                     \
-                raw[p][k] = Loader<float, float, 4>::load(rsrc, quad_bcast<J>(off[p0 + p][k]) + coff);                         \
-            consume(raw, J, p0);                                                                                               \
-        }
-#define ALO_F32_LDS(J)                                                                                                         \
-        _Pragma("unroll") for (int p0 = 0; p0 < 4; p0 += 2) {                                                                 \
-            u32x4 raw[2][4];                                                                                                   \
-            _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                     \
-            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                                     \
-                raw[p][k] = *reinterpret_cast<const u32x4*>(smem + (quad_bcast<J>(off[p0 + p][k]) + coff));                   \
-            consume(raw, J, p0);                                                                                               \
-        }
-        ALO_F32_BUFFER(0)
-        __builtin_amdgcn_sched_barrier(0);
-        ALO_F32_BUFFER(1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (res_ok) {   // wave-uniform
-            ALO_F32_LDS(2)
-            ALO_F32_LDS(3)
-        } else {        // the host's view of the pyramid is not the device's: every level through the buffer path
-            ALO_F32_BUFFER(2)
-            __builtin_amdgcn_sched_barrier(0);
-            ALO_F32_BUFFER(3)
-        }
-#undef ALO_F32_BUFFER
-#undef ALO_F32_LDS
-        if (!dead) *reinterpret_cast<f32x4*>(out_b + (qc * (unsigned)dm.M * 32u + lane_out)) = f32x4{acc01.x, acc01.y, acc23.x, acc23.y};
-        cur = nxt;
-        ALO_WAVE_LDS_ORDER();
-    }
-}
-
-// value (N, S, M, 32) fp32 -> (N, 2 M, S, 16): half-head-major, rows of padded pixels zeroed (`value.masked_fill(mask, 0)` of
-// ms_deform_attn.py:112-113 and the re-layout the kernel above wants, one pass)
-__global__ void __launch_bounds__(256)
-value_half_head_major_kernel(const float* __restrict__ value, const unsigned char* __restrict__ mask, float* __restrict__ out, int N, int S,
-                             int M) {
-    const long total = (long)N * S * M * 8;   // 16-byte pieces
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-        const int piece = (int)(idx & 7);
-        const long row = idx >> 3;            // (n, s, m)
-        const int m = (int)(row % M);
-        const long ns = row / M;
-        const int s = (int)(ns % S);
-        const long n = ns / S;
-        f32x4 v = *reinterpret_cast<const f32x4*>(value + idx * 4);
-        if (mask != nullptr && mask[ns]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(out + ((((n * 2 * M) + 2 * m + (piece >> 2)) * S + s) * 16 + (piece & 3) * 4)) = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, typename LT, typename CT, int VEC, int G, int LP_CT>
@@ -2049,62 +1835,6 @@ extern "C" int alo_msda_forward_fused_hm_resident(const void* value_hm, const in
 extern "C" int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq, int policy) {
     ResDims rd;
     return host_spatial_shapes ? resident_plan(host_spatial_shapes, N, S, M, L, Lq, policy, &rd) : 0;
-}
-
-extern "C" int alo_value_half_head_major(const void* value, const void* padding_mask, void* out, int N, int S, int M, int D, int dtype,
-                                         void* stream) {
-    ALO_REQUIRE(value && out, ALO_ERR_INVALID_ARGUMENT, "alo_value_half_head_major: null pointer argument");
-    ALO_REQUIRE(N > 0 && S > 0 && M > 0 && D == 32, ALO_ERR_UNSUPPORTED,
-                "alo_value_half_head_major: dimensions must be positive and D = 32 (N=%d S=%d M=%d D=%d)", N, S, M, D);
-    ALO_REQUIRE(dtype == ALO_F32, ALO_ERR_UNSUPPORTED, "alo_value_half_head_major: fp32 only (dtype %d)", dtype);
-    ALO_REQUIRE((((uintptr_t)value | (uintptr_t)out) & 15) == 0, ALO_ERR_INVALID_ARGUMENT, "alo_value_half_head_major: pointers must be 16-byte aligned");
-    long blocks = ((long)N * S * M * 8 + 255) / 256;
-    if (blocks > 256L * 32) blocks = 256L * 32;
-    void* args[] = {&value, &padding_mask, &out, &N, &S, &M};
-    hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(value_half_head_major_kernel), dim3((unsigned)blocks), dim3(256), args, 0,
-                                   static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_value_half_head_major: %s", hipGetErrorString(e));
-    return check_launch("alo_value_half_head_major");
-}
-
-extern "C" int alo_msda_forward_fused_hh_f32(const void* value_hh, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                                             const void* sampling_offsets, const void* attn_logits, long offsets_row_elems,
-                                             long logits_row_elems, const void* reference_points, void* out, int N, int S, int M, int D,
-                                             int L, int Lq, int P, int ref_dim, const int32_t* host_spatial_shapes, int policy,
-                                             void* stream_) {
-    ALO_REQUIRE(value_hh && spatial_shapes && level_start_index && sampling_offsets && attn_logits && reference_points && out &&
-                    host_spatial_shapes, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hh_f32: null pointer argument");
-    ALO_REQUIRE(N > 0 && S > 0 && M > 0 && Lq > 0, ALO_ERR_INVALID_ARGUMENT, "alo_msda_forward_fused_hh_f32: dimensions must be positive");
-    ALO_REQUIRE(D == 32 && L == 4 && P == 4, ALO_ERR_UNSUPPORTED, "alo_msda_forward_fused_hh_f32: needs D = 32, L = P = 4 (D=%d L=%d P=%d)", D, L, P);
-    ALO_REQUIRE(ref_dim == 2 || ref_dim == 4, ALO_ERR_INVALID_ARGUMENT,
-                "alo_msda_forward_fused_hh_f32: last dim of reference_points must be 2 or 4, got %d", ref_dim);
-    ALO_REQUIRE(offsets_row_elems >= (long)M * 32 && logits_row_elems >= (long)M * 16 && offsets_row_elems % 4 == 0 && logits_row_elems % 4 == 0 &&
-                    offsets_row_elems < (1L << 30) && logits_row_elems < (1L << 30), ALO_ERR_INVALID_ARGUMENT,
-                "alo_msda_forward_fused_hh_f32: row strides must cover a query's M*32 offsets / M*16 logits and keep 16-byte alignment");
-    ALO_REQUIRE((((uintptr_t)value_hh | (uintptr_t)sampling_offsets | (uintptr_t)attn_logits | (uintptr_t)out) & 15) == 0 &&
-                    (((uintptr_t)reference_points) & (ref_dim == 4 ? 15 : 7)) == 0, ALO_ERR_INVALID_ARGUMENT,
-                "alo_msda_forward_fused_hh_f32: pointers must be 16-byte aligned");
-    ALO_REQUIRE(S < (1 << 23) && (double)Lq * offsets_row_elems < 4.0e9 && (double)Lq * logits_row_elems < 4.0e9 && (double)Lq * M * 32 < 4.0e9 &&
-                    (double)Lq * 4 * ref_dim < 4.0e9, ALO_ERR_UNSUPPORTED, "alo_msda_forward_fused_hh_f32: 32-bit per-image offsets exceeded");
-    ResDims rd;
-    const int rl = resident_plan(host_spatial_shapes, N, S, 2 * M, L, Lq, policy, &rd);
-    ALO_REQUIRE(rl == 2, ALO_ERR_UNSUPPORTED,
-                "alo_msda_forward_fused_hh_f32: this launch does not take the LDS-resident kernel (ask alo_msda_resident_levels(shapes, N, S, "
-                "2 * M, L, Lq, policy) first and use alo_msda_forward_fused otherwise)");
-    Dims dm = make_dims(N, S, M, D, L, Lq, P, 16, 16384);
-    dm.ref_dim = ref_dim;
-    dm.loc_row_elems = (int)offsets_row_elems;
-    dm.attn_row_elems = (int)logits_row_elems;
-    dm.nblocks = (unsigned)((long)N * 2 * M * rd.wps);
-    const size_t lds = (size_t)rd.image_bytes + kResFixed + (size_t)kResWaves * kF32WaveLds;
-    static unsigned long long attr_done = 0;   // one bit per device
-    const void* fn = reinterpret_cast<const void*>(msda_fwd_f32_resident_kernel);
-    hipError_t ea = ensure_dynamic_lds(fn, kResLdsTotal, &attr_done);
-    if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hh_f32: %s", hipGetErrorString(ea));
-    void* rargs[] = {&value_hh, &spatial_shapes, &level_start_index, &sampling_offsets, &attn_logits, &reference_points, &out, &dm, &rd};
-    hipError_t el = hipLaunchKernel(fn, dim3(dm.nblocks), dim3(kResThreads), rargs, lds, static_cast<hipStream_t>(stream_));
-    if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_forward_fused_hh_f32: %s", hipGetErrorString(el));
-    return check_launch("alo_msda_forward_fused_hh_f32");
 }
 
 namespace {

@@ -146,22 +146,6 @@ int alo_msda_forward_fused_hm_resident(const void* value_hm, const int32_t* spat
 int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int N, int S, int M, int L, int Lq, int policy);
 
 /*
- * The same structure for FP32 values — the reference op's own dtype (ms_deform_attn_cuda.cu:64) — D = 32, L = P = 4 (extension;
- * csrc/msda.hip: msda_fwd_f32_resident_kernel).  An fp32 head row is 128 bytes and a slab's coarse levels do not fit in LDS, but half
- * a head does: alo_value_half_head_major re-lays value (N, S, M, 32) as (N, 2 M, S, 16) — rows of 64 bytes, padded pixels zeroed
- * (ms_deform_attn.py:112-113) — and alo_msda_forward_fused_hh_f32 runs the fused forward (raw offsets (N, Lq, M, L, P, 2), raw logits
- * (N, Lq, M, L * P), reference points, all fp32; row strides as in alo_msda_forward_fused_hm_rows) with levels 2-3 of every (image,
- * half head) slab resident in LDS: exact expf / divisions as the generic fp32 path, fp32 FMA accumulation.  It exists for launches
- * that take the resident kernel only: ask alo_msda_resident_levels(host_spatial_shapes, N, S, 2 * M, L, Lq, policy) == 2 first and
- * call alo_msda_forward_fused otherwise (the entry returns ALO_ERR_UNSUPPORTED instead of falling back).
- */
-int alo_value_half_head_major(const void* value, const void* padding_mask, void* out, int N, int S, int M, int D, int dtype, void* stream);
-int alo_msda_forward_fused_hh_f32(const void* value_hh, const int32_t* spatial_shapes, const int32_t* level_start_index,
-                                  const void* sampling_offsets, const void* attn_logits, long offsets_row_elems, long logits_row_elems,
-                                  const void* reference_points, void* out, int N, int S, int M, int D, int L, int Lq, int P, int ref_dim,
-                                  const int32_t* host_spatial_shapes, int policy, void* stream);
-
-/*
  * value (N, S, M, D) -> out (N, M, S, D), rows of padded pixels zeroed (padding_mask (N, S) uint8/bool, nullable):
  * MSDeformAttn's `value.masked_fill(input_padding_mask[..., None], 0)` (ms_deform_attn.py:112-113) and the re-layout
  * in one pass.  bf16, D % 8 == 0.

@@ -822,93 +822,3 @@ def test_resident_policy_auto_takes_the_kernel_that_is_faster_at_the_launch_size
             assert any(k.startswith("msda_fwd_fused_resident") for k in timer.summary()) == bool(expect), (N, shapes_l, mode)
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
 
-
-
-
-# ---- fp32 on the LDS-resident structure (alo_value_half_head_major + alo_msda_forward_fused_hh_f32) ----------------------------------
-def _f32_case(N, shapes_l, Lq, ref_dim, seed):
-    value, mask, offsets, logits, ref, shapes, start = _resident_case(N, shapes_l, Lq, ref_dim, seed)
-    return value.float(), mask, offsets.float(), logits.float(), ref, shapes, start
-
-
-@pytest.mark.parametrize("case", RESIDENT_CASES, ids=lambda c: f"N{c[0]}-{c[1][2][0]}x{c[1][2][1]}-Lq{c[2]}-ref{c[3]}")
-def test_f32_resident_forward_matches_the_generic_fp32_kernel_and_the_oracle(case):
-    """The reference op's own dtype on the resident structure (half-head-major value, levels 2-3 of every (image, half head) in LDS):
-    same function as the generic fused fp32 kernel (other order of the 64-term sum: 5e-6 of the largest output) and within 1e-5 of
-    the float64 oracle; borders, samples outside the map, padded pixels, box reference points, ragged last runs."""
-    N, shapes_l, Lq, ref_dim = case
-    value, mask, offsets, logits, ref, shapes, start = _f32_case(N, shapes_l, Lq, ref_dim, 141 + N)
-    Lq_ = offsets.shape[1]
-    assert alo_hip.msda_f32_resident_supported(value, shapes, Lq_, 4, 4, resident="always")
-    vhh = alo_hip.value_half_head_major(value, mask)
-    assert tuple(vhh.shape) == (N, 16, value.shape[1], 16)
-    with alo_hip.LaunchTimer() as timer:
-        got = alo_hip.msda_forward_fused_hh_f32(vhh, shapes, start, offsets, logits, ref, resident="always")
-    assert any(k.startswith("msda_fwd_fused_resident_f32") for k in timer.summary()), timer.summary().keys()
-    want = alo_hip.msda_forward_fused(value.masked_fill(mask[..., None, None], 0), shapes, start, offsets, logits, ref)
-    assert (got - want).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item())
-    sel = slice(0, None, 7)
-    loc, attn = _prologue_in_torch(offsets[:, sel].double(), logits[:, sel].double(), ref[:, sel].double(), shapes, 4)
-    exact = O.msda_forward(value.masked_fill(mask[..., None, None], 0).double().cpu().numpy(), shapes.cpu().numpy(),
-                           start.cpu().numpy(), loc.cpu().numpy(), attn.cpu().numpy())
-    assert np.abs(got[:, sel].double().cpu().numpy() - exact).max() <= 1e-5 * max(1.0, np.abs(exact).max())
-
-
-def test_f32_resident_forward_survives_a_wrong_host_copy_and_nan_outside_the_footprint():
-    """A host copy of the shapes that disagrees with the device's (same S) only costs speed — every level then takes the buffer path —
-    and NaN in pixels no sample touches never reaches an output (zero LDS row / buffer range check)."""
-    N, shapes_l = 2, [(40, 50), (20, 25), (10, 13), (5, 7)]
-    value, mask, offsets, logits, ref, shapes, start = _f32_case(N, shapes_l, None, 2, 155)
-    vhh = alo_hip.value_half_head_major(value, mask)
-    want = alo_hip.msda_forward_fused_hh_f32(vhh, shapes, start, offsets, logits, ref, resident="always")
-    wrong = torch.tensor(shapes_l, dtype=torch.int32, device=DEV)
-    wrong._alo_shapes = [(40, 50), (20, 25), (13, 10), (5, 7)]        # level 2 transposed: same S, another LDS image
-    got = alo_hip.msda_forward_fused_hh_f32(vhh, wrong, start, offsets, logits, ref, resident="always")
-    assert torch.equal(got, want)
-    offsets.zero_()
-    ref[:] = 0.25
-    vclean = alo_hip.value_half_head_major(value, None)
-    clean = alo_hip.msda_forward_fused_hh_f32(vclean, shapes, start, offsets, logits, ref, resident="always")
-    poisoned = vclean.clone()
-    st = level_start(shapes_l)
-    for lvl, (h, w) in enumerate(shapes_l):
-        keep = torch.zeros(h, w, dtype=torch.bool, device=DEV)
-        y, x = int(np.floor(0.25 * h - 0.5)), int(np.floor(0.25 * w - 0.5))
-        keep[y:y + 2, x:x + 2] = True
-        rows = torch.nonzero(~keep.view(-1)).view(-1) + int(st[lvl])
-        poisoned[:, :, rows] = float("nan")
-    got = alo_hip.msda_forward_fused_hh_f32(poisoned, shapes, start, offsets, logits, ref, resident="always")
-    assert torch.isfinite(got).all() and torch.equal(got, clean)
-
-
-def test_f32_resident_forward_full_size_and_inside_the_module():
-    """BASELINE shape of the encoder call in fp32 (N = 8, S = Lq = 22223): the AUTO policy takes the resident kernel; a strided query
-    subset + the tail against the float64 oracle; and MSDeformAttn in fp32 eval mode reaches it by itself (same output as the
-    generic fused kernel to 5e-6)."""
-    value, mask, offsets, logits, ref, shapes, start = _f32_case(8, DETR_SHAPES, None, 2, 99)
-    assert alo_hip.msda_f32_resident_supported(value, shapes, 22223, 4, 4)
-    vhh = alo_hip.value_half_head_major(value, mask)
-    got = alo_hip.msda_forward_fused_hh_f32(vhh, shapes, start, offsets, logits, ref)
-    vm = value.masked_fill(mask[..., None, None], 0)
-    for qsel in (slice(0, None, 61), slice(22223 - 40, None)):
-        loc, attn = _prologue_in_torch(offsets[:, qsel].double(), logits[:, qsel].double(), ref[:, qsel].double(), shapes, 4)
-        exact = O.msda_forward(vm.double().cpu().numpy(), shapes.cpu().numpy(), start.cpu().numpy(), loc.cpu().numpy(), attn.cpu().numpy())
-        assert np.abs(got[:, qsel].double().cpu().numpy() - exact).max() <= 1e-5 * max(1.0, np.abs(exact).max())
-    del vhh, got, vm
-    from alonet.deformable_detr.ops.modules import MSDeformAttn
-
-    torch.manual_seed(5)
-    attn_mod = MSDeformAttn(d_model=256, n_levels=4, n_heads=8, n_points=4).to(DEV).eval()
-    torch.nn.init.normal_(attn_mod.sampling_offsets.weight, std=0.02)
-    torch.nn.init.normal_(attn_mod.attention_weights.weight, std=0.05)
-    q = torch.randn(2, 22223, 256, device=DEV)
-    src = torch.randn(2, 22223, 256, device=DEV)
-    refp = ref[:2]
-    with torch.no_grad(), alo_hip.LaunchTimer() as timer:
-        out = attn_mod(q, refp, src, shapes, start, mask[:2])
-    assert any(k.startswith("msda_fwd_fused_resident_f32") for k in timer.summary()), timer.summary().keys()
-    plain_shapes = shapes.clone()                                   # no host copy attached: the generic fused kernel
-    with torch.no_grad(), alo_hip.LaunchTimer() as timer2:
-        out2 = attn_mod(q, refp, src, plain_shapes, start, mask[:2])
-    assert not any(k.startswith("msda_fwd_fused_resident_f32") for k in timer2.summary())
-    assert (out - out2).abs().max().item() <= 5e-6 * max(1.0, out2.abs().max().item())
