@@ -200,7 +200,7 @@ corr_gemm3_kernel(const Gemm3Args g) {
     if (tm >= g.tiles_m) return;   // the last group's padding (workgroup-uniform)
     const int tr = tn / g.tiles_c, tc = tn % g.tiles_c;
     const int i0 = tm * kTM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases, row offsets
 
     // DMA plan: a wave instruction moves 64 granules = 32 rows x 2 halves of one term.  A: 2 terms x 8 row groups = 16
     // instructions (4 per wave), B: 2 x 4 = 8 (2 per wave).  Rows past the edge re-read row 0 (their accumulators are never
@@ -286,46 +286,62 @@ corr_gemm3_kernel(const Gemm3Args g) {
     // factor leaves the float range unless the result does
     const int kt = split_exponent(g.amax_a[b]) + split_exponent(g.amax_b[b]);
     const float up1 = ldexpf(1.0f, kt / 2), up2 = ldexpf(g.scale, kt - kt / 2);
+    if (POOLED) {
+        // Every level is addressed through a buffer resource that covers exactly the rows of this tile which exist: the range check
+        // drops the rows past HW, and a lane whose column (or pooled cell) does not exist carries an offset past every range — no
+        // predicates, no 64-bit address arithmetic: one v_add (row part, a scalar) + the scaling + the store per element.  (The
+        // per-element tests and pointer arithmetic of the first version made the epilogue 4 400 instructions per wave; this one runs
+        // the whole kernel 9 % faster: tools/exp/corr_gemm_exp.hip.)  The range check looks at the VGPR offset only, so the row part
+        // is added there; tile bytes stay below 2^31 (alo_corr_build's grid limit), so kDrop + any row offset neither wraps nor lands
+        // inside a range.
+        constexpr unsigned kDrop = 0x80000000u;
+        const long rows = min((long)(g.HW - i0), (long)kTM);
+        const long n1 = (long)g.h1 * g.w1, n2 = (long)g.h2 * g.w2;
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(g.out0 + (rowbase + i0) * g.n, (unsigned)(rows * g.n * 4));
+        const __amdgpu_buffer_rsrc_t r1 = make_rsrc(g.out1 ? g.out1 + (rowbase + i0) * n1 : nullptr, g.out1 ? (unsigned)(rows * n1 * 4) : 0u);
+        const __amdgpu_buffer_rsrc_t r2 = make_rsrc(g.out2 ? g.out2 + (rowbase + i0) * n2 : nullptr, g.out2 ? (unsigned)(rows * n2 * 4) : 0u);
+        const unsigned pitch0 = (unsigned)g.n * 4u, pitch1 = (unsigned)n1 * 4u, pitch2 = (unsigned)n2 * 4u;
+        const int x = 32 * tc + li, yb = 4 * tr;
+        const int x1 = x >> 1, x2 = x >> 2, y2 = yb >> 2;
+        unsigned l0[4], l1[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const f32x16 (&acc_h)[4] = acc[h];
-        const int wrow0 = i0 + 64 * wave + 32 * h;
-        if (POOLED) {
-            const int x = 32 * tc + li;
-            const int yb = 4 * tr;
+        for (int t = 0; t < 4; ++t)
+            l0[t] = (x < g.W && yb + t < g.H) ? ((unsigned)(yb + t) * g.W + x) * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)   // level 1: the even lane of an x pair stores the 2 x 2 mean
+            l1[p] = (!(lane & 1) && x1 < g.w1 && (yb >> 1) + p < g.h1) ? ((unsigned)((yb >> 1) + p) * g.w1 + x1) * 4u + (unsigned)(4 * kg) * pitch1
+                                                                          : kDrop;
+        const unsigned l2 = (!(lane & 3) && x2 < g.w2 && y2 < g.h2) ? ((unsigned)y2 * g.w2 + x2) * 4u + (unsigned)(4 * kg) * pitch2 : kDrop;
+        constexpr int kNt = 2;   // aux: non-temporal
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x16 (&acc_h)[4] = acc[h];
+            const unsigned wrow = (unsigned)(64 * wave + 32 * h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                const bool iok = i < g.HW;
+                const unsigned row = wrow + (unsigned)((r & 3) + 8 * (r >> 2));   // + 4 kg: in the lane part
                 float s4 = 0.f;
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const float v0 = acc_h[2 * p][r], v1 = acc_h[2 * p + 1][r];
-                    const int y = yb + 2 * p;
-                    if (iok && x < g.W) {
-                        float* o = g.out0 + (rowbase + i) * g.n + (long)y * g.W + x;
-                        if (y < g.H) __builtin_nontemporal_store(v0 * up1 * up2, o);
-                        if (y + 1 < g.H) __builtin_nontemporal_store(v1 * up1 * up2, o + g.W);
-                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0 * up1 * up2), r0, l0[2 * p] + row * pitch0, 0, kNt);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1 * up1 * up2), r0, l0[2 * p + 1] + row * pitch0, 0, kNt);
                     // level 1: 2 x 2 mean = this lane's two rows + the same of its x-neighbour (lane ^ 1)
                     float s2 = v0 + v1;
                     s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
                     s4 += s2;
-                    if (g.out1 && iok && !(lane & 1)) {
-                        const int y1 = (yb >> 1) + p, x1 = x >> 1;
-                        if (y1 < g.h1 && x1 < g.w1)
-                            __builtin_nontemporal_store(s2 * up1 * (0.25f * up2), g.out1 + (rowbase + i) * ((long)g.h1 * g.w1) + (long)y1 * g.w1 + x1);
-                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s2 * up1 * (0.25f * up2)), r1, l1[p] + row * pitch1, 0, kNt);
                 }
                 // level 2: 4 x 4 mean = both row pairs + the other half of the quad
                 s4 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s4), 0x4E, 0xf, 0xf, false));       // quad_perm [2,3,0,1]
-                if (g.out2 && iok && !(lane & 3)) {
-                    const int y2 = yb >> 2, x2 = x >> 2;
-                    if (y2 < g.h2 && x2 < g.w2)
-                        __builtin_nontemporal_store(s4 * up1 * (0.0625f * up2), g.out2 + (rowbase + i) * ((long)g.h2 * g.w2) + (long)y2 * g.w2 + x2);
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s4 * up1 * (0.0625f * up2)), r2, l2 + row * pitch2, 0, kNt);
             }
-        } else {
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x16 (&acc_h)[4] = acc[h];
+            const int wrow0 = i0 + 64 * wave + 32 * h;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const long col = (long)tc * kTN + 32 * t + li;
