@@ -338,19 +338,28 @@ corr_gemm3_kernel(const Gemm3Args g) {
             }
         }
     } else {
+        // plain columns (pyramid levels >= 3 as extra contractions): the same addressing, one resource
+        constexpr unsigned kDrop = 0x80000000u;
+        const long rows = min((long)(g.HW - i0), (long)kTM);
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(g.out0 + (rowbase + i0) * g.n, (unsigned)(rows * g.n * 4));
+        const unsigned pitch0 = (unsigned)g.n * 4u;
+        unsigned l0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long col = (long)tc * kTN + 32 * t + li;
+            l0[t] = col < g.n ? (unsigned)col * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const f32x16 (&acc_h)[4] = acc[h];
-            const int wrow0 = i0 + 64 * wave + 32 * h;
+            const unsigned wrow = (unsigned)(64 * wave + 32 * h);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const long col = (long)tc * kTN + 32 * t + li;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    if (i < g.HW && col < g.n) __builtin_nontemporal_store(acc_h[t][r] * up1 * up2, g.out0 + (rowbase + i) * g.n + col);
+                    const unsigned row = wrow + (unsigned)((r & 3) + 8 * (r >> 2));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc_h[t][r] * up1 * up2), r0, l0[t] + row * pitch0, 0, 2 /* nt */);
                 }
-            }
         }
     }
 }
