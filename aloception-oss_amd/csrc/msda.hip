@@ -485,12 +485,18 @@ __device__ __forceinline__ void wave_prologue(const u32x4 lr, const u32x2 ar, fl
     for (int i = 0; i < 4; ++i) a[i] = __expf(a[i] - mx);
     const float inv = __builtin_amdgcn_rcpf(quad_sum((a[0] + a[1]) + (a[2] + a[3])));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a[i] *= inv;
-        if (ref_dim == 2) {
+    for (int i = 0; i < 4; ++i) a[i] *= inv;
+    // ONE wave-uniform branch around the four points (written inside the loop the compiler kept four diamonds, i.e. eight scalar
+    // branches per run that also cut the descriptor stage into small scheduling regions)
+    if (ref_dim == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             x[i] = __builtin_fmaf(x[i], inv_w, r0);
             y[i] = __builtin_fmaf(y[i], inv_h, r1);
-        } else {
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             x[i] = r0 + x[i] / (float)P * r2 * 0.5f;
             y[i] = r1 + y[i] / (float)P * r3 * 0.5f;
         }

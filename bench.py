@@ -706,11 +706,11 @@ def main():
             tframes = aloscene.Frame.batch_list(tframes).to(device)
             crit, opt = build_criterion(), configure_optimizers(tmodel)
             with alo_hip.LaunchTimer() as ttimer:
-                tsec = timed_steps(lambda: training_step(step_model, crit, opt, tframes)[0].item(), a.train_steps, 1, world, device)
+                tsec = timed_steps(lambda: training_step(step_model, crit, opt, tframes)[0].item(), a.train_steps, 2, world, device)
             tk = kernel_report(ttimer.summary())
             kernels.update({k + "[train]": v for k, v in tk.items()})
             train = {"metric": "frames/sec (whole node) DeformableDETR-R50 training step", "unit": "frames/s",
-                     "value": round(a.train_batch * world * a.train_steps / tsec, 3), "steps": a.train_steps, "warmup": 1,
+                     "value": round(a.train_batch * world * a.train_steps / tsec, 3), "steps": a.train_steps, "warmup": 2,
                      "ms_per_step": round(tsec / a.train_steps * 1e3, 2), "dtype": "f32",
                      "config": {"workload": f"forward + Hungarian match + set loss + backward (alo_msda_backward) + clip + AdamW, "
                                             f"{a.train_batch} synthetic 1333x800 frames x 10 boxes per GPU, global batch {a.train_batch * world}",
