@@ -30,6 +30,9 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
   g13_criterion.npz      (make_golden_criterion.py) the reference's DetrCriterion / DeformableCriterion + Hungarian matchers on a
                          seeded batch: matched indices per decoder level, every loss term, totals, monitoring metrics
   g9_posenc.npz          PositionEmbeddingSine on a partly padded map (centred and default variants)
+  g17_msda_trt_plugin_case.npz   the case the reference's TensorRT-plugin test feeds the same kernel (torch2trt/plugins/ms_deform_im2col/
+                         test.py:103-121: N, M, D = 1, 8, 32; Lq = 12000; levels 64^2 .. 8^2): seed + sha256 of the 24 MB of inputs,
+                         the reference's outputs for every 32nd query + the last 16 (float32 and float64)
   g14 / g14b / g15 / g16 (make_golden_models.py) the reference's DeformableDETR / Detr / PanopticHead forward + inference() over a
                          stub convolution pyramid, and the real aloscene.Frame's norm_* / batch_list
 
@@ -423,12 +426,42 @@ def g11(ref):
                         x=_np(x), fpn0=_np(fpns[0]), fpn1=_np(fpns[1]), fpn2=_np(fpns[2]), seg=_np(seg))
 
 
+def g17(ref):
+    """The case of the reference's TensorRT-plugin test for the same kernel (alonet/torch2trt/plugins/ms_deform_im2col/test.py:103-121:
+    N, M, D = 1, 8, 32; Lq, L, P = 12000, 4, 4; square levels 64 .. 8; value / locations ~ U(0, 1), weights normalised over L * P),
+    compared there with ms_deform_attn_core_pytorch.  The inputs are 24 MB of uniform noise: the fixture keeps the seed, a sha256 of
+    each input (the test re-draws them with the same torch CPU generator and checks the digests) and the reference's outputs for
+    every 32nd query + the last 16, in float32 (what that test compares) and float64."""
+    import hashlib
+
+    N, M, D, Lq, L, P = 1, 8, 32, 12000, 4, 4
+    shapes = torch.as_tensor([(64, 64), (32, 32), (16, 16), (8, 8)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    seed = 17
+    torch.manual_seed(seed)
+    value = torch.rand(N, S, M, D)
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    attn = torch.rand(N, Lq, M, L, P) + 1e-5
+    attn /= attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    out32 = ref.func.ms_deform_attn_core_pytorch(value, shapes, loc, attn)
+    out64 = ref.func.ms_deform_attn_core_pytorch(value.double(), shapes, loc.double(), attn.double())
+    keep = torch.cat([torch.arange(0, Lq, 32), torch.arange(Lq - 16, Lq)]).unique()
+    digest = lambda t: np.frombuffer(hashlib.sha256(_np(t).tobytes()).digest(), dtype=np.uint8)
+    np.savez_compressed(
+        os.path.join(OUT, "g17_msda_trt_plugin_case.npz"),
+        seed=np.int64(seed), dims=np.array([N, M, D, Lq, L, P], dtype=np.int64),
+        shapes=_np(shapes.to(torch.int32)), level_start=_np(_level_start(shapes)),
+        sha_value=digest(value), sha_loc=digest(loc), sha_attn=digest(attn),
+        keep=_np(keep), out_f32=_np(out32[:, keep]), out_f64=_np(out64[:, keep]),
+    )
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
     torch.set_num_threads(4)
     ref = load_reference()
-    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12)
+    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g17)
             if len(sys.argv) == 1 or fn.__name__ in sys.argv[1:]]   # `make_golden.py g12` regenerates one fixture
     for fn in todo:
         fn(ref)

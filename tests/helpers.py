@@ -107,3 +107,24 @@ def tied_formula_state_dict(model, seed=0, scale=None):
         for key in keys:
             sd[key] = sd[owner].clone()
     return sd
+
+
+def g17_inputs(g):
+    """Re-draws the inputs of the G17 fixture (the reference's TensorRT-plugin test case for the MSDA kernel: 24 MB of uniform noise,
+    kept as a seed) with torch's CPU generator, in the generator's call order, and checks them against the fixture's sha256 digests.
+    Returns (value, loc, attn) as float32 tensors, or None when this torch build draws a different stream."""
+    import hashlib
+
+    import torch
+
+    N, M, D, Lq, L, P = (int(v) for v in g["dims"])
+    S = int(np.prod(g["shapes"].astype(np.int64), axis=1).sum())
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    value = torch.rand(N, S, M, D, generator=gen)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=gen)
+    attn = torch.rand(N, Lq, M, L, P, generator=gen) + 1e-5
+    attn /= attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    for t, key in ((value, "sha_value"), (loc, "sha_loc"), (attn, "sha_attn")):
+        if hashlib.sha256(t.numpy().tobytes()).digest() != g[key].tobytes():
+            return None
+    return value, loc, attn

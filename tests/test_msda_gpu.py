@@ -73,6 +73,31 @@ def test_g8_known_answers(golden):
     np.testing.assert_allclose(hip_forward(c, torch.float32).cpu().numpy().ravel(), g["expected"], atol=1e-6)
 
 
+def test_g17_the_reference_trt_plugin_test_case_at_full_size(golden):
+    """The case the reference's TensorRT-plugin test feeds the same kernel (N, M, D = 1, 8, 32; Lq = 12000; levels 64^2 .. 8^2;
+    torch2trt/plugins/ms_deform_im2col/test.py:103-136), all 12000 queries through the op; the kept rows against the reference's own
+    outputs: float64 to rounding, float32 far inside the reference's bar, bf16 values within half a bf16 ulp of the result."""
+    from helpers import g17_inputs
+
+    g = golden("g17_msda_trt_plugin_case.npz")
+    drawn = g17_inputs(g)
+    assert drawn is not None, "torch's CPU generator draws another stream than the build the fixture was made with"
+    value, loc, attn = drawn
+    keep = torch.from_numpy(g["keep"]).to(DEV)
+    shapes, start = torch.from_numpy(g["shapes"]).to(DEV), torch.from_numpy(g["level_start"]).to(DEV)
+    want64, want32 = g["out_f64"], g["out_f32"]
+    out64 = alo_hip.msda_forward(value.double().to(DEV), shapes, start, loc.double().to(DEV), attn.double().to(DEV))[:, keep].cpu().numpy()
+    np.testing.assert_allclose(out64, want64, rtol=1e-12, atol=1e-14)
+    out32 = alo_hip.msda_forward(value.to(DEV), shapes, start, loc.to(DEV), attn.to(DEV))[:, keep].cpu().numpy()
+    np.testing.assert_allclose(out32, want32, rtol=1e-2, atol=1e-3)   # the reference's fp32 bar (ops/test.py:83)
+    err = np.abs(out32 - want64)
+    assert err.max() <= 5e-6 and err.mean() <= 5e-7, (err.max(), err.mean())   # what the plugin test prints: mean / max abs error
+    vb = value.to(torch.bfloat16)
+    outb = alo_hip.msda_forward(vb.to(DEV), shapes, start, loc.to(DEV), attn.to(DEV))[:, keep].float().cpu().numpy()
+    exact = O.msda_forward(vb.double().numpy(), g["shapes"], g["level_start"], loc[:, g["keep"]].double().numpy(), attn[:, g["keep"]].double().numpy())
+    assert np.all(np.abs(outb - exact) <= 2.0 ** -8 * np.abs(exact) + 1e-6)   # half a bf16 ulp is at most 2^-8 of the value
+
+
 # ---- oracle on seeded inputs: every kernel variant ---------------------------------------------------------------
 CASES = [  # (N, M, D, Lq, shapes, P)          which plan it exercises (fp32)
     (2, 8, 32, 77, [(16, 21), (8, 11), (4, 6), (2, 3)], 4),  # vec4 / group 8 / unrolled LP=16  (the DETR shape)

@@ -49,6 +49,24 @@ def test_g8_known_answers(golden):
     np.testing.assert_allclose(g["out"].ravel(), g["expected"], rtol=0, atol=1e-15)  # the reference agrees
 
 
+def test_g17_the_reference_trt_plugin_test_case(golden):
+    """N, M, D = 1, 8, 32; Lq = 12000; square levels 64 .. 8 (torch2trt/plugins/ms_deform_im2col/test.py:103-121): the C oracle on the
+    kept queries against the reference's float64 and float32 outputs."""
+    from helpers import g17_inputs
+
+    g = golden("g17_msda_trt_plugin_case.npz")
+    drawn = g17_inputs(g)
+    assert drawn is not None, "torch's CPU generator draws another stream than the build the fixture was made with"
+    value, loc, attn = drawn
+    keep = g["keep"]
+    l, a = loc[:, keep].numpy(), attn[:, keep].numpy()
+    out = O.msda_forward(value.numpy().astype(np.float64), g["shapes"], g["level_start"], l.astype(np.float64), a.astype(np.float64))
+    np.testing.assert_allclose(out, g["out_f64"], rtol=1e-12, atol=1e-14)
+    out32 = O.msda_forward(value.numpy(), g["shapes"], g["level_start"], l, a)
+    np.testing.assert_allclose(out32, g["out_f32"], rtol=1e-2, atol=1e-3)   # the reference's fp32 bar
+    np.testing.assert_allclose(out32, g["out_f64"], rtol=0, atol=5e-6)
+
+
 def test_f32_oracle_tracks_f64(golden):
     g = golden("g3_msda_medium.npz")
     args32 = [g[k].astype(np.float32) for k in ("value", "loc", "attn")]
