@@ -65,6 +65,8 @@ def _declare(lib):
     lib.alo_corr_build.argtypes = [vp, vp, c.POINTER(vp), vp, sz] + [ip] * 5 + [vp]
     lib.alo_corr_lookup.restype = ip
     lib.alo_corr_lookup.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
+    lib.alo_corr_lookup_backward.restype = ip
+    lib.alo_corr_lookup_backward.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
     lib.alo_corr_lookup_conv1x1_kpad.restype = ip
     lib.alo_corr_lookup_conv1x1_kpad.argtypes = [ip]
     lib.alo_corr_lookup_conv1x1.restype = ip
@@ -566,6 +568,29 @@ def corr_lookup(levels, coords, radius=4):
     with torch.cuda.device(coords.device), _timed("corr_lookup", nbytes):
         _check(lib().alo_corr_lookup(ptrs, _ptr(coords), _ptr(out), B, H, W, radius, L, _stream(coords.device)))
     return out
+
+
+def corr_lookup_backward(grad_levels, coords, grad_out, radius=4):
+    """Adds the pyramid gradients of ONE lookup to ``grad_levels`` (tensors shaped like the pyramid, zeroed by the caller before the
+    first lookup whose gradients are to be summed): the adjoint of :func:`corr_lookup` with respect to the levels (autograd through
+    the reference's bilinear_sampler, corr.py:29-50).  In place; returns ``grad_levels``."""
+    _require_f32_cuda("coords", coords, 4)
+    _require_f32_cuda("grad_out", grad_out, 4)
+    coords, grad_out = coords.contiguous(), grad_out.contiguous()
+    B, two, H, W = coords.shape
+    L = len(grad_levels)
+    if two != 2 or tuple(grad_out.shape) != (B, L * (2 * radius + 1) ** 2, H, W):
+        raise RuntimeError("corr_lookup_backward: coords must be (B,2,H,W) and grad_out (B, L*(2r+1)^2, H, W)")
+    for lvl, t in enumerate(grad_levels):
+        _require_f32_cuda(f"grad_levels[{lvl}]", t, 4)
+        if not t.is_contiguous() or t.shape[0] != B * H * W:
+            raise RuntimeError(f"grad_levels[{lvl}] must be a contiguous (B*H*W,1,h,w) tensor")
+    ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in grad_levels])
+    taps = (2 * radius + 2) ** 2
+    nbytes = 4.0 * B * H * W * (L * (2 * radius + 1) ** 2 + 2 * L * taps + 2)
+    with torch.cuda.device(coords.device), _timed("corr_lookup_backward", nbytes):
+        _check(lib().alo_corr_lookup_backward(ptrs, _ptr(coords), _ptr(grad_out), B, H, W, radius, L, _stream(coords.device)))
+    return grad_levels
 
 
 def corr_lookup_conv1x1_supported(levels, weight, radius):

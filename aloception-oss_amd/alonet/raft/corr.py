@@ -7,11 +7,22 @@ hook (alonet/raft/raft.py:47-60,168,185): ``CorrBlock(fmap1, fmap2, num_levels=4
 ``(B, num_levels*(2r+1)^2, H, W)`` float32 window features.  ``AlternateCorrBlock`` is not provided: the reference's
 version needs the absent third-party ``alt_cuda_corr`` extension and is unreachable (corr.py:5-9,86).
 
-Differentiability.  The reference's block is plain autograd-able torch code, so RAFT can be fine-tuned through it.  The HIP
-kernels are forward kernels; under autograd they run inside ``torch.autograd.Function`` s whose BACKWARD re-evaluates the torch
-formulation below (``pyramid_torch`` / ``lookup_torch`` — matmul, ``avg_pool2d``, ``grid_sample``) on the device and
-differentiates that: gradients are those of the reference's own graph, the forward values are the kernels'.  The backward
-holds a second copy of the volume while it runs (training crops are small; BASELINE.json trains no RAFT config).
+Differentiability.  The reference's block is plain autograd-able torch code, so RAFT can be fine-tuned through it.  Here, when
+the feature maps require a gradient:
+
+* the pyramid is built by the HIP kernel inside ``_BuildFunction``; its backward is the matmul's own gradient written out —
+  ``dF1 = P_l(F2) . dC_l^T / sqrt(C)``, ``dF2 = P_l^T(F1 . dC_l) / sqrt(C)`` summed over the levels that received a gradient, ``P_l`` =
+  l-fold 2x2 mean of the feature map (a mean over a cell of the correlation is the correlation with the cell's mean feature) — as
+  library GEMMs (``torch.bmm``) over the gradient maps: the volume is never re-evaluated and no second copy of it is held;
+* a lookup runs the HIP kernel inside ``_LookupFunction``; its backward is the kernel's exact adjoint
+  (``alo_corr_lookup_backward``), ACCUMULATED into gradient maps shared by all lookups of the block (RAFT looks the pyramid up 32
+  times; autograd through ``grid_sample`` would materialise a dense gradient of the whole volume for each).  The maps reach
+  ``_BuildFunction.backward`` through a scalar token every lookup depends on, not as dense autograd gradients;
+* a gradient with respect to the COORDINATES (RAFT detaches them, raft.py:186; the reference's block is differentiable there too)
+  comes from the torch formulation below, differentiated with respect to the coordinates only;
+* ``corr_pyramid`` tensors used directly in somebody's own graph receive dense gradients the ordinary way; they are added to the
+  accumulated maps.
+Without gradients nothing of this exists: ``CorrBlock`` is two kernel calls.
 """
 import math
 
@@ -62,34 +73,108 @@ class TorchCorrBlock:
         return pyramid_torch(fmap1, fmap2, 1)[0].view(B, H, W, 1, H, W)
 
 
-# ---- HIP forward, torch-formulation backward -----------------------------------------------------------------------------------
+# ---- HIP forward and backward ----------------------------------------------------------------------------------------------------
 def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+class _PyramidState:
+    """What the build node and the lookup nodes of one CorrBlock share: the pyramid and, during a backward pass, the gradient maps
+    the lookups accumulate into."""
+
+    def __init__(self):
+        self.pyramid = None
+        self.grad = None
+
+    def grad_maps(self):
+        if self.grad is None:
+            self.grad = [torch.zeros_like(p) for p in self.pyramid]
+        return self.grad
+
+
+def _pooled_chain(fmap, num_levels):
+    """[fmap, 2x2 mean of it, ...]: what the pyramid's level l correlates fmap1 with (avg_pool2d drops an odd last row / column on
+    the volume and on the feature map alike)."""
+    chain = [fmap]
+    for _ in range(num_levels - 1):
+        chain.append(F.avg_pool2d(chain[-1], 2, stride=2))
+    return chain
+
+
 class _BuildFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fmap1, fmap2, num_levels):
+    def forward(ctx, fmap1, fmap2, num_levels, state):
         ctx.save_for_backward(fmap1, fmap2)
         ctx.num_levels = num_levels
-        return tuple(alo_hip.corr_build(fmap1, fmap2, num_levels))
+        ctx.state = state
+        state.pyramid = alo_hip.corr_build(fmap1, fmap2, num_levels)
+        token = fmap1.new_zeros(())   # every lookup takes it as an input: autograd runs them all before this node's backward
+        # the outputs are VIEWS: autograd hangs this node on them, and the state (which this node holds) must not hold the node back
+        return (token,) + tuple(p.view_as(p) for p in state.pyramid)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, *grads):
+    def backward(ctx, _gtoken, *grads):
         fmap1, fmap2 = ctx.saved_tensors
+        state = ctx.state
+        sparse, state.grad = state.grad, None   # a later backward pass through the same graph starts from zero again
+        totals = []
+        for lvl in range(ctx.num_levels):
+            parts = [g for g in (grads[lvl], sparse[lvl] if sparse is not None else None) if g is not None]
+            totals.append(None if not parts else (parts[0] if len(parts) == 1 else parts[0] + parts[1]))
+        if all(t is None for t in totals):
+            return None, None, None, None
+        B, C, H, W = fmap1.shape
+        scale = 1.0 / math.sqrt(C)
+        f1 = fmap1.reshape(B, C, H * W)
+        g1 = torch.zeros_like(f1) if ctx.needs_input_grad[0] else None
+        g2 = None
         with torch.enable_grad():
-            a = fmap1.detach().requires_grad_(ctx.needs_input_grad[0])
-            b = fmap2.detach().requires_grad_(ctx.needs_input_grad[1])
-            pyramid = pyramid_torch(a, b, ctx.num_levels)
-            pairs = [(p, g) for p, g in zip(pyramid, grads) if g is not None]
-            wrt = [t for t in (a, b) if t.requires_grad]
-            got = torch.autograd.grad([p for p, _ in pairs], wrt, [g for _, g in pairs], allow_unused=True) if pairs and wrt else ()
-        it = iter(got)
-        return (next(it) if a.requires_grad and pairs else None, next(it) if b.requires_grad and pairs else None, None)
+            leaf = fmap2.detach().requires_grad_(ctx.needs_input_grad[1])
+            chain = _pooled_chain(leaf, ctx.num_levels)
+        heads, head_grads = [], []
+        for lvl, t in enumerate(totals):
+            if t is None:
+                continue
+            n = chain[lvl].shape[-2] * chain[lvl].shape[-1]
+            dvol = t.reshape(B, H * W, n)                                   # d loss / d vol_l[b, i, j]
+            if g1 is not None:                                              # sum_j dvol[i, j] * P_l(F2)[c, j]
+                g1.baddbmm_(chain[lvl].detach().reshape(B, C, n), dvol.transpose(1, 2), alpha=scale)
+            if ctx.needs_input_grad[1]:                                     # sum_i dvol[i, j] * F1[c, i], then back through the means
+                heads.append(chain[lvl])
+                head_grads.append((torch.bmm(f1, dvol) * scale).reshape(chain[lvl].shape))
+        if heads:
+            (g2,) = torch.autograd.grad(heads, leaf, head_grads)
+        return (g1.reshape(fmap1.shape) if g1 is not None else None), g2, None, None
 
 
 class _LookupFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coords, token, radius, state):
+        ctx.save_for_backward(coords)
+        ctx.radius = radius
+        ctx.state = state
+        return alo_hip.corr_lookup(state.pyramid, coords, radius)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        (coords,) = ctx.saved_tensors
+        state = ctx.state
+        gcoords = None
+        if ctx.needs_input_grad[0]:
+            with torch.enable_grad():
+                c = coords.detach().requires_grad_(True)
+                (gcoords,) = torch.autograd.grad(lookup_torch([p.detach() for p in state.pyramid], c, ctx.radius), c, grad_out)
+        if ctx.needs_input_grad[1]:
+            alo_hip.corr_lookup_backward(state.grad_maps(), coords, grad_out, ctx.radius)
+        return gcoords, (coords.new_zeros(()) if ctx.needs_input_grad[1] else None), None, None
+
+
+class _LookupDenseFunction(torch.autograd.Function):
+    """A lookup into pyramid tensors that did not come out of ``_BuildFunction`` under autograd (somebody's own differentiable
+    pyramid, or coordinates that want a gradient while the features do not): the torch formulation differentiates it."""
+
     @staticmethod
     def forward(ctx, coords, radius, *pyramid):
         ctx.save_for_backward(coords, *pyramid)
@@ -114,8 +199,11 @@ class CorrBlock:
         self.num_levels = num_levels
         self.radius = radius
         fmap1, fmap2 = fmap1.float(), fmap2.float()
+        self._state = self._token = None
         if _needs_grad(fmap1, fmap2):
-            self.corr_pyramid = list(_BuildFunction.apply(fmap1.contiguous(), fmap2.contiguous(), num_levels))
+            self._state = _PyramidState()
+            self._token, *pyramid = _BuildFunction.apply(fmap1.contiguous(), fmap2.contiguous(), num_levels, self._state)
+            self.corr_pyramid = list(pyramid)
         else:
             self.corr_pyramid = alo_hip.corr_build(fmap1, fmap2, num_levels)
 
@@ -132,8 +220,11 @@ class CorrBlock:
 
     def __call__(self, coords):
         coords = coords.float()
+        if (self._state is not None and torch.is_grad_enabled() and len(self.corr_pyramid) == len(self._state.pyramid)
+                and all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(self.corr_pyramid, self._state.pyramid))):
+            return _LookupFunction.apply(coords.contiguous(), self._token, self.radius, self._state)
         if _needs_grad(coords, *self.corr_pyramid):
-            return _LookupFunction.apply(coords.contiguous(), self.radius, *self.corr_pyramid)
+            return _LookupDenseFunction.apply(coords.contiguous(), self.radius, *self.corr_pyramid)
         return alo_hip.corr_lookup(self.corr_pyramid, coords, self.radius)
 
     @staticmethod
@@ -142,7 +233,7 @@ class CorrBlock:
         B, _, H, W = fmap1.shape
         fmap1, fmap2 = fmap1.float(), fmap2.float()
         if _needs_grad(fmap1, fmap2):
-            (vol,) = _BuildFunction.apply(fmap1.contiguous(), fmap2.contiguous(), 1)
+            _, vol = _BuildFunction.apply(fmap1.contiguous(), fmap2.contiguous(), 1, _PyramidState())
         else:
             (vol,) = alo_hip.corr_build(fmap1, fmap2, 1)
         return vol.view(B, H, W, 1, H, W)

@@ -538,6 +538,114 @@ corr_lookup_kernel(const LookupArgs a) {
     }
 }
 
+// Backward of the lookup with respect to the pyramid (the reference's block is plain torch code — bilinear_sampler = grid_sample —
+// so autograd differentiates it, corr.py:29-50; RAFT detaches the coordinates before every lookup, raft.py:186): the exact adjoint of
+// the kernel above, ACCUMULATED into gradient maps of the pyramid's own layout.  A query's window lies in its own row of every level,
+// so nothing another query touches: a workgroup serves one (32-query tile, level), thread (query, staged row) gathers the row's
+// share of the tile's output gradients (vertical weights of the taps that read it), spreads it horizontally over the row's 2r + 3
+// staged columns and adds them to the map with plain loads and stores — no atomics, and the 32 lookups of a RAFT forward add into the
+// same maps one launch after the other instead of each materialising a dense gradient of the whole volume (what autograd does with
+// grid_sample's backward: 4.4 GB per lookup at 720p).  Tap positions, shifts and weights are computed exactly as in strip_finish.
+struct LookupBwdArgs {
+    float* glvl[kMaxPyr];
+    int h[kMaxPyr], w[kMaxPyr];
+    const float* coords;
+    const float* gout;
+    int B, HW, num_levels, tiles_per_batch;
+};
+
+template <int R>
+__global__ void __launch_bounds__(lookup_threads<R>())
+corr_lookup_bwd_kernel(const LookupBwdArgs a) {
+    constexpr int NT = lookup_threads<R>();
+    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, COLS = WIN + 2;
+    __shared__ float gbuf[WIN * WIN * TQ];   // the tile's output gradients of this level: [ax * WIN + cy][query]
+    __shared__ float tybuf[WIN * TQ];
+    __shared__ int rowbuf[WIN * TQ];
+    const int b = blockIdx.x / a.tiles_per_batch;
+    const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
+    const int l = blockIdx.y, tid = threadIdx.x;
+    const int h = a.h[l], w = a.w[l];
+    const int CH = a.num_levels * WIN * WIN;
+    for (int o = tid; o < WIN * WIN * TQ; o += NT) {
+        const int q = o % TQ, rem = o / TQ, i = q0 + q;
+        gbuf[o] = i < a.HW ? a.gout[((long)b * CH + l * WIN * WIN + rem) * a.HW + i] : 0.f;
+    }
+    const int q = tid % TQ, row = tid / TQ, i = q0 + q;
+    bool ok = tid < ROWS * TQ && i < a.HW;
+    float cx = 0.f, cy = 0.f;
+    int xb = 0, yb = 0;
+    if (ok) {
+        const float inv = 1.0f / (float)(1 << l);
+        cx = a.coords[((long)b * 2 + 0) * a.HW + i] * inv;
+        cy = a.coords[((long)b * 2 + 1) * a.HW + i] * inv;
+        const float iy0 = round_trip(cy - (float)R, h), ix0 = round_trip(cx - (float)R, w);
+        ok = fabsf(iy0) < 1e6f && fabsf(ix0) < 1e6f;   // NaN too: such queries read (and therefore spread) nothing
+        if (ok) {
+            yb = (int)floorf(iy0);
+            xb = (int)floorf(ix0);
+        }
+    }
+    if (tid < WIN * TQ) {   // rows 0 .. WIN - 1 double as the window's tap rows: where tap row `row` reads, and with which fraction
+        float ty = 0.f;
+        int trow = row;
+        if (ok) {
+            const float iy = round_trip(cy + (float)(row - R), h);
+            int d = (int)floorf(iy) - (yb + row);
+            d = d < -1 ? -1 : (d > 1 ? 1 : d);
+            if (row == 0) d = 0;
+            trow = row + d;
+            ty = iy - (float)(yb + trow);
+        }
+        tybuf[row * TQ + q] = ty;
+        rowbuf[row * TQ + q] = trow;
+    }
+    __syncthreads();
+    const int ry = yb + row;
+    if (!ok || ry < 0 || ry >= h) return;   // rows outside the map were read as zeros
+    // vertical adjoint: tap row c read staged rows trow_c (weight 1 - ty_c) and trow_c + 1 (weight ty_c)
+    float gh[WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) gh[k] = 0.f;
+    for (int c = 0; c < WIN; ++c) {
+        const int r0 = rowbuf[c * TQ + q];
+        const float ty = tybuf[c * TQ + q];
+        const float wgt = r0 == row ? 1.0f - ty : (r0 + 1 == row ? ty : 0.f);
+        if (r0 == row || r0 + 1 == row) {
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) gh[k] += wgt * gbuf[(k * WIN + c) * TQ + q];
+        }
+    }
+    // horizontal adjoint: tap column k read staged columns k + d and k + d + 1
+    float gv[COLS];
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) gv[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) {
+        const float ix = round_trip(cx + (float)(k - R), w);
+        int d = (int)floorf(ix) - (xb + k);
+        d = (k == 0) ? 0 : (d < -1 ? -1 : (d > 1 ? 1 : d));
+        const float tx = ix - (float)(xb + k + d);
+        const float lo = (1.0f - tx) * gh[k], hi = tx * gh[k];
+        if (d == 0) {
+            gv[k] += lo;
+            gv[k + 1] += hi;
+        } else if (d > 0) {
+            gv[k + 1] += lo;
+            gv[k + 2] += hi;
+        } else {
+            gv[k > 0 ? k - 1 : 0] += lo;
+            gv[k] += hi;
+        }
+    }
+    float* dst = a.glvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+        const int x = xb + j;
+        if (x >= 0 && x < w) dst[x] += gv[j];
+    }
+}
+
 // Lookup fused with the 1x1 convolution that consumes it: the window features never leave the chip.  RAFT's motion encoder
 // reads them in `convc1` (update.py:83-101: L*(2r+1)^2 -> Cout channels, + bias, ReLU); here that contraction runs level by
 // level on the bf16 matrix cores at fp32 accuracy (the volume itself uses the two-term fp16 form; here its per-query scaling pass
@@ -691,6 +799,12 @@ int launch_lookup_conv(const LookupArgs& a, const ConvArgs& cv, hipStream_t stre
     }
     hipLaunchKernelGGL(corr_lookup_conv_kernel<R>, dim3(a.B * a.tiles_per_batch), dim3(kConvThreads), ConvLds<R>::bytes, stream, a, cv);
     return check_launch("alo_corr_lookup_conv1x1");
+}
+
+template <int R>
+int launch_lookup_bwd(const LookupBwdArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(corr_lookup_bwd_kernel<R>, dim3(a.B * a.tiles_per_batch, a.num_levels), dim3(lookup_threads<R>()), 0, stream, a);
+    return check_launch("alo_corr_lookup_backward");
 }
 
 int fill_lookup_args(LookupArgs& a, const float* const* levels, const float* coords, float* out, int B, int H, int W, int radius,
@@ -865,6 +979,42 @@ extern "C" int alo_corr_lookup(const float* const* levels, const float* coords, 
         case 5: return launch_lookup<5>(a, stream);
         case 6: return launch_lookup<6>(a, stream);
         default: return launch_lookup<7>(a, stream);
+    }
+}
+
+extern "C" int alo_corr_lookup_backward(float* const* grad_levels, const float* coords, const float* grad_out, int B, int H, int W,
+                                        int radius, int num_levels, void* stream_) {
+    const char* what = "alo_corr_lookup_backward";
+    ALO_REQUIRE(grad_levels && coords && grad_out, ALO_ERR_INVALID_ARGUMENT, "%s: null pointer argument", what);
+    ALO_REQUIRE(B > 0 && H > 0 && W > 0, ALO_ERR_INVALID_ARGUMENT, "%s: dimensions must be positive", what);
+    ALO_REQUIRE(radius >= 0 && radius <= 7, ALO_ERR_UNSUPPORTED, "%s: radius must be in [0,7], got %d", what, radius);
+    ALO_REQUIRE(num_levels >= 1 && num_levels <= kMaxPyr, ALO_ERR_INVALID_ARGUMENT, "%s: num_levels must be in [1,%d], got %d", what,
+                kMaxPyr, num_levels);
+    LookupBwdArgs a;
+    for (int l = 0; l < kMaxPyr; ++l) { a.glvl[l] = nullptr; a.h[l] = a.w[l] = 2; }
+    for (int l = 0; l < num_levels; ++l) {
+        ALO_REQUIRE(grad_levels[l], ALO_ERR_INVALID_ARGUMENT, "%s: grad_levels[%d] is null", what, l);
+        alo_corr_level_shape(H, W, l, &a.h[l], &a.w[l]);
+        ALO_REQUIRE(a.h[l] >= 2 && a.w[l] >= 2, ALO_ERR_INVALID_ARGUMENT,
+                    "%s: level %d is %dx%d; the reference divides by (size-1) and needs >= 2", what, l, a.h[l], a.w[l]);
+        a.glvl[l] = grad_levels[l];
+    }
+    a.coords = coords;
+    a.gout = grad_out;
+    a.B = B;
+    a.HW = H * W;
+    a.num_levels = num_levels;
+    a.tiles_per_batch = (a.HW + TQ - 1) / TQ;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    switch (radius) {
+        case 0: return launch_lookup_bwd<0>(a, stream);
+        case 1: return launch_lookup_bwd<1>(a, stream);
+        case 2: return launch_lookup_bwd<2>(a, stream);
+        case 3: return launch_lookup_bwd<3>(a, stream);
+        case 4: return launch_lookup_bwd<4>(a, stream);
+        case 5: return launch_lookup_bwd<5>(a, stream);
+        case 6: return launch_lookup_bwd<6>(a, stream);
+        default: return launch_lookup_bwd<7>(a, stream);
     }
 }
 

@@ -234,6 +234,25 @@ int alo_corr_lookup(const float* const* levels, const float* coords, float* out,
                     int B, int H, int W, int radius, int num_levels, void* stream);
 
 /*
+ * Backward of alo_corr_lookup with respect to the pyramid: the exact adjoint of the lookup, ACCUMULATED into gradient maps.
+ * The reference's CorrBlock is plain torch code (alonet/raft/corr.py:29-50: bilinear_sampler = F.grid_sample) that autograd
+ * differentiates; RAFT detaches the coordinates before every lookup (alonet/raft/raft.py:186), so this is the gradient a RAFT
+ * training step needs from the block.  (The gradient with respect to the coordinates is not provided here.)
+ *
+ *   grad_levels[l][b*HW + y*W + x, :, :] += sum over the window taps (a, c) of
+ *                                           grad_out[b, l*(2r+1)^2 + a*(2r+1) + c, y, x] * bilinear weights of that tap
+ *
+ *   grad_levels  HOST array of num_levels DEVICE pointers, each (B*H*W, 1, h_l, w_l) float32 like the pyramid: read-modify-write
+ *                (zero them before the first of the lookups whose gradients are to be summed; successive calls on one stream add up)
+ *   coords       (B, 2, H, W) float32, the coordinates the forward lookup was given
+ *   grad_out     (B, num_levels*(2r+1)^2, H, W) float32, contiguous
+ * A query's window lies in its own (h_l, w_l) map on every level, so no two threads ever add to the same element: plain loads and
+ * stores, deterministic.  Same limits as alo_corr_lookup.
+ */
+int alo_corr_lookup_backward(float* const* grad_levels, const float* coords, const float* grad_out,
+                             int B, int H, int W, int radius, int num_levels, void* stream);
+
+/*
  * The lookup above fused with the 1x1 convolution that consumes it in RAFT's motion encoder (update.py:83-101, `convc1`:
  * L*(2r+1)^2 -> Cout channels, + bias, ReLU): the (B, L*(2r+1)^2, H, W) window features are never written.
  *

@@ -299,8 +299,9 @@ def test_config3_build_and_lookup_at_batch4_720p():
 
 def test_hip_corr_block_under_autograd_has_the_gradients_of_the_torch_formulation():
     """The reference's CorrBlock is differentiable torch code (corr.py:12-60).  Here the forward is the HIP kernels whatever the
-    grad mode; under autograd their backward re-evaluates the torch formulation: gradients w.r.t. both feature maps (through the
-    pyramid AND the lookup) and w.r.t. the coordinates must equal those of TorchCorrBlock."""
+    grad mode; under autograd the lookup's backward is the kernel's adjoint (accumulated maps), the build's two GEMMs per level, the
+    coordinates' the torch formulation: gradients w.r.t. both feature maps (through the lookup AND through pyramid tensors used
+    directly in the loss) and w.r.t. the coordinates must equal those of TorchCorrBlock."""
     from alonet.raft.corr import TorchCorrBlock
 
     gen = torch.Generator(device="cpu").manual_seed(17)
@@ -328,6 +329,91 @@ def test_hip_corr_block_under_autograd_has_the_gradients_of_the_torch_formulatio
     # no autograd graph: the plain kernels, no Function objects in the way
     with torch.no_grad():
         assert not CorrBlock(a, f2)(coords).requires_grad
+
+
+@pytest.mark.parametrize("B,H,W,r,L", [(1, 16, 24, 4, 4), (2, 9, 13, 3, 2), (1, 17, 18, 1, 3), (2, 8, 8, 0, 1), (1, 33, 20, 2, 4), (1, 40, 64, 7, 3)])
+def test_lookup_backward_is_the_adjoint_of_the_lookup(B, H, W, r, L):
+    """alo_corr_lookup_backward against autograd through the torch formulation (the reference's bilinear_sampler = grid_sample,
+    corr.py:29-50) with respect to every pyramid level: coordinates inside, on integer positions, across every border, far outside
+    and non-finite; two calls accumulate; the result does not depend on the order of anything (plain loads and stores)."""
+    from alonet.raft.corr import lookup_torch
+
+    gen = torch.Generator(device="cpu").manual_seed(100 * H + W + r)
+    pyr = []
+    for lvl in range(L):
+        h, w = H // 2 ** lvl, W // 2 ** lvl
+        pyr.append(torch.randn(B * H * W, 1, h, w, generator=gen).to(DEV))
+    coords = coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 3.0
+    coords[:, :, 0, :] = torch.round(coords[:, :, 0, :])                       # integer positions: a weight is exactly zero
+    coords[:, 0, 1, :] = -float(r) - 2.5                                       # window entirely left of the map
+    coords[:, 1, 2, :] = float(H) + 0.25                                       # window straddling the lower border
+    if H > 4:
+        coords[:, :, 3, 0] = float("nan")
+        coords[:, :, 3, 1] = 3e7
+    gout = torch.randn(B, L * (2 * r + 1) ** 2, H, W, generator=gen).to(DEV)
+    leaves = [p.clone().requires_grad_(True) for p in pyr]
+    ref_out = lookup_torch(leaves, coords, r)
+    finite = torch.isfinite(ref_out)                                           # the torch formulation turns NaN coordinates into NaN features;
+    want = torch.autograd.grad(ref_out, leaves, torch.where(finite, gout, torch.zeros_like(gout)))   # the kernels read them as zeros
+    want = [torch.nan_to_num(g, nan=0.0) for g in want]
+    got = [torch.zeros_like(p) for p in pyr]
+    assert alo_hip.corr_lookup_backward(got, coords, gout, r) is got
+    for lvl, (g, w_) in enumerate(zip(got, want)):
+        assert (g - w_).abs().max().item() <= 2e-5 * max(1.0, w_.abs().max().item()), lvl
+    again = [g.clone() for g in got]
+    alo_hip.corr_lookup_backward(again, coords, gout, r)                       # accumulates
+    for g, a in zip(got, again):
+        assert torch.equal(a, 2 * g)
+    # <lookup(P), G> == <P, lookup_backward(G)> for the kernels themselves (fp32 sums of ~1e5 terms: 1e-4 relative)
+    fwd = alo_hip.corr_lookup(pyr, coords, r)
+    lhs = (fwd.double() * gout.double()).sum().item()
+    rhs = sum((p.double() * g.double()).sum().item() for p, g in zip(pyr, got))
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_corr_block_gradients_over_many_lookups_and_repeated_backward():
+    """RAFT's pattern: one pyramid, many lookups at moving (detached) coordinates, one backward — the lookups accumulate into shared
+    gradient maps that the build node turns into feature gradients with two GEMMs per level.  Gradients equal those of the torch
+    formulation; a second backward through the retained graph gives the same result (the maps start from zero again); odd sizes."""
+    from alonet.raft.corr import TorchCorrBlock
+
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    B, C, H, W = 2, 40, 15, 22
+    f1 = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    f2 = torch.randn(B, C, H, W, generator=gen).to(DEV)
+    steps = [coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * (1.0 + k) for k in range(5)]
+    wts = [torch.randn(B, 3 * 49, H, W, generator=gen).to(DEV) for _ in steps]
+    res = {}
+    for name, cls in (("hip", CorrBlock), ("torch", TorchCorrBlock)):
+        a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        blk = cls(a, b, num_levels=3, radius=3)
+        loss = sum((blk(c) * w_).sum() for c, w_ in zip(steps, wts))
+        loss.backward(retain_graph=True)
+        first = (a.grad.clone(), b.grad.clone())
+        a.grad = b.grad = None
+        loss.backward()
+        res[name] = (first, (a.grad, b.grad))
+    for k in range(2):
+        assert torch.equal(res["hip"][0][k], res["hip"][1][k])                 # deterministic, and nothing left over from the first pass
+        want = res["torch"][0][k]
+        assert (res["hip"][0][k] - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item())
+    # only one of the two feature maps trains
+    a = f1.clone().requires_grad_(True)
+    blk = CorrBlock(a, f2, num_levels=3, radius=3)
+    sum((blk(c) * w_).sum() for c, w_ in zip(steps, wts)).backward()
+    assert (a.grad - res["torch"][0][0]).abs().max().item() <= 2e-4 * max(1.0, res["torch"][0][0].abs().max().item())
+    b = f2.clone().requires_grad_(True)
+    blk = CorrBlock(f1, b, num_levels=3, radius=3)
+    sum((blk(c) * w_).sum() for c, w_ in zip(steps, wts)).backward()
+    assert (b.grad - res["torch"][0][1]).abs().max().item() <= 2e-4 * max(1.0, res["torch"][0][1].abs().max().item())
+    # CorrBlock.corr (the volume alone) is differentiable the same way
+    a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    g = torch.randn(B, H, W, 1, H, W, generator=gen).to(DEV)
+    (CorrBlock.corr(a, b) * g).sum().backward()
+    a2, b2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    (TorchCorrBlock.corr(a2, b2) * g).sum().backward()
+    assert (a.grad - a2.grad).abs().max().item() <= 2e-4 * max(1.0, a2.grad.abs().max().item())
+    assert (b.grad - b2.grad).abs().max().item() <= 2e-4 * max(1.0, b2.grad.abs().max().item())
 
 
 def test_raft_is_trainable_with_the_default_corr_block():
