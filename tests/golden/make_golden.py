@@ -33,6 +33,8 @@ Fixtures written (float64 or float32 numpy arrays, about 5 MB in total):
   g17_msda_trt_plugin_case.npz   the case the reference's TensorRT-plugin test feeds the same kernel (torch2trt/plugins/ms_deform_im2col/
                          test.py:103-121: N, M, D = 1, 8, 32; Lq = 12000; levels 64^2 .. 8^2): seed + sha256 of the 24 MB of inputs,
                          the reference's outputs for every 32nd query + the last 16 (float32 and float64)
+  g18_corr_grad.npz      the reference's CorrBlock under autograd: gradients w.r.t. both feature maps through three lookups, and
+                         w.r.t. attached coordinates
   g14 / g14b / g15 / g16 (make_golden_models.py) the reference's DeformableDETR / Detr / PanopticHead forward + inference() over a
                          stub convolution pyramid, and the real aloscene.Frame's norm_* / batch_list
 
@@ -456,12 +458,40 @@ def g17(ref):
     )
 
 
+def g18(ref):
+    """The reference's CorrBlock UNDER AUTOGRAD (corr.py:12-60 is plain torch code; RAFT fine-tunes through it): one pyramid, three
+    lookups at moving coordinates (RAFT's pattern: coordinates detached), a loss that weighs every window feature, gradients with
+    respect to both feature maps; and once more with the coordinates attached.  Odd sizes, 3 levels, radius 2, fp64 run stored fp32."""
+    B, C, H, W = 2, 24, 13, 18
+    torch.manual_seed(18)
+    f1 = torch.randn(B, C, H, W, dtype=torch.float64, requires_grad=True)
+    f2 = torch.randn(B, C, H, W, dtype=torch.float64, requires_grad=True)
+    grid = ref.rutils.coords_grid(B, H, W).double()
+    coords = [grid + torch.randn(B, 2, H, W, dtype=torch.float64) * s for s in (0.0, 1.5, 4.0)]
+    coords[1][:, :, 0, :] = coords[1][:, :, 0, :].round()
+    coords[2][:, 0, 1, :] = -6.0                      # a row of windows left of the map
+    wts = [torch.randn(B, 3 * 25, H, W, dtype=torch.float64) for _ in coords]
+    blk = ref.corr.CorrBlock(f1, f2, num_levels=3, radius=2)
+    outs = [blk(c) for c in coords]
+    loss = sum((o.double() * w).sum() for o, w in zip(outs, wts))
+    g1, g2 = torch.autograd.grad(loss, (f1, f2))
+    c_att = coords[1].clone().requires_grad_(True)
+    out_c = ref.corr.CorrBlock(f1.detach(), f2.detach(), num_levels=3, radius=2)(c_att)
+    (gc,) = torch.autograd.grad((out_c.double() * wts[1]).sum(), c_att)
+    f32 = lambda t: _np(t).astype(np.float32)
+    np.savez_compressed(
+        os.path.join(OUT, "g18_corr_grad.npz"),
+        f1=f32(f1), f2=f32(f2), coords=np.stack([f32(c) for c in coords]), weights=np.stack([f32(w) for w in wts]),
+        out=np.stack([f32(o) for o in outs]), grad_f1=f32(g1), grad_f2=f32(g2), grad_coords1=f32(gc),
+    )
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
     torch.set_num_threads(4)
     ref = load_reference()
-    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g17)
+    todo = [fn for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g17, g18)
             if len(sys.argv) == 1 or fn.__name__ in sys.argv[1:]]   # `make_golden.py g12` regenerates one fixture
     for fn in todo:
         fn(ref)

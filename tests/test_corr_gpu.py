@@ -416,6 +416,30 @@ def test_corr_block_gradients_over_many_lookups_and_repeated_backward():
     assert (b.grad - b2.grad).abs().max().item() <= 2e-4 * max(1.0, b2.grad.abs().max().item())
 
 
+def test_g18_hip_corr_block_has_the_reference_gradients(golden):
+    """The HIP block's gradients (adjoint kernel + GEMMs; coordinates through the torch formulation) against the REFERENCE's own
+    CorrBlock differentiated by autograd (G18, float64 run): odd sizes, 3 levels, radius 2, three lookups, windows off the map."""
+    g = golden("g18_corr_grad.npz")
+    f1 = torch.from_numpy(g["f1"]).to(DEV).requires_grad_(True)
+    f2 = torch.from_numpy(g["f2"]).to(DEV).requires_grad_(True)
+    coords, wts = torch.from_numpy(g["coords"]).to(DEV), torch.from_numpy(g["weights"]).to(DEV)
+    blk = CorrBlock(f1, f2, num_levels=3, radius=2)
+    outs = [blk(c) for c in coords]
+    for o, want in zip(outs, torch.from_numpy(g["out"]).to(DEV)):
+        assert (o - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    g1, g2 = torch.autograd.grad(sum((o * w).sum() for o, w in zip(outs, wts)), (f1, f2))
+    for got, key in ((g1, "grad_f1"), (g2, "grad_f2")):
+        want = torch.from_numpy(g[key]).to(DEV)
+        assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), key
+    c = coords[1].clone().requires_grad_(True)
+    out = CorrBlock(f1.detach(), f2.detach(), num_levels=3, radius=2)(c)
+    (gc,) = torch.autograd.grad((out * wts[1]).sum(), c)
+    want = torch.from_numpy(g["grad_coords1"]).to(DEV)
+    # row 0 of these coordinates sits on integer positions, where the interpolant has a kink: its one-sided derivatives differ and
+    # fp32 / fp64 evaluation of the position may land on either side — compared away from it
+    assert (gc - want)[:, :, 1:].abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+
+
 def test_raft_is_trainable_with_the_default_corr_block():
     """`RAFT()` (default corr_block = the HIP CorrBlock) under autograd: the feature encoder receives gradients through the
     correlation volume — fine-tuning is drop-in, as with the reference's torch CorrBlock."""

@@ -246,6 +246,30 @@ def test_torch_corr_block_matches_reference_outputs_and_is_differentiable(golden
     assert TorchCorrBlock.corr(f1, f2).shape == (1, 16, 20, 1, 16, 20)
 
 
+def test_torch_corr_block_gradients_match_the_reference_under_autograd(golden):
+    """G18 = the reference's own CorrBlock differentiated by autograd (three lookups, both feature maps; attached coordinates): the
+    torch formulation shipped here (coordinate gradients of the HIP block; the all-torch block) reproduces them in float64."""
+    from alonet.raft.corr import TorchCorrBlock
+
+    g = golden("g18_corr_grad.npz")
+    f1 = torch.from_numpy(g["f1"]).double().requires_grad_(True)
+    f2 = torch.from_numpy(g["f2"]).double().requires_grad_(True)
+    coords, wts = torch.from_numpy(g["coords"]).double(), torch.from_numpy(g["weights"]).double()
+    blk = TorchCorrBlock(f1, f2, num_levels=3, radius=2)
+    outs = [blk(c) for c in coords]
+    for o, want in zip(outs, torch.from_numpy(g["out"])):
+        assert (o - want).abs().max().item() <= 1e-5
+    g1, g2 = torch.autograd.grad(sum((o.double() * w).sum() for o, w in zip(outs, wts)), (f1, f2))
+    for got, key in ((g1, "grad_f1"), (g2, "grad_f2")):
+        want = torch.from_numpy(g[key]).double()
+        assert (got - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item()), key
+    c = coords[1].clone().requires_grad_(True)
+    out = TorchCorrBlock(f1.detach(), f2.detach(), num_levels=3, radius=2)(c)
+    (gc,) = torch.autograd.grad((out.double() * wts[1]).sum(), c)
+    want = torch.from_numpy(g["grad_coords1"]).double()
+    assert (gc - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+
+
 def test_hip_corr_block_on_cpu_tensors_raises_instead_of_falling_back():
     with pytest.raises(RuntimeError, match="CUDA"):
         CorrBlock(torch.randn(1, 8, 4, 4), torch.randn(1, 8, 4, 4))
