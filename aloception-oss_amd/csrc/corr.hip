@@ -639,10 +639,26 @@ corr_lookup_bwd_kernel(const LookupBwdArgs a) {
         }
     }
     float* dst = a.glvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
+    constexpr int NV = (COLS + 3) / 4;
+    if (xb >= 0 && xb + 4 * NV <= w) {
+        // the staged columns (and the spare lanes of the last vector) lie inside this map row, which no other thread touches: 16-byte
+        // loads / stores from a 4-byte aligned start, as in the forward — 2 NV memory instructions instead of 2 COLS (the scalar form
+        // took 0.53 ms per lookup at 720p, B = 4; the texture path charges per instruction)
+        typedef f32x4 __attribute__((aligned(4))) f32x4_u;
+        f32x4_u* p = reinterpret_cast<f32x4_u*>(dst + xb);
+        f32x4 cur[NV];
 #pragma unroll
-    for (int j = 0; j < COLS; ++j) {
-        const int x = xb + j;
-        if (x >= 0 && x < w) dst[x] += gv[j];
+        for (int j = 0; j < NV; ++j) cur[j] = p[j];
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) cur[j / 4][j % 4] += gv[j];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) p[j] = cur[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) {
+            const int x = xb + j;
+            if (x >= 0 && x < w) dst[x] += gv[j];
+        }
     }
 }
 

@@ -219,6 +219,19 @@ def bench_corr_lookup(B, reps, H=90, W=160, C=256):
     return dict(kernel="corr_lookup", B=B, ms=t * 1e3, alg_bytes=nbytes, GBps=nbytes / t / 1e9)
 
 
+def bench_corr_lookup_bwd(B, reps, H=90, W=160):
+    """The lookup's adjoint: read the 324 output gradients, read-modify-write the 4 x 10 x 10 footprints (the gradient maps)."""
+    shapes = alo_hip.corr_level_shapes(H, W, 4)
+    HW = H * W
+    grads = [torch.zeros((B * HW, 1, h, w), device=DEV) for h, w in shapes]
+    ys, xs = torch.meshgrid(torch.arange(H, device=DEV), torch.arange(W, device=DEV), indexing="ij")
+    coords = torch.stack([xs, ys]).float()[None].repeat(B, 1, 1, 1) + torch.randn(B, 2, H, W, device=DEV) * 4.0
+    gout = torch.randn(B, 324, H, W, device=DEV)
+    t = time_launches(lambda: alo_hip.corr_lookup_backward(grads, coords, gout, 4), reps)
+    nbytes = 4 * B * (HW * 324 + 2 * HW * 4 * 100 + 2 * HW)
+    return dict(kernel="corr_lookup_backward", B=B, ms=t * 1e3, alg_bytes=nbytes, GBps=nbytes / t / 1e9)
+
+
 def bench_epilogues(N, dtype, reps):
     """alo_add_layernorm on the encoder's (N*S, 256) rows and alo_bias_act on the layer1 NHWC map, next to the stock ops."""
     S = sum(h * w for h, w in DETR_SHAPES)
@@ -284,6 +297,8 @@ def main():
             res = [bench_msda_bwd(4, S, "uniform", torch.float32, max(3, a.reps // 4))]
         elif w == "corr_build":
             res = [bench_corr_build(a.B, max(3, a.reps // 4))]
+        elif w == "corr_lookup_bwd":
+            res = [bench_corr_lookup_bwd(4, a.reps)]
         elif w == "corr_lookup":
             res = [bench_corr_lookup(a.B, a.reps)]
         elif w == "epilogues":
