@@ -1,4 +1,5 @@
-"""Randomised differential run of alo_corr_build / alo_corr_lookup against the C oracle (a development tool; the committed parity
+"""Randomised differential run of alo_corr_build / alo_corr_lookup against the C oracle, and of alo_corr_lookup_backward against
+autograd through the torch formulation (a development tool; the committed parity
 tests are in tests/).  Random batch sizes, channel counts, map sizes (odd ones too), magnitudes, level counts, radii, coordinate spreads.
 
     python tools/exp/fuzz_corr.py [--seconds 120] [--seed 0]
@@ -12,7 +13,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-for p in ("aloception-oss_amd", "oracle", "tests"):
+for p in ("aloception-oss_amd", "oracle", "tests"):  # noqa: the product package for the kernels AND the torch formulation
     sys.path.insert(0, os.path.join(ROOT, p))
 import alo_hip  # noqa: E402
 import oracle as O  # noqa: E402
@@ -54,6 +55,24 @@ def run_case(rng):
     d = np.abs(out - ref).max()
     if not d <= 4e-6 * max(vmax, float(np.abs(levels[0].cpu().numpy()).max())):
         return f"lookup: {d:.4g} of {vmax:.4g} (spread {spread})", (B, C, H, W, L, r)
+    # the lookup's adjoint: <lookup(P), G> == <P, lookup_backward(G)> on a unit-scale pyramid, and against autograd through the torch
+    # formulation of the reference's block (bilinear_sampler = grid_sample)
+    from alonet.raft.corr import lookup_torch
+
+    pyr = [torch.randn_like(lv) for lv in levels]
+    gout = torch.randn(B, L * (2 * r + 1) ** 2, H, W, device=DEV)
+    cdev = dev(coords)
+    grads = alo_hip.corr_lookup_backward([torch.zeros_like(p) for p in pyr], cdev, gout, r)
+    lhs = float((alo_hip.corr_lookup(pyr, cdev, r).double() * gout.double()).sum())
+    rhs = float(sum((p.double() * g.double()).sum() for p, g in zip(pyr, grads)))
+    if not abs(lhs - rhs) <= 2e-4 * max(1.0, abs(lhs), float(gout.numel()) ** 0.5):
+        return f"adjoint identity: {lhs:.6g} vs {rhs:.6g} (spread {spread})", (B, C, H, W, L, r)
+    leaves = [p.clone().requires_grad_(True) for p in pyr]
+    want = torch.autograd.grad(lookup_torch(leaves, cdev, r), leaves, gout)
+    for lvl, (g, w_) in enumerate(zip(grads, want)):
+        d = float((g - w_).abs().max())
+        if not d <= 3e-5 * max(1.0, float(w_.abs().max())):
+            return f"lookup backward level {lvl}: {d:.4g} (spread {spread})", (B, C, H, W, L, r)
     return None, None
 
 
