@@ -600,9 +600,24 @@ corr_lookup_bwd_kernel(const LookupBwdArgs a) {
         tybuf[row * TQ + q] = ty;
         rowbuf[row * TQ + q] = trow;
     }
-    __syncthreads();
+    // this thread's map row: requested NOW (interior rows: three 16-byte loads), consumed after the gather below — the round trip
+    // to memory runs under the barrier and the two adjoint passes instead of behind them
+    constexpr int NV = (COLS + 3) / 4;
+    typedef f32x4 __attribute__((aligned(4))) f32x4_u;
     const int ry = yb + row;
-    if (!ok || ry < 0 || ry >= h) return;   // rows outside the map were read as zeros
+    const bool live = ok && ry >= 0 && ry < h;   // rows outside the map were read as zeros
+    const bool interior = live && xb >= 0 && xb + 4 * NV <= w;
+    float* dst = a.glvl[l] + ((long)b * a.HW + (live ? i : 0)) * ((long)h * w) + (long)(live ? ry : 0) * w;
+    f32x4 cur[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) cur[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (interior) {
+        const f32x4_u* p = reinterpret_cast<const f32x4_u*>(dst + xb);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) cur[j] = p[j];
+    }
+    __syncthreads();
+    if (!live) return;
     // vertical adjoint: tap row c read staged rows trow_c (weight 1 - ty_c) and trow_c + 1 (weight ty_c)
     float gh[WIN];
 #pragma unroll
@@ -638,17 +653,11 @@ corr_lookup_bwd_kernel(const LookupBwdArgs a) {
             gv[k] += hi;
         }
     }
-    float* dst = a.glvl[l] + ((long)b * a.HW + i) * ((long)h * w) + (long)ry * w;
-    constexpr int NV = (COLS + 3) / 4;
-    if (xb >= 0 && xb + 4 * NV <= w) {
+    if (interior) {
         // the staged columns (and the spare lanes of the last vector) lie inside this map row, which no other thread touches: 16-byte
         // loads / stores from a 4-byte aligned start, as in the forward — 2 NV memory instructions instead of 2 COLS (the scalar form
         // took 0.53 ms per lookup at 720p, B = 4; the texture path charges per instruction)
-        typedef f32x4 __attribute__((aligned(4))) f32x4_u;
         f32x4_u* p = reinterpret_cast<f32x4_u*>(dst + xb);
-        f32x4 cur[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) cur[j] = p[j];
 #pragma unroll
         for (int j = 0; j < COLS; ++j) cur[j / 4][j % 4] += gv[j];
 #pragma unroll
