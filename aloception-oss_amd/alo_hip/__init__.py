@@ -67,6 +67,8 @@ def _declare(lib):
     lib.alo_corr_lookup.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
     lib.alo_corr_lookup_backward.restype = ip
     lib.alo_corr_lookup_backward.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
+    lib.alo_corr_lookup_backward_coords.restype = ip
+    lib.alo_corr_lookup_backward_coords.argtypes = [c.POINTER(vp), vp, vp, vp] + [ip] * 5 + [vp]
     lib.alo_corr_lookup_conv1x1_kpad.restype = ip
     lib.alo_corr_lookup_conv1x1_kpad.argtypes = [ip]
     lib.alo_corr_lookup_conv1x1.restype = ip
@@ -591,6 +593,30 @@ def corr_lookup_backward(grad_levels, coords, grad_out, radius=4):
     with torch.cuda.device(coords.device), _timed("corr_lookup_backward", nbytes):
         _check(lib().alo_corr_lookup_backward(ptrs, _ptr(coords), _ptr(grad_out), B, H, W, radius, L, _stream(coords.device)))
     return grad_levels
+
+
+def corr_lookup_backward_coords(levels, coords, grad_out, radius=4):
+    """Gradient of :func:`corr_lookup` with respect to ``coords`` -> (B, 2, H, W): grid_sample's gradient with respect to the grid
+    chained through the reference's coordinate arithmetic (corr.py:29-50); per-level maps from the kernel, added here."""
+    _require_f32_cuda("coords", coords, 4)
+    _require_f32_cuda("grad_out", grad_out, 4)
+    coords, grad_out = coords.contiguous(), grad_out.contiguous()
+    B, two, H, W = coords.shape
+    L = len(levels)
+    if two != 2 or tuple(grad_out.shape) != (B, L * (2 * radius + 1) ** 2, H, W):
+        raise RuntimeError("corr_lookup_backward_coords: coords must be (B,2,H,W) and grad_out (B, L*(2r+1)^2, H, W)")
+    for lvl, t in enumerate(levels):
+        _require_f32_cuda(f"corr_pyramid[{lvl}]", t, 4)
+        if not t.is_contiguous() or t.shape[0] != B * H * W:
+            raise RuntimeError(f"corr_pyramid[{lvl}] must be a contiguous (B*H*W,1,h,w) tensor")
+    per_level = torch.empty((B, L, 2, H, W), dtype=torch.float32, device=coords.device)
+    ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in levels])
+    taps = (2 * radius + 2) ** 2
+    nbytes = 4.0 * B * H * W * (L * (2 * radius + 1) ** 2 + L * taps + 2 + 2 * L)
+    with torch.cuda.device(coords.device), _timed("corr_lookup_backward_coords", nbytes):
+        _check(lib().alo_corr_lookup_backward_coords(ptrs, _ptr(coords), _ptr(grad_out), _ptr(per_level), B, H, W, radius, L,
+                                                     _stream(coords.device)))
+    return per_level.sum(1)
 
 
 def corr_lookup_conv1x1_supported(levels, weight, radius):

@@ -19,7 +19,8 @@ the feature maps require a gradient:
   times; autograd through ``grid_sample`` would materialise a dense gradient of the whole volume for each).  The maps reach
   ``_BuildFunction.backward`` through a scalar token every lookup depends on, not as dense autograd gradients;
 * a gradient with respect to the COORDINATES (RAFT detaches them, raft.py:186; the reference's block is differentiable there too)
-  comes from the torch formulation below, differentiated with respect to the coordinates only;
+  is a kernel as well (``alo_corr_lookup_backward_coords``: the forward's gather with the horizontal differences kept, one map per
+  level);
 * ``corr_pyramid`` tensors used directly in somebody's own graph receive dense gradients the ordinary way; they are added to the
   accumulated maps.
 Without gradients nothing of this exists: ``CorrBlock`` is two kernel calls.
@@ -34,7 +35,7 @@ import alo_hip
 from .utils.utils import bilinear_sampler
 
 
-# ---- the torch formulation: what the reference computes, op for op (used for gradients, and as ``TorchCorrBlock``) ----------------
+# ---- the torch formulation: what the reference computes, op for op (``TorchCorrBlock``; the tests' yardstick for the gradients) ------
 def pyramid_torch(fmap1, fmap2, num_levels=4):
     """corr.py:13-27,52-60: ``<fmap1[b,:,i], fmap2[b,:,j]> / sqrt(C)`` as ``(B*H*W, 1, H, W)`` + ``num_levels - 1`` 2x2 means."""
     B, C, H, W = fmap1.shape
@@ -163,9 +164,7 @@ class _LookupFunction(torch.autograd.Function):
         state = ctx.state
         gcoords = None
         if ctx.needs_input_grad[0]:
-            with torch.enable_grad():
-                c = coords.detach().requires_grad_(True)
-                (gcoords,) = torch.autograd.grad(lookup_torch([p.detach() for p in state.pyramid], c, ctx.radius), c, grad_out)
+            gcoords = alo_hip.corr_lookup_backward_coords(state.pyramid, coords, grad_out, ctx.radius)
         if ctx.needs_input_grad[1]:
             alo_hip.corr_lookup_backward(state.grad_maps(), coords, grad_out, ctx.radius)
         return gcoords, (coords.new_zeros(()) if ctx.needs_input_grad[1] else None), None, None
@@ -173,7 +172,7 @@ class _LookupFunction(torch.autograd.Function):
 
 class _LookupDenseFunction(torch.autograd.Function):
     """A lookup into pyramid tensors that did not come out of ``_BuildFunction`` under autograd (somebody's own differentiable
-    pyramid, or coordinates that want a gradient while the features do not): the torch formulation differentiates it."""
+    pyramid, or coordinates that want a gradient while the features do not): the same two backward kernels, dense gradient maps."""
 
     @staticmethod
     def forward(ctx, coords, radius, *pyramid):
@@ -185,13 +184,12 @@ class _LookupDenseFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         coords, *pyramid = ctx.saved_tensors
-        with torch.enable_grad():
-            c = coords.detach().requires_grad_(ctx.needs_input_grad[0])
-            pyr = [p.detach().requires_grad_(ctx.needs_input_grad[2 + i]) for i, p in enumerate(pyramid)]
-            wrt = [t for t in [c] + pyr if t.requires_grad]
-            got = torch.autograd.grad(lookup_torch(pyr, c, ctx.radius), wrt, grad_out, allow_unused=True) if wrt else ()
-        it = iter(got)
-        return (next(it) if c.requires_grad else None, None) + tuple(next(it) if p.requires_grad else None for p in pyr)
+        gcoords = alo_hip.corr_lookup_backward_coords(pyramid, coords, grad_out, ctx.radius) if ctx.needs_input_grad[0] else None
+        gpyr = [None] * len(pyramid)
+        if any(ctx.needs_input_grad[2:]):   # dense maps: this pyramid is somebody's own tensors, autograd wants a gradient per tensor
+            maps = alo_hip.corr_lookup_backward([torch.zeros_like(p) for p in pyramid], coords, grad_out, ctx.radius)
+            gpyr = [m if need else None for m, need in zip(maps, ctx.needs_input_grad[2:])]
+        return (gcoords, None) + tuple(gpyr)
 
 
 class CorrBlock:

@@ -447,14 +447,16 @@ __device__ __forceinline__ void strip_request(const LookupArgs& a, int l, int b,
     }
 }
 
+// `dbuf` (optional, same shape as hbuf): hi - lo of every tap = the derivative of the row's interpolated value with respect to the
+// tap's x position (the coordinate gradient's horizontal half; zeros outside the map count as values, as in grid_sample's backward)
 template <int R>
 __device__ __forceinline__ void strip_finish(const LookupArgs& a, int l, int row, int q, const Strip<R>& s, float* hbuf, float* tybuf,
-                                             int* rowbuf) {
+                                             int* rowbuf, float* dbuf = nullptr) {
     constexpr int WIN = 2 * R + 1, COLS = Strip<R>::COLS;
     const int h = a.h[l], w = a.w[l];
-    float hv[WIN];
+    float hv[WIN], dv[WIN];
 #pragma unroll
-    for (int k = 0; k < WIN; ++k) hv[k] = 0.f;
+    for (int k = 0; k < WIN; ++k) hv[k] = dv[k] = 0.f;
     float ty = 0.f;
     int trow = row < WIN ? row : 0;
     if (s.mode >= 0) {
@@ -488,12 +490,18 @@ __device__ __forceinline__ void strip_finish(const LookupArgs& a, int l, int row
                 const float hi = d == 0 ? v[k + 1] : (d > 0 ? v[k + 2] : v[k]);
                 const float tx = ix - (float)(s.xb + k + d);
                 hv[k] = (1.0f - tx) * lo + tx * hi;
+                dv[k] = hi - lo;
             }
         }
     }
     float* dst = hbuf + (row * WIN) * TQ + q;
 #pragma unroll
     for (int k = 0; k < WIN; ++k) dst[k * TQ] = hv[k];
+    if (dbuf) {
+        float* dd = dbuf + (row * WIN) * TQ + q;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) dd[k * TQ] = dv[k];
+    }
     if (row < WIN) {
         tybuf[row * TQ + q] = ty;
         rowbuf[row * TQ + q] = trow;
@@ -534,6 +542,69 @@ corr_lookup_kernel(const LookupArgs a) {
             const float top = hbuf[(r0 * WIN + ax) * TQ + q];
             const float bot = hbuf[((r0 + 1) * WIN + ax) * TQ + q];
             a.out[((long)b * CH + l * WIN * WIN + rem) * a.HW + i] = (1.0f - ty) * top + ty * bot;
+        }
+    }
+}
+
+// Backward of the lookup with respect to the COORDINATES (RAFT detaches them before every lookup, raft.py:186, but the reference's block
+// is differentiable there as well: grid_sample's gradient with respect to the grid, chained through the reference's own coordinate
+// arithmetic, whose derivative is 1 / 2^l).  Stage 1 is the forward's, with the horizontal difference hi - lo of every tap kept next
+// to the interpolated value; stage 2 forms, per tap,  d out / d x = (1 - ty) dtop + ty dbot  and  d out / d y = bot - top,  weighs them
+// with the tap's output gradient and sums over the window: a thread keeps the partial sums of ITS query (the thread count is a
+// multiple of the tile's 32 queries), twelve partials per query meet in LDS.  One (B, 2, H, W) map per level; the caller adds the levels
+// (a fixed order: deterministic).
+struct LookupCoordsBwdArgs {
+    LookupArgs fwd;       // levels, coords; `out` unused
+    const float* gout;    // (B, L * WIN^2, H, W)
+    float* gcoords;       // (B, L, 2, H, W)
+};
+
+template <int R>
+__global__ void __launch_bounds__(lookup_threads<R>())
+corr_lookup_coords_bwd_kernel(const LookupCoordsBwdArgs ca) {
+    const LookupArgs& a = ca.fwd;
+    constexpr int NT = lookup_threads<R>();
+    constexpr int WIN = 2 * R + 1, ROWS = WIN + 2;
+    static_assert(NT % TQ == 0, "a thread's outputs all belong to one query");
+    __shared__ float hbuf[ROWS * WIN * TQ];
+    __shared__ float dbuf[ROWS * WIN * TQ];
+    __shared__ float tybuf[WIN * TQ];
+    __shared__ int rowbuf[WIN * TQ];
+    __shared__ float part[2][NT];
+    const int b = blockIdx.x / a.tiles_per_batch;
+    const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
+    const int l = blockIdx.y, tid = threadIdx.x;
+    if (tid < ROWS * TQ) {
+        Strip<R> s;
+        strip_request<R>(a, l, b, q0 + tid % TQ, tid / TQ, s);
+        strip_finish<R>(a, l, tid / TQ, tid % TQ, s, hbuf, tybuf, rowbuf, dbuf);
+    }
+    __syncthreads();
+    const int CH = a.num_levels * WIN * WIN;
+    const int q = tid % TQ, i = q0 + q;
+    float gx = 0.f, gy = 0.f;
+    if (i < a.HW) {
+        for (int rem = tid / TQ; rem < WIN * WIN; rem += NT / TQ) {
+            const int ax = rem / WIN, cy = rem % WIN;
+            const float ty = tybuf[cy * TQ + q];
+            const int r0 = rowbuf[cy * TQ + q];
+            const float top = hbuf[(r0 * WIN + ax) * TQ + q], bot = hbuf[((r0 + 1) * WIN + ax) * TQ + q];
+            const float dtop = dbuf[(r0 * WIN + ax) * TQ + q], dbot = dbuf[((r0 + 1) * WIN + ax) * TQ + q];
+            const float g = ca.gout[((long)b * CH + l * WIN * WIN + rem) * a.HW + i];
+            gx += g * ((1.0f - ty) * dtop + ty * dbot);
+            gy += g * (bot - top);
+        }
+    }
+    part[0][tid] = gx;
+    part[1][tid] = gy;
+    __syncthreads();
+    if (tid < 2 * TQ) {
+        const int c = tid / TQ, qq = tid % TQ, ii = q0 + qq;
+        if (ii < a.HW) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < NT / TQ; ++k) sum += part[c][k * TQ + qq];
+            ca.gcoords[(((long)b * a.num_levels + l) * 2 + c) * a.HW + ii] = sum * (1.0f / (float)(1 << l));
         }
     }
 }
@@ -827,6 +898,13 @@ int launch_lookup_conv(const LookupArgs& a, const ConvArgs& cv, hipStream_t stre
 }
 
 template <int R>
+int launch_lookup_coords_bwd(const LookupCoordsBwdArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(corr_lookup_coords_bwd_kernel<R>, dim3(a.fwd.B * a.fwd.tiles_per_batch, a.fwd.num_levels), dim3(lookup_threads<R>()), 0,
+                       stream, a);
+    return check_launch("alo_corr_lookup_backward_coords");
+}
+
+template <int R>
 int launch_lookup_bwd(const LookupBwdArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(corr_lookup_bwd_kernel<R>, dim3(a.B * a.tiles_per_batch, a.num_levels), dim3(lookup_threads<R>()), 0, stream, a);
     return check_launch("alo_corr_lookup_backward");
@@ -1040,6 +1118,27 @@ extern "C" int alo_corr_lookup_backward(float* const* grad_levels, const float* 
         case 5: return launch_lookup_bwd<5>(a, stream);
         case 6: return launch_lookup_bwd<6>(a, stream);
         default: return launch_lookup_bwd<7>(a, stream);
+    }
+}
+
+extern "C" int alo_corr_lookup_backward_coords(const float* const* levels, const float* coords, const float* grad_out,
+                                               float* grad_coords_levels, int B, int H, int W, int radius, int num_levels, void* stream_) {
+    const char* what = "alo_corr_lookup_backward_coords";
+    ALO_REQUIRE(grad_out, ALO_ERR_INVALID_ARGUMENT, "%s: null pointer argument", what);
+    LookupCoordsBwdArgs ca;
+    if (int rc = fill_lookup_args(ca.fwd, levels, coords, grad_coords_levels, B, H, W, radius, num_levels, what)) return rc;
+    ca.gout = grad_out;
+    ca.gcoords = grad_coords_levels;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    switch (radius) {
+        case 0: return launch_lookup_coords_bwd<0>(ca, stream);
+        case 1: return launch_lookup_coords_bwd<1>(ca, stream);
+        case 2: return launch_lookup_coords_bwd<2>(ca, stream);
+        case 3: return launch_lookup_coords_bwd<3>(ca, stream);
+        case 4: return launch_lookup_coords_bwd<4>(ca, stream);
+        case 5: return launch_lookup_coords_bwd<5>(ca, stream);
+        case 6: return launch_lookup_coords_bwd<6>(ca, stream);
+        default: return launch_lookup_coords_bwd<7>(ca, stream);
     }
 }
 

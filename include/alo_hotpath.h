@@ -253,6 +253,23 @@ int alo_corr_lookup_backward(float* const* grad_levels, const float* coords, con
                              int B, int H, int W, int radius, int num_levels, void* stream);
 
 /*
+ * Backward of alo_corr_lookup with respect to the COORDINATES (grid_sample's gradient with respect to the grid chained through the
+ * reference's coordinate arithmetic, corr.py:29-50 / utils.py:5-20; RAFT itself detaches the coordinates, raft.py:186):
+ *
+ *   grad_coords_levels[b, l, 0, y, x] = 2^-l * sum over taps (a, c) of grad_out[b, l*(2r+1)^2 + a*(2r+1) + c, y, x] * d tap / d px
+ *   grad_coords_levels[b, l, 1, y, x] = the same with d tap / d py
+ *
+ * with the bilinear interpolant's one-sided derivatives of the cell a tap falls in (values outside the map count as zeros, as in
+ * grid_sample).  One (2, H, W) map per level, fully written; the gradient of `coords` is their sum over l (the caller adds them).
+ *
+ *   levels              HOST array of num_levels DEVICE pointers: the pyramid the forward lookup read
+ *   coords, grad_out    as for alo_corr_lookup_backward
+ *   grad_coords_levels  (B, num_levels, 2, H, W) float32
+ */
+int alo_corr_lookup_backward_coords(const float* const* levels, const float* coords, const float* grad_out,
+                                    float* grad_coords_levels, int B, int H, int W, int radius, int num_levels, void* stream);
+
+/*
  * The lookup above fused with the 1x1 convolution that consumes it in RAFT's motion encoder (update.py:83-101, `convc1`:
  * L*(2r+1)^2 -> Cout channels, + bias, ReLU): the (B, L*(2r+1)^2, H, W) window features are never written.
  *

@@ -371,6 +371,51 @@ def test_lookup_backward_is_the_adjoint_of_the_lookup(B, H, W, r, L):
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
 
 
+@pytest.mark.parametrize("B,H,W,r,L", [(1, 16, 24, 4, 4), (2, 9, 13, 3, 2), (1, 17, 18, 1, 3), (2, 8, 8, 0, 1), (1, 40, 64, 7, 3)])
+def test_lookup_backward_with_respect_to_the_coordinates(B, H, W, r, L):
+    """alo_corr_lookup_backward_coords against autograd through the torch formulation (grid_sample's gradient with respect to the
+    grid, chained through the reference's coordinate arithmetic): random sub-pixel positions inside, across the borders and far
+    outside the maps.  Positions within 1e-3 of an integer are left out of the comparison — the interpolant has a kink there and
+    fp32 arithmetic of two formulations may land on either side of it."""
+    from alonet.raft.corr import lookup_torch
+
+    gen = torch.Generator(device="cpu").manual_seed(7 * H + W + r)
+    pyr = [torch.randn(B * H * W, 1, H // 2 ** lvl, W // 2 ** lvl, generator=gen).to(DEV) for lvl in range(L)]
+    coords = coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 3.0
+    coords[:, 0, 1, :] = -float(r) - 2.5
+    coords[:, 1, 2, :] = float(H) + 0.25
+    gout = torch.randn(B, L * (2 * r + 1) ** 2, H, W, generator=gen).to(DEV)
+    c = coords.clone().requires_grad_(True)
+    (want,) = torch.autograd.grad(lookup_torch(pyr, c, r), c, gout)
+    got = alo_hip.corr_lookup_backward_coords(pyr, coords, gout, r)
+    assert got.shape == want.shape
+    safe = torch.ones_like(coords, dtype=torch.bool)
+    for lvl in range(L):
+        p = coords / 2 ** lvl
+        near = ((p - p.round()).abs() < 1e-3).any(dim=1, keepdim=True)
+        safe &= ~near
+    assert safe.float().mean().item() > 0.9
+    err = ((got - want).abs() * safe).max().item()
+    assert err <= 1e-4 * max(1.0, want.abs().max().item()), err
+    # the block: coordinates attached, features detached, and both at once
+    f1 = torch.randn(B, 24, H, W, generator=gen).to(DEV)
+    f2 = torch.randn(B, 24, H, W, generator=gen).to(DEV)
+    from alonet.raft.corr import TorchCorrBlock
+
+    res = {}
+    for name, cls in (("hip", CorrBlock), ("torch", TorchCorrBlock)):
+        a, cc = f1.clone().requires_grad_(True), coords.clone().requires_grad_(True)
+        out = cls(a, f2, num_levels=L, radius=r)(cc)
+        ga, gc = torch.autograd.grad((out * gout).sum(), (a, cc))
+        res[name] = (ga, gc)
+    assert (res["hip"][0] - res["torch"][0]).abs().max().item() <= 2e-4 * max(1.0, res["torch"][0].abs().max().item())
+    assert ((res["hip"][1] - res["torch"][1]).abs() * safe).max().item() <= 2e-4 * max(1.0, res["torch"][1].abs().max().item())
+    cc = coords.clone().requires_grad_(True)
+    out = CorrBlock(f1, f2, num_levels=L, radius=r)(cc)                      # only the coordinates: the dense-function route
+    (gc,) = torch.autograd.grad((out * gout).sum(), cc)
+    assert ((gc - res["torch"][1]).abs() * safe).max().item() <= 2e-4 * max(1.0, res["torch"][1].abs().max().item())
+
+
 def test_corr_block_gradients_over_many_lookups_and_repeated_backward():
     """RAFT's pattern: one pyramid, many lookups at moving (detached) coordinates, one backward — the lookups accumulate into shared
     gradient maps that the build node turns into feature gradients with two GEMMs per level.  Gradients equal those of the torch

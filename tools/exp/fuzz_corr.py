@@ -68,7 +68,16 @@ def run_case(rng):
     if not abs(lhs - rhs) <= 2e-4 * max(1.0, abs(lhs), float(gout.numel()) ** 0.5):
         return f"adjoint identity: {lhs:.6g} vs {rhs:.6g} (spread {spread})", (B, C, H, W, L, r)
     leaves = [p.clone().requires_grad_(True) for p in pyr]
-    want = torch.autograd.grad(lookup_torch(leaves, cdev, r), leaves, gout)
+    cleaf = cdev.clone().requires_grad_(True)
+    *want, want_c = torch.autograd.grad(lookup_torch(leaves, cleaf, r), leaves + [cleaf], gout)
+    got_c = alo_hip.corr_lookup_backward_coords(pyr, cdev, gout, r)
+    safe = torch.isfinite(want_c)
+    for lvl in range(L):   # away from the interpolant's kinks (integer positions on any level)
+        pos = cdev / 2 ** lvl
+        safe &= ~((pos - pos.round()).abs() < 2e-3 * torch.clamp(pos.abs(), min=1.0)).any(dim=1, keepdim=True)
+    d = float(((got_c - torch.nan_to_num(want_c)).abs() * safe).max())
+    if not d <= 2e-4 * max(1.0, float((torch.nan_to_num(want_c).abs() * safe).max())):
+        return f"coordinate gradient: {d:.4g} (spread {spread})", (B, C, H, W, L, r)
     for lvl, (g, w_) in enumerate(zip(grads, want)):
         d = float((g - w_).abs().max())
         if not d <= 3e-5 * max(1.0, float(w_.abs().max())):
