@@ -364,7 +364,11 @@ msda_fwd_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes,
                         for (int s0 = 0; s0 < LP; s0 += SB) {
                             Desc d[SB];
                             typename Ld::raw_t raw[SB][4];
+                            // requests at raised wave priority: they reach the memory system ahead of the other waves' FMA work
+                            // (fp32 encoder call 0.451 -> 0.425 ms un-fused, 0.456 -> 0.445 fused; same box, alternating)
+                            __builtin_amdgcn_s_setprio(3);
                             issue(s0, d, raw);
+                            __builtin_amdgcn_s_setprio(0);
                             consume(d, raw);
                         }
                     }
