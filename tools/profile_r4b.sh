@@ -22,6 +22,6 @@ cd $ROOT
 (cd tools/exp && ./corr_gemm_exp 20 2>&1 | grep -v amdgpu.ids) > $OUT/corr_gemm_exp.txt
 cp tools/exp/corr_trace_0.csv $OUT/ 2>/dev/null
 FWD=msda_fused_hm,msda_fused_hm_plain,msda_fused_hm_survey,msda_fused_hm_uniform
-python tools/kbench.py --which $FWD,msda_enc,msda_survey,msda_rand,msda_bwd,msda_bwd_rand,corr_build,corr_lookup --reps 40 2>/dev/null | grep kernel > $OUT/kbench.txt
+python tools/kbench.py --which $FWD,msda_enc,msda_survey,msda_rand,msda_bwd,msda_bwd_rand,corr_build,corr_lookup,corr_lookup_bwd --reps 40 2>/dev/null | grep kernel > $OUT/kbench.txt
 python bench.py > $OUT/r04_bench_line.json 2> $OUT/bench.err
 tail -c 400 $OUT/r04_bench_line.json; grep corr $OUT/r04_raft_kernel_stats.csv | cut -c1-150; cat $OUT/hipblaslt_corr.txt
