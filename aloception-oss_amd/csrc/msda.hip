@@ -812,8 +812,7 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
     const unsigned coff = (unsigned)lane * 16u;   // this lane's 8 channels of a 64-byte row
     // transpose-read roles: in its 16-lane group this lane FETCHES corner (lid >> 2) & 3 of the group's pair lid & 3
     const unsigned fetch_off = (unsigned)((((lid >> 4) * 4 + (lid & 3)) * 16) + ((lid >> 2) & 3) * 4);
-    const int run_lo = part * rd.runs_per_wg;
-    const int run_hi = min(run_lo + rd.runs_per_wg, rd.runs_per_slab);
+    const int run_hi = rd.runs_per_slab;
     unsigned char* aw_wr = aw + (4 * lane) * kResSampleStride + pl * 24;
     const unsigned char* aw_rd = aw + pl * 24 + 8 * min(lane, 2);   // lane 3's row of A is ignored (D[3] is never summed)
 
@@ -830,7 +829,11 @@ msda_fwd_bf16_resident_kernel(const bf16_t* __restrict__ value, const int32_t* _
     int next_index = wave;   // runs are dealt out round-robin over the workgroup's waves (every run costs the same instructions)
     auto next_run = [&]() -> RunIn {
         RunIn in;
-        in.run = run_lo + next_index;
+        // The workgroups of a slab take every wps-th run and their waves every twelfth of those: the slab's 12 * wps waves sweep
+        // the image TOGETHER, so the level-0 / 1 rows they gather at any moment come from a band of a few image rows (and the eight
+        // heads of an image, which share an XCD, read the same offset / logit lines at the same time) instead of from wps
+        // separate quarters of the pyramid: survey 0.196 -> 0.184 ms, ring 0.1695 -> 0.166, uniform unchanged.
+        in.run = part + rd.wps * next_index;
         next_index += kResWaves;
         const int q = in.run * 16 + pl;
         in.dead = q >= Lq || in.run >= run_hi;
