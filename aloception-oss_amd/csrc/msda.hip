@@ -1612,7 +1612,9 @@ Dims make_dims(int N, int S, int M, int D, int L, int Lq, int P, int G, long tar
     const long iters_total = ((long)d.pairs_per_batch + pairs - 1) / pairs;
     long ipb = iters_total * N / target_blocks;  // keep >= ~4096 workgroups of 4 waves in flight when the problem allows it
     if (ipb < 1) ipb = 1;
-    if (ipb > 8) ipb = 8;
+    if (ipb > 4) ipb = 4;   // workgroups in flight sweep the image in query order: the shorter their shares, the narrower the band of rows
+                            // the L2 has to hold (8 -> 4: fp32 survey 0.497 -> 0.473 ms, plain head-major 0.224 -> 0.216; 2 and 1 lose to
+                            // the per-workgroup overhead)
     d.iters_per_block = (int)ipb;
     d.runs_per_batch = (int)iters_total;
     d.blocks_per_batch = (int)((iters_total + ipb - 1) / ipb);
