@@ -26,9 +26,12 @@ _lib = None
 
 
 def tensor_version(t):
-    """``t._version`` for the ``(version, data_ptr)`` cache keys of this package; a constant for inference tensors
-    (``torch.inference_mode()``), which carry no version counter and raise when asked for one (round-3 advisor finding)."""
-    return -1 if t.is_inference() else t._version
+    """``t._version`` for the ``(version, data_ptr)`` cache keys of this package.  Inference tensors (``torch.inference_mode()``)
+    carry no version counter and raise when asked for one (round-3 advisor finding), yet can still be updated in place inside
+    inference mode with their ``data_ptr`` unchanged — so for them the key is a fresh object that equals nothing, itself of an
+    earlier call included: whatever is derived from an inference tensor is re-derived on every use instead of being cached
+    (round-4 advisor finding: a constant there made stale packed weights / host shapes possible)."""
+    return object() if t.is_inference() else t._version
 
 
 class HotpathUnavailable(RuntimeError):
@@ -69,10 +72,6 @@ def _declare(lib):
     lib.alo_corr_lookup_backward.argtypes = [c.POINTER(vp), vp, vp] + [ip] * 5 + [vp]
     lib.alo_corr_lookup_backward_coords.restype = ip
     lib.alo_corr_lookup_backward_coords.argtypes = [c.POINTER(vp), vp, vp, vp] + [ip] * 5 + [vp]
-    lib.alo_corr_lookup_conv1x1_kpad.restype = ip
-    lib.alo_corr_lookup_conv1x1_kpad.argtypes = [ip]
-    lib.alo_corr_lookup_conv1x1.restype = ip
-    lib.alo_corr_lookup_conv1x1.argtypes = [c.POINTER(vp), vp, vp, vp, vp] + [ip] * 7 + [vp]
     lib.alo_msda_forward_fused_hm.restype = ip
     lib.alo_msda_forward_fused_hm_rows.restype = ip
     lib.alo_msda_forward_fused_hm_rows.argtypes = [vp] * 5 + [c.c_long, c.c_long, vp, vp] + [ip] * 9 + [vp]
@@ -617,56 +616,6 @@ def corr_lookup_backward_coords(levels, coords, grad_out, radius=4):
         _check(lib().alo_corr_lookup_backward_coords(ptrs, _ptr(coords), _ptr(grad_out), _ptr(per_level), B, H, W, radius, L,
                                                      _stream(coords.device)))
     return per_level.sum(1)
-
-
-def corr_lookup_conv1x1_supported(levels, weight, radius):
-    """The fused lookup + 1x1 convolution exists for fp32, radius 1..4, Cout in (128, 256)."""
-    return (weight.is_cuda and weight.dtype == torch.float32 and 1 <= radius <= 4 and weight.shape[0] in (128, 256)
-            and weight.numel() == weight.shape[0] * len(levels) * (2 * radius + 1) ** 2)
-
-
-def corr_lookup_conv1x1(levels, coords, weight, bias=None, radius=4, relu=True):
-    """``act(conv1x1(corr_lookup(levels, coords, radius), weight, bias))`` in one kernel: levels from :func:`corr_build`,
-    coords (B,2,H,W), weight (Cout, L*(2r+1)^2[, 1, 1]) -> (B, Cout, H, W) float32 (RAFT's motion encoder ``convc1``)."""
-    _require_f32_cuda("coords", coords, 4)
-    coords = coords.contiguous()
-    B, two, H, W = coords.shape
-    L = len(levels)
-    K = L * (2 * radius + 1) ** 2
-    if two != 2 or not corr_lookup_conv1x1_supported(levels, weight, radius):
-        raise RuntimeError("corr_lookup_conv1x1: needs (B,2,H,W) coords, a float32 CUDA (Cout, L*(2r+1)^2) weight, Cout 128 or 256, radius 1..4")
-    for lvl, t in enumerate(levels):
-        _require_f32_cuda(f"corr_pyramid[{lvl}]", t, 4)
-        if not t.is_contiguous() or t.shape[0] != B * H * W:
-            raise RuntimeError(f"corr_pyramid[{lvl}] must be a contiguous (B*H*W,1,h,w) tensor")
-    cout = weight.shape[0]
-    # per-level regrouping with zero padding to a multiple of 8 entries; cached on the weight tensor per version
-    tag = (tensor_version(weight), weight.data_ptr(), L, radius)
-    hit = getattr(weight, "_alo_packed", None)
-    if hit is None or hit[0] != tag:
-        kp = lib().alo_corr_lookup_conv1x1_kpad(radius)
-        wp = torch.zeros((cout, L, kp), dtype=torch.float32, device=weight.device)
-        wp[:, :, :K // L] = weight.detach().reshape(cout, L, K // L)
-        # exact three-way bf16 split by truncation: t0 = upper 16 bits of w, t1 = upper 16 bits of (w - t0), t2 = the rest
-        terms, rest = [], wp
-        for _ in range(3):
-            top = (rest.view(torch.int32) & -65536).view(torch.float32)
-            terms.append((top.view(torch.int32) >> 16).to(torch.int16))
-            rest = rest - top
-        # matrix-operand order (include/alo_hotpath.h): (term, level, k-step, 32-channel tile, kg, channel in tile, 8 entries)
-        w2 = torch.stack(terms).reshape(3, cout // 32, 32, L, kp // 16, 2, 8).permute(0, 3, 4, 1, 5, 2, 6).contiguous()
-        hit = (tag, w2)
-        weight._alo_packed = hit
-    w2 = hit[1]
-    bias_c = None if bias is None else bias.detach().float().contiguous()
-    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=coords.device)
-    ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in levels])
-    taps = (2 * radius + 2) ** 2
-    nbytes = 4.0 * B * H * W * (cout + L * taps + 2)
-    with torch.cuda.device(coords.device), _timed("corr_lookup_convc1", nbytes, 2.0 * B * H * W * K * cout):
-        _check(lib().alo_corr_lookup_conv1x1(ptrs, _ptr(coords), _ptr(w2), None if bias_c is None else _ptr(bias_c), _ptr(out),
-                                             B, H, W, radius, L, cout, 1 if relu else 0, _stream(coords.device)))
-    return out
 
 
 # ---- one-pass epilogues around the attention op (alo_add_layernorm / alo_bias_act) ---------------------------------------

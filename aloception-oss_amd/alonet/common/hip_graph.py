@@ -6,7 +6,18 @@ ROCm) the same kernels replay with one host call and back-to-back dispatch: 10.1
 on 8 frames of 1333x800 (MI355X), bit-identical outputs.  No tracing compiler is involved: the graph is the recorded launch
 sequence of the eager code, hand-written kernels included.
 """
+import weakref
+
 import torch
+
+# Every live wrapper of a model, so that one wrapper's capture does not re-derive (free) the tensors another one's live graphs
+# replay on.  Kept OUTSIDE the module object (a weak set inside ``model.__dict__`` made ``torch.save(model)`` fail on the weak
+# references and ``copy.deepcopy(model)`` carry ghost wrappers over: round-4 advisor finding).
+_WRAPPERS = weakref.WeakKeyDictionary()   # model -> WeakSet of GraphedForward
+
+
+def _wrappers_of(model):
+    return _WRAPPERS.get(model, ())
 
 
 class GraphedForward:
@@ -28,11 +39,7 @@ class GraphedForward:
         self.adopt_inputs = adopt_inputs
         self._graphs = {}
         self._epoch = 0
-        # every wrapper of this model, so that one wrapper's capture does not re-derive (free) the tensors another one's live
-        # graphs replay on
-        import weakref
-
-        model.__dict__.setdefault("_graph_wrappers_alo", weakref.WeakSet()).add(self)
+        _WRAPPERS.setdefault(model, weakref.WeakSet()).add(self)
 
     def reset(self):
         """Forget every captured graph (the next call captures again)."""
@@ -51,7 +58,7 @@ class GraphedForward:
         # alo_hip.invalidate_caches(model) (load_weights calls it), which bumps the model's cache epoch: __call__ then drops
         # every graph and captures again.
         others_live = any(w._graphs and w._epoch == alo_hip.cache_epoch(self.model)
-                          for w in self.model.__dict__.get("_graph_wrappers_alo", ()) if w is not self)
+                          for w in _wrappers_of(self.model) if w is not self)
         if not self._graphs and not others_live:
             alo_hip.invalidate_caches(self.model)  # weights edited through .data since the last forward: re-derive before pinning
         # (with another wrapper's graphs alive on the current epoch the derived tensors are kept: re-deriving them would bump the

@@ -86,11 +86,34 @@ class _PyramidState:
     def __init__(self):
         self.pyramid = None
         self.grad = None
+        self.grad_pass = None
+
+    @staticmethod
+    def _current_pass():
+        """Identity of the autograd pass that is running (the engine's graph-task id; -1 outside a backward)."""
+        return torch._C._current_graph_task_id()
 
     def grad_maps(self):
-        if self.grad is None:
+        """The maps of the backward pass that is running.  They belong to THAT pass: the first lookup backward of a pass creates
+        them, tags them with the engine's graph-task id and queues an end-of-pass callback that drops whatever the build node did
+        not consume — a pass that never reaches the build node (``autograd.grad(loss, coords)``) must not leave volume-sized maps
+        behind to be added to the next pass's gradients.  The engine skips its callbacks when a pass aborts on an exception, so
+        maps tagged by another pass are also discarded here, when the next pass first asks for them."""
+        now = self._current_pass()
+        if self.grad is None or self.grad_pass != now:
             self.grad = [torch.zeros_like(p) for p in self.pyramid]
+            self.grad_pass = now
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
         return self.grad
+
+    def take_grad_maps(self):
+        """What the lookups of the running pass accumulated (None if none did); the state is left empty."""
+        maps, tag = self.grad, self.grad_pass
+        self.grad = self.grad_pass = None
+        return maps if tag == self._current_pass() else None
+
+    def _end_of_pass(self):
+        self.grad = self.grad_pass = None
 
 
 def _pooled_chain(fmap, num_levels):
@@ -118,7 +141,7 @@ class _BuildFunction(torch.autograd.Function):
     def backward(ctx, _gtoken, *grads):
         fmap1, fmap2 = ctx.saved_tensors
         state = ctx.state
-        sparse, state.grad = state.grad, None   # a later backward pass through the same graph starts from zero again
+        sparse = state.take_grad_maps()   # a later backward pass through the same graph starts from zero again
         totals = []
         for lvl in range(ctx.num_levels):
             parts = [g for g in (grads[lvl], sparse[lvl] if sparse is not None else None) if g is not None]
@@ -204,17 +227,6 @@ class CorrBlock:
             self.corr_pyramid = list(pyramid)
         else:
             self.corr_pyramid = alo_hip.corr_build(fmap1, fmap2, num_levels)
-
-    def lookup_conv1x1(self, coords, weight, bias, relu=True):
-        """``act(conv1x1(self(coords)))`` without materialising the window features (the motion encoder's ``convc1``);
-        None when the fused kernel does not cover the configuration or a gradient is wanted (the caller then convolves
-        ``self(coords)``).  A C-ABI extra (``alo_corr_lookup_conv1x1``), NOT used by ``RAFT.forward``: measured 0.23 ms against
-        0.20 ms for lookup + convolution, so the model keeps the two-kernel form."""
-        if _needs_grad(coords, weight, bias, *self.corr_pyramid):
-            return None
-        if not alo_hip.corr_lookup_conv1x1_supported(self.corr_pyramid, weight, self.radius):
-            return None
-        return alo_hip.corr_lookup_conv1x1(self.corr_pyramid, coords.float(), weight, bias, self.radius, relu)
 
     def __call__(self, coords):
         coords = coords.float()

@@ -742,161 +742,11 @@ corr_lookup_bwd_kernel(const LookupBwdArgs a) {
     }
 }
 
-// Lookup fused with the 1x1 convolution that consumes it: the window features never leave the chip.  RAFT's motion encoder
-// reads them in `convc1` (update.py:83-101: L*(2r+1)^2 -> Cout channels, + bias, ReLU); here that contraction runs level by
-// level on the bf16 matrix cores at fp32 accuracy (the volume itself uses the two-term fp16 form; here its per-query scaling pass
-// costs more than it saves): out[b, n, query] = act(bias[n] + sum_l sum_k
-// W[n][l][k] * feature_l[k][query]) with every fp32 feature (and, once on the host side, every weight) split exactly into
-// three bf16 terms and the six largest cross products accumulated in fp32.
-// Per level: stage 1 as above; stage 2 writes the level's (2r+1)^2 features of the 32 queries to LDS as three bf16 planes in
-// operand order; then every wave multiplies them into the accumulators of its 32 output channels.  A store instruction
-// writes two whole 128-byte lines (32 consecutive queries of one output channel).
-struct ConvArgs {
-    const uint16_t* weight;   // [3 terms][L][KP / 16][Cout / 32][64 lanes][8] bf16: the convolution's weight regrouped per level
-                              // (K zero-padded to KP) in the order the matrix operand is loaded: lane = 32 * kg + i holds
-                              // W[32 * tile + i][level][16 * kstep + 8 * kg + 0..7]
-    const float* bias;        // (Cout) or null
-    int cout, relu, kp;       // kp = round_up((2r+1)^2, 16)
-};
-
-// a workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-constexpr int kConvThreads = 512;
-constexpr int kConvLevels = 4;   // pyramid levels whose strips are in flight together
-
-template <int R>
-struct ConvLds {
-    static constexpr int WIN = 2 * R + 1, ROWS = WIN + 2, KP = (WIN * WIN + 15) / 16 * 16;
-    static constexpr int hbuf_floats = ROWS * WIN * TQ, meta = WIN * TQ;
-    static constexpr size_t bytes = (size_t)kConvLevels * (hbuf_floats * 4 + meta * 8) + (size_t)3 * KP * TQ * 2;
-};
-
-template <int R>
-__global__ void __launch_bounds__(kConvThreads, 4)
-corr_lookup_conv_kernel(const LookupArgs a, const ConvArgs cv) {
-    using Lds = ConvLds<R>;
-    constexpr int WIN = Lds::WIN, ROWS = Lds::ROWS, KP = Lds::KP, NT = kConvThreads;
-    constexpr int ITEMS = ROWS * TQ;                                  // strips of one level
-    constexpr int SLOTS = (kConvLevels * ITEMS + NT - 1) / NT;       // strips a thread has in flight
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* hbuf = reinterpret_cast<float*>(smem);                                   // [kConvLevels][ROWS][WIN][TQ]
-    float* tybuf = hbuf + kConvLevels * Lds::hbuf_floats;                           // [kConvLevels][WIN][TQ]
-    int* rowbuf = reinterpret_cast<int*>(tybuf + kConvLevels * Lds::meta);
-    uint16_t* feat = reinterpret_cast<uint16_t*>(rowbuf + kConvLevels * Lds::meta);   // [term][k / 8][query][k % 8]
-    const int b = blockIdx.x / a.tiles_per_batch;
-    const int q0 = (blockIdx.x % a.tiles_per_batch) * TQ;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 5, li = lane & 31;
-    const bool multiplies = wave * 32 < cv.cout;   // one 32-channel tile per wave: 8 waves for Cout = 256, 4 for 128
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int o = tid; o < 3 * KP * TQ / 2; o += NT) reinterpret_cast<unsigned*>(feat)[o] = 0u;   // the K padding stays zero
-    const long wterm = (long)cv.cout * a.num_levels * KP;   // elements between two terms of the packed weight
-    for (int l0 = 0; l0 < a.num_levels; l0 += kConvLevels) {
-        const int nl = min(kConvLevels, a.num_levels - l0);
-        // every strip of these levels is requested before the first one is consumed: what a level-by-level walk pays four times
-        // in a row (coordinates -> strip reads with a DRAM page miss each) is paid once
-        Strip<R> st[SLOTS];
-#pragma unroll
-        for (int j = 0; j < SLOTS; ++j) {
-            const int item = j * NT + tid;
-            const int lv = item / ITEMS, rem = item % ITEMS;
-            if (lv < nl) strip_request<R>(a, l0 + lv, b, q0 + rem % TQ, rem / TQ, st[j]);
-        }
-        // ... and consumed slot by slot (items are ordered by level): the levels a slot completes are multiplied while the
-        // strips of the later slots are still on their way.  The barriers in between order LDS traffic only.
-        int done = 0;
-#pragma unroll
-        for (int j = 0; j < SLOTS; ++j) {
-            {
-                const int item = j * NT + tid;
-                const int lv = item / ITEMS, rem = item % ITEMS;
-                if (lv < nl)
-                    strip_finish<R>(a, l0 + lv, rem / TQ, rem % TQ, st[j], hbuf + lv * Lds::hbuf_floats, tybuf + lv * Lds::meta,
-                                    rowbuf + lv * Lds::meta);
-            }
-            lds_barrier();
-            const int ready = j == SLOTS - 1 ? nl : min(nl, ((j + 1) * NT) / ITEMS);
-            for (int lv = done; lv < ready; ++lv) {
-                const float* hb = hbuf + lv * Lds::hbuf_floats;
-                for (int o = tid; o < WIN * WIN * TQ; o += NT) {
-                    const int q = o % TQ, rem = o / TQ;
-                    const int ax = rem / WIN, cy = rem % WIN;
-                    const float ty = tybuf[lv * Lds::meta + cy * TQ + q];
-                    const int r0 = rowbuf[lv * Lds::meta + cy * TQ + q];
-                    const float top = hb[(r0 * WIN + ax) * TQ + q];
-                    const float bot = hb[((r0 + 1) * WIN + ax) * TQ + q];
-                    const float x = (1.0f - ty) * top + ty * bot;
-                    const unsigned hi = __float_as_uint(x);
-                    const float r1 = x - __uint_as_float(hi & 0xffff0000u);
-                    const unsigned mid = __float_as_uint(r1);
-                    const float r2 = r1 - __uint_as_float(mid & 0xffff0000u);
-                    const int at = ((rem >> 3) * TQ + q) * 8 + (rem & 7);
-                    feat[at] = (uint16_t)(hi >> 16);
-                    feat[KP * TQ + at] = (uint16_t)(mid >> 16);
-                    feat[2 * KP * TQ + at] = (uint16_t)(__float_as_uint(r2) >> 16);
-                }
-                lds_barrier();
-                if (multiplies) {
-                    // operand order: a wave's load instruction reads 1 KB of consecutive bytes
-                    const uint16_t* wrow = cv.weight + (((long)(l0 + lv) * (KP / 16) * (cv.cout / 32) + wave) * 64 + lane) * 8;
-#pragma unroll
-                    for (int k0 = 0; k0 < KP; k0 += 16) {
-                        const uint16_t* wk = wrow + (long)(k0 / 16) * (cv.cout / 32) * 512;
-                        const u32x4 wh = *reinterpret_cast<const u32x4*>(wk);
-                        const u32x4 wm = *reinterpret_cast<const u32x4*>(wk + wterm);
-                        const u32x4 wl = *reinterpret_cast<const u32x4*>(wk + 2 * wterm);
-                        const uint16_t* fp = feat + (((k0 >> 3) + kg) * TQ + li) * 8;
-                        const u32x4 fh = *reinterpret_cast<const u32x4*>(fp);
-                        const u32x4 fm = *reinterpret_cast<const u32x4*>(fp + KP * TQ);
-                        const u32x4 fl = *reinterpret_cast<const u32x4*>(fp + 2 * KP * TQ);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wl), as_bf16x8(fh), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fl), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fm), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wm), as_bf16x8(fh), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fm), acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(fh), acc, 0, 0, 0);
-                    }
-                }
-                lds_barrier();   // feat is rewritten by the next level (hbuf by the next group of levels)
-            }
-            done = ready;
-        }
-    }
-    // C/D layout: col = lane & 31 (query), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (output channel)
-    const int i = q0 + li;
-    if (multiplies) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            float v = acc[r] + (cv.bias ? cv.bias[n] : 0.f);
-            if (cv.relu) v = fmaxf(v, 0.f);
-            if (i < a.HW) a.out[((long)b * cv.cout + n) * a.HW + i] = v;
-        }
-    }
-}
-
 template <int R>
 int launch_lookup(const LookupArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(corr_lookup_kernel<R>, dim3(a.B * a.tiles_per_batch, a.num_levels), dim3(lookup_threads<R>()), 0, stream, a);
     return check_launch("alo_corr_lookup");
 }
-template <int R>
-int launch_lookup_conv(const LookupArgs& a, const ConvArgs& cv, hipStream_t stream) {
-    static unsigned long long attr_done = 0;   // per template instance, one bit per device
-    {
-        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(corr_lookup_conv_kernel<R>), (int)ConvLds<R>::bytes, &attr_done);
-        if (e != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_lookup_conv1x1: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(corr_lookup_conv_kernel<R>, dim3(a.B * a.tiles_per_batch), dim3(kConvThreads), ConvLds<R>::bytes, stream, a, cv);
-    return check_launch("alo_corr_lookup_conv1x1");
-}
-
 template <int R>
 int launch_lookup_coords_bwd(const LookupCoordsBwdArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(corr_lookup_coords_bwd_kernel<R>, dim3(a.fwd.B * a.fwd.tiles_per_batch, a.fwd.num_levels), dim3(lookup_threads<R>()), 0,
@@ -1139,26 +989,5 @@ extern "C" int alo_corr_lookup_backward_coords(const float* const* levels, const
         case 5: return launch_lookup_coords_bwd<5>(ca, stream);
         case 6: return launch_lookup_coords_bwd<6>(ca, stream);
         default: return launch_lookup_coords_bwd<7>(ca, stream);
-    }
-}
-
-extern "C" int alo_corr_lookup_conv1x1_kpad(int radius) { return ((2 * radius + 1) * (2 * radius + 1) + 15) / 16 * 16; }
-
-extern "C" int alo_corr_lookup_conv1x1(const float* const* levels, const float* coords, const void* weight_packed, const float* bias,
-                                       float* out, int B, int H, int W, int radius, int num_levels, int cout, int relu,
-                                       void* stream_) {
-    const char* what = "alo_corr_lookup_conv1x1";
-    LookupArgs a;
-    if (int rc = fill_lookup_args(a, levels, coords, out, B, H, W, radius, num_levels, what)) return rc;
-    ALO_REQUIRE(weight_packed && ((uintptr_t)weight_packed & 15) == 0, ALO_ERR_INVALID_ARGUMENT, "%s: weight must be non-null and 16-byte aligned", what);
-    ALO_REQUIRE(cout > 0 && cout % 128 == 0 && cout <= 256, ALO_ERR_UNSUPPORTED, "%s: Cout must be 128 or 256, got %d", what, cout);
-    const ConvArgs cv{static_cast<const uint16_t*>(weight_packed), bias, cout, relu ? 1 : 0, alo_corr_lookup_conv1x1_kpad(radius)};
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    switch (radius) {
-        case 1: return launch_lookup_conv<1>(a, cv, stream);
-        case 2: return launch_lookup_conv<2>(a, cv, stream);
-        case 3: return launch_lookup_conv<3>(a, cv, stream);
-        case 4: return launch_lookup_conv<4>(a, cv, stream);
-        default: return fail(ALO_ERR_UNSUPPORTED, "%s: radius must be in [1,4], got %d", what, radius);
     }
 }

@@ -69,7 +69,7 @@ F32_MFMA_TAGS = ()  # kernels whose contraction runs on the fp32 matrix instruct
 # largest cross products in fp32: executed matrix flops = products x algorithmic.  corr_build: two fp16 terms, 3 products (it also
 # multiplies 220 pooled level-3 columns per 14400 at the 1280x720 grid: x 1.0153); the fused lookup + convolution: three bf16
 # terms, 6 products, K padded from 81 to 96 per level
-SPLIT_TAGS = {"corr_build": 3 * (1 + 220.0 / 14400.0), "corr_lookup_convc1": 6 * 96.0 / 81.0}
+SPLIT_TAGS = {"corr_build": 3 * (1 + 220.0 / 14400.0)}
 
 
 def parse():

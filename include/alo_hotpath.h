@@ -237,7 +237,8 @@ int alo_corr_lookup(const float* const* levels, const float* coords, float* out,
  * Backward of alo_corr_lookup with respect to the pyramid: the exact adjoint of the lookup, ACCUMULATED into gradient maps.
  * The reference's CorrBlock is plain torch code (alonet/raft/corr.py:29-50: bilinear_sampler = F.grid_sample) that autograd
  * differentiates; RAFT detaches the coordinates before every lookup (alonet/raft/raft.py:186), so this is the gradient a RAFT
- * training step needs from the block.  (The gradient with respect to the coordinates is not provided here.)
+ * training step needs from the block.  (The gradient with respect to the coordinates is a kernel of its own:
+ * alo_corr_lookup_backward_coords below.)
  *
  *   grad_levels[l][b*HW + y*W + x, :, :] += sum over the window taps (a, c) of
  *                                           grad_out[b, l*(2r+1)^2 + a*(2r+1) + c, y, x] * bilinear weights of that tap
@@ -268,26 +269,6 @@ int alo_corr_lookup_backward(float* const* grad_levels, const float* coords, con
  */
 int alo_corr_lookup_backward_coords(const float* const* levels, const float* coords, const float* grad_out,
                                     float* grad_coords_levels, int B, int H, int W, int radius, int num_levels, void* stream);
-
-/*
- * The lookup above fused with the 1x1 convolution that consumes it in RAFT's motion encoder (update.py:83-101, `convc1`:
- * L*(2r+1)^2 -> Cout channels, + bias, ReLU): the (B, L*(2r+1)^2, H, W) window features are never written.
- *
- *   out[b, n, y, x] = act( bias[n] + sum_k weight[n, k] * lookup[b, k, y, x] )
- *
- *   weight_packed  (3, L, KP/16, Cout/32, 64, 8) bf16: the convolution's (Cout, L*(2r+1)^2, 1, 1) fp32 weight regrouped per pyramid
- *                  level (each level's (2r+1)^2 entries zero-padded to KP = alo_corr_lookup_conv1x1_kpad(radius)), split exactly into
- *                  three bf16 terms w = t0 + t1 + t2 (t0 = upper 16 bits of w, t1 = upper 16 bits of w - t0, t2 = the rest) and
- *                  laid out in the order the matrix operand is loaded: entry [t][l][s][c][32*g + i][e] = term t of
- *                  W[32*c + i][l][16*s + 8*g + e]; 16-byte aligned
- *   bias           (Cout) float32 or NULL;   relu != 0: act = max(., 0)
- *   out            (B, Cout, H, W) float32, fully written
- *   Cout in {128, 256}, 1 <= radius <= 4.  The contraction runs on the bf16 matrix cores at fp32 accuracy (features split the same
- *   way on the fly, the six largest cross products accumulated in fp32).
- */
-int alo_corr_lookup_conv1x1_kpad(int radius);
-int alo_corr_lookup_conv1x1(const float* const* levels, const float* coords, const void* weight_packed, const float* bias,
-                            float* out, int B, int H, int W, int radius, int num_levels, int cout, int relu, void* stream);
 
 /*
  * ---- Extensions: one-pass epilogues of the layers that call the attention op -------------------------------------------

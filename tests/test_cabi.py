@@ -20,7 +20,7 @@ def declared_functions():
 def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted(
         ["alo_abi_version", "alo_last_error", "alo_msda_forward", "alo_msda_forward_fused", "alo_msda_backward", "alo_msda_backward_hinted", "alo_corr_level_shape",
-         "alo_corr_build_workspace_bytes", "alo_corr_build", "alo_corr_lookup", "alo_corr_lookup_backward", "alo_corr_lookup_backward_coords", "alo_corr_lookup_conv1x1", "alo_corr_lookup_conv1x1_kpad", "alo_add_layernorm", "alo_bias_act", "alo_msda_forward_fused_hm", "alo_msda_forward_fused_hm_rows", "alo_msda_forward_fused_hm_resident", "alo_msda_resident_levels", "alo_value_head_major", "alo_bias_act_nchw", "alo_gru_gate", "alo_gru_update", "alo_pos_sine_flat", "alo_linear_shortk", "alo_ffn256", "alo_pack_mfma_b", "alo_value_proj_head_major", "alo_conv3x3_nhwc", "alo_conv3x3_workspace_bytes", "alo_stem_conv_pool", "alo_mask_pyramid", "alo_panoptic_onehot", "alo_encoder_reference_points", "alo_linear_packed", "alo_conv1x1_nhwc", "alo_groupnorm_rows", "alo_groupnorm_rows_workspace_bytes", "alo_groupnorm_rows_act", "alo_upsample_add_nhwc", "alo_conv3x3_small_nhwc"]
+         "alo_corr_build_workspace_bytes", "alo_corr_build", "alo_corr_lookup", "alo_corr_lookup_backward", "alo_corr_lookup_backward_coords", "alo_add_layernorm", "alo_bias_act", "alo_msda_forward_fused_hm", "alo_msda_forward_fused_hm_rows", "alo_msda_forward_fused_hm_resident", "alo_msda_resident_levels", "alo_value_head_major", "alo_bias_act_nchw", "alo_gru_gate", "alo_gru_update", "alo_pos_sine_flat", "alo_linear_shortk", "alo_ffn256", "alo_pack_mfma_b", "alo_value_proj_head_major", "alo_conv3x3_nhwc", "alo_conv3x3_workspace_bytes", "alo_stem_conv_pool", "alo_mask_pyramid", "alo_panoptic_onehot", "alo_encoder_reference_points", "alo_linear_packed", "alo_conv1x1_nhwc", "alo_groupnorm_rows", "alo_groupnorm_rows_workspace_bytes", "alo_groupnorm_rows_act", "alo_upsample_add_nhwc", "alo_conv3x3_small_nhwc"]
     )
 
 

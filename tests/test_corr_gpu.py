@@ -216,36 +216,6 @@ def test_batch_items_are_independent():
     assert torch.equal(full(coords)[1], solo(coords[1:2])[0])
 
 
-@pytest.mark.parametrize("B,H,W,r,L,cout", [(2, 24, 32, 4, 4, 256), (1, 19, 23, 3, 4, 128), (1, 90, 160, 4, 4, 256)])
-def test_lookup_fused_with_the_1x1_convolution(B, H, W, r, L, cout):
-    """alo_corr_lookup_conv1x1 == relu(conv1x1(alo_corr_lookup)) (RAFT's motion encoder, update.py:83-101): the lookup is
-    pinned on the oracle above, the contraction here against a float64 product of the same features."""
-    gen = torch.Generator(device="cpu").manual_seed(H + cout)
-    f1 = torch.randn(B, 64, H, W, generator=gen).to(DEV)
-    f2 = torch.randn(B, 64, H, W, generator=gen).to(DEV)
-    levels = alo_hip.corr_build(f1, f2, L)
-    coords = coords_grid(B, H, W, device=DEV) + torch.randn(B, 2, H, W, generator=gen).to(DEV) * 3.0
-    K = L * (2 * r + 1) ** 2
-    weight = (torch.randn(cout, K, 1, 1, generator=gen) / K ** 0.5).to(DEV)
-    bias = torch.randn(cout, generator=gen).to(DEV)
-    feats = alo_hip.corr_lookup(levels, coords, r)
-    want = torch.relu(torch.einsum("nk,bkhw->bnhw", weight.view(cout, K).double(), feats.double()) + bias.double()[None, :, None, None])
-    got = alo_hip.corr_lookup_conv1x1(levels, coords, weight, bias, r, relu=True)
-    assert got.shape == (B, cout, H, W) and got.dtype == torch.float32
-    assert (got.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
-    plain = alo_hip.corr_lookup_conv1x1(levels, coords, weight, None, r, relu=False)
-    want2 = torch.einsum("nk,bkhw->bnhw", weight.view(cout, K).double(), feats.double())
-    assert (plain.double() - want2).abs().max().item() <= 2e-5 * max(1.0, want2.abs().max().item())
-
-
-def test_corr_block_lookup_conv1x1_declines_what_the_kernel_does_not_cover():
-    f = torch.randn(1, 32, 16, 16, device=DEV)
-    blk = CorrBlock(f, f, radius=3)
-    conv = torch.nn.Conv2d(4 * 49, 96, 1).to(DEV)   # RAFT-small's convc1: 96 output channels
-    with torch.no_grad():
-        assert blk.lookup_conv1x1(coords_grid(1, 16, 16, device=DEV), conv.weight, conv.bias) is None
-
-
 # ---- BASELINE configs[2] at its own batch size ------------------------------------------------------------------------------------
 def test_config3_build_and_lookup_at_batch4_720p():
     """B = 4 pairs of 256 x 90 x 160 features — where level 0 (3.3 GB) crosses 2^31 bytes and the per-item power-of-two scales,
@@ -300,7 +270,7 @@ def test_config3_build_and_lookup_at_batch4_720p():
 def test_hip_corr_block_under_autograd_has_the_gradients_of_the_torch_formulation():
     """The reference's CorrBlock is differentiable torch code (corr.py:12-60).  Here the forward is the HIP kernels whatever the
     grad mode; under autograd the lookup's backward is the kernel's adjoint (accumulated maps), the build's two GEMMs per level, the
-    coordinates' the torch formulation: gradients w.r.t. both feature maps (through the lookup AND through pyramid tensors used
+    coordinates' the alo_corr_lookup_backward_coords kernel: gradients w.r.t. both feature maps (through the lookup AND through pyramid tensors used
     directly in the loss) and w.r.t. the coordinates must equal those of TorchCorrBlock."""
     from alonet.raft.corr import TorchCorrBlock
 
@@ -462,7 +432,7 @@ def test_corr_block_gradients_over_many_lookups_and_repeated_backward():
 
 
 def test_g18_hip_corr_block_has_the_reference_gradients(golden):
-    """The HIP block's gradients (adjoint kernel + GEMMs; coordinates through the torch formulation) against the REFERENCE's own
+    """The HIP block's gradients (adjoint kernel + GEMMs; coordinates through the alo_corr_lookup_backward_coords kernel) against the REFERENCE's own
     CorrBlock differentiated by autograd (G18, float64 run): odd sizes, 3 levels, radius 2, three lookups, windows off the map."""
     g = golden("g18_corr_grad.npz")
     f1 = torch.from_numpy(g["f1"]).to(DEV).requires_grad_(True)
@@ -502,3 +472,30 @@ def test_raft_is_trainable_with_the_default_corr_block():
     loss.backward()
     g = model.fnet.conv1.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
+
+
+def test_partial_backward_does_not_leak_into_the_next_one():
+    """Round-4 advisor finding on the real kernels: ``autograd.grad(loss, coords)`` runs the lookups' backward (which accumulates
+    pyramid-gradient maps) without reaching the build node; the following full backward must not see those maps again."""
+    from alonet.raft.corr import TorchCorrBlock
+
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    f1 = torch.randn(1, 32, 12, 16, generator=gen).to(DEV)
+    f2 = torch.randn(1, 32, 12, 16, generator=gen).to(DEV)
+    cs = [coords_grid(1, 12, 16, device=DEV) + torch.randn(1, 2, 12, 16, generator=gen).to(DEV) * 2.0 for _ in range(2)]
+
+    def grads(cls, partial_first):
+        a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        cc = [c.clone().requires_grad_(True) for c in cs]
+        blk = cls(a, b, num_levels=3, radius=2)
+        loss = sum(blk(c).square().sum() for c in cc)
+        if partial_first:
+            torch.autograd.grad(loss, cc, retain_graph=True)
+        loss.backward()
+        return a.grad, b.grad
+
+    want = grads(TorchCorrBlock, False)
+    for partial_first in (False, True):
+        got = grads(CorrBlock, partial_first)
+        for g, w in zip(got, want):
+            assert (g - w).abs().max().item() <= 2e-4 * w.abs().max().item(), partial_first

@@ -330,7 +330,11 @@ def test_cache_keys_do_not_read_version_counters_of_inference_tensors():
     assert alo_hip.tensor_version(normal) == normal._version == 1
     with torch.inference_mode():
         inf = torch.zeros(3)
-    assert inf.is_inference() and alo_hip.tensor_version(inf) == -1
+    # no counter to read: the key of an inference tensor equals nothing (not even the key of the previous call), so nothing
+    # derived from it is ever served from a cache after an in-place update under inference mode (round-4 advisor finding)
+    assert inf.is_inference()
+    k1, k2 = (alo_hip.tensor_version(inf), inf.data_ptr()), (alo_hip.tensor_version(inf), inf.data_ptr())
+    assert k1 != k2 and not (k1 == k2)
     import glob
     import os
 
@@ -341,3 +345,129 @@ def test_cache_keys_do_not_read_version_counters_of_inference_tensors():
         if path.endswith(os.path.join("deformable_detr", "deformable_detr.py")):
             continue   # its two reads are guarded by is_inference() (the packed detections)
         assert "._version" not in src, path
+
+
+def _mock_corr_kernels(monkeypatch):
+    """The four correlation entry points of alo_hip replaced by the torch formulation (CPU): what is under test is the autograd
+    wiring of alonet.raft.corr.CorrBlock, not the kernels."""
+    import alo_hip
+    from alonet.raft import corr as C
+
+    def build(f1, f2, num_levels=4):
+        return [p.detach().contiguous() for p in C.pyramid_torch(f1.detach(), f2.detach(), num_levels)]
+
+    def lookup(levels, coords, radius=4):
+        return C.lookup_torch([p.detach() for p in levels], coords.detach(), radius)
+
+    def lookup_backward(grad_levels, coords, grad_out, radius=4):
+        with torch.enable_grad():
+            leaves = [torch.zeros_like(g).requires_grad_(True) for g in grad_levels]
+            out = C.lookup_torch(leaves, coords.detach(), radius)   # linear in the levels: the gradient does not depend on their values
+            grads = torch.autograd.grad(out, leaves, grad_out)
+        for acc, g in zip(grad_levels, grads):
+            acc += g
+        return grad_levels
+
+    def lookup_backward_coords(levels, coords, grad_out, radius=4):
+        with torch.enable_grad():
+            c = coords.detach().requires_grad_(True)
+            (g,) = torch.autograd.grad(C.lookup_torch([p.detach() for p in levels], c, radius), c, grad_out)
+        return g
+
+    monkeypatch.setattr(alo_hip, "corr_build", build)
+    monkeypatch.setattr(alo_hip, "corr_lookup", lookup)
+    monkeypatch.setattr(alo_hip, "corr_lookup_backward", lookup_backward)
+    monkeypatch.setattr(alo_hip, "corr_lookup_backward_coords", lookup_backward_coords)
+
+
+def test_corr_block_gradient_maps_belong_to_one_backward_pass(monkeypatch):
+    """Round-4 advisor finding: a backward pass that runs the lookups' backward but never reaches the build node
+    (``autograd.grad(loss, coords)``) left the accumulated pyramid-gradient maps behind, and the next full backward added them
+    again — exactly twice the feature gradients.  The maps now die with the pass that made them."""
+    from alonet.raft.corr import CorrBlock, TorchCorrBlock
+
+    _mock_corr_kernels(monkeypatch)
+    gen = torch.Generator().manual_seed(5)
+    f1 = torch.randn(1, 8, 6, 7, generator=gen)
+    f2 = torch.randn(1, 8, 6, 7, generator=gen)
+    base = torch.stack(torch.meshgrid(torch.arange(7.0), torch.arange(6.0), indexing="xy"), 0)[None]
+    coords = [base + torch.randn(1, 2, 6, 7, generator=gen) for _ in range(2)]
+
+    def run(block_cls, partial_first):
+        a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        cs = [c.clone().requires_grad_(True) for c in coords]
+        blk = block_cls(a, b, num_levels=2, radius=1)
+        loss = sum(blk(c).square().sum() for c in cs)
+        if partial_first:
+            torch.autograd.grad(loss, cs, retain_graph=True)   # lookups' backward only: the build node is never reached
+            if block_cls is CorrBlock:
+                assert blk._state.grad is None, "the partial pass left its maps behind"
+        loss.backward()
+        return a.grad, b.grad, [c.grad for c in cs]
+
+    want = run(TorchCorrBlock, False)
+    for partial_first in (False, True):
+        got = run(CorrBlock, partial_first)
+        for g, w in zip(got[:2], want[:2]):
+            assert (g - w).abs().max().item() <= 1e-4 * w.abs().max().item(), partial_first
+        for g, w in zip(got[2], want[2]):
+            assert (g - w).abs().max().item() <= 1e-4 * max(1.0, w.abs().max().item())
+
+
+def test_corr_block_backward_that_aborts_leaves_no_maps(monkeypatch):
+    """Same finding, other trigger: an exception between the lookups' backward and the build node."""
+    import alo_hip
+    from alonet.raft.corr import CorrBlock
+
+    _mock_corr_kernels(monkeypatch)
+    f1 = torch.randn(1, 4, 5, 5).requires_grad_(True)
+    f2 = torch.randn(1, 4, 5, 5).requires_grad_(True)
+    blk = CorrBlock(f1, f2, num_levels=2, radius=1)
+    coords = torch.rand(1, 2, 5, 5) * 4
+    loss = blk(coords).sum() + blk(coords + 0.5).sum()
+    calls = {"n": 0}
+    real = alo_hip.corr_lookup_backward
+
+    def flaky(*args, **kw):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise RuntimeError("injected")
+        return real(*args, **kw)
+
+    monkeypatch.setattr(alo_hip, "corr_lookup_backward", flaky)
+    with pytest.raises(RuntimeError, match="injected"):
+        loss.backward(retain_graph=True)
+    # the engine runs no end-of-pass callbacks after an exception: the half-filled maps are still there, tagged with the dead pass ...
+    monkeypatch.setattr(alo_hip, "corr_lookup_backward", real)
+    loss.backward()
+    ga, gb = f1.grad.clone(), f2.grad.clone()
+    # ... and the next pass must not add them: its gradients equal those of a fresh block
+    a, b = f1.detach().clone().requires_grad_(True), f2.detach().clone().requires_grad_(True)
+    blk2 = CorrBlock(a, b, num_levels=2, radius=1)
+    (blk2(coords).sum() + blk2(coords + 0.5).sum()).backward()
+    assert torch.allclose(ga, a.grad, rtol=1e-5, atol=1e-6) and torch.allclose(gb, b.grad, rtol=1e-5, atol=1e-6)
+    assert blk._state.grad is None
+
+
+def test_model_with_graph_wrappers_still_pickles_and_deep_copies():
+    """Round-4 advisor finding: GraphedForward kept its registry (a WeakSet) inside ``model.__dict__``, so ``torch.save(model)``
+    failed on the weak references and ``copy.deepcopy(model)`` carried ghost wrappers over.  The registry lives outside now."""
+    import copy
+    import io
+
+    from alonet.common import GraphedForward
+    from alonet.common import hip_graph
+
+    model = torch.nn.Linear(3, 2)
+    a, b = GraphedForward(model), GraphedForward(model)
+    assert set(hip_graph._wrappers_of(model)) == {a, b}
+    assert not any(isinstance(v, type(hip_graph._WRAPPERS.get(model))) for v in model.__dict__.values())
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    clone = copy.deepcopy(model)
+    assert len(hip_graph._wrappers_of(clone)) == 0 and torch.equal(clone.weight, model.weight)
+    del a
+    import gc
+
+    gc.collect()
+    assert set(hip_graph._wrappers_of(model)) == {b}
