@@ -315,6 +315,21 @@ class DeformableDETR(nn.Module):
         return None
 
     # ---- post-processing ----------------------------------------------------------------------------------------------
+    def _to_host_pinned(self, packed):
+        """The step's one device-to-host hand-over (B x Q x 6 floats) through a page-locked buffer kept with the model: the copy is
+        a DMA straight into it (a pageable ``.cpu()`` stages through the runtime's own bounce buffer under a process-wide lock —
+        with eight ranks on one host at 9 ms per step that is the first place weak scaling is lost).  The buffer is overwritten by the
+        next call; everything inference() returns is copied out of it (boolean selection)."""
+        if not packed.is_cuda:
+            return packed
+        buf = self.__dict__.get("_alo_host_detections")
+        if buf is None or buf.shape != packed.shape or buf.dtype != packed.dtype:
+            buf = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+            self.__dict__["_alo_host_detections"] = buf
+        buf.copy_(packed, non_blocking=True)
+        torch.cuda.current_stream(packed.device).synchronize()
+        return buf
+
     def get_outs_labels(self, m_outputs=None, activation_fn=None):
         assert m_outputs is not None
         activation_fn = m_outputs.get("activation_fn") or activation_fn or self.activation_fn
@@ -352,7 +367,7 @@ class DeformableDETR(nn.Module):
         if packed is not None:
             # the forward already packed (score, label, box) of THESE tensors: one copy to the host, one selection for the whole
             # batch, then views per image
-            host = packed.cpu()
+            host = self._to_host_pinned(packed)
             if filters is None:
                 filters = self.get_outs_filter(outs_scores=host[..., 0], outs_labels=host[..., 1].long(), threshold=threshold,
                                                activation_fn=activation_fn, **kwargs)

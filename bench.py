@@ -89,6 +89,9 @@ def parse():
                     help="also time K detection steps with eager launches after the graph-replayed ones (0 = skip)")
     ap.add_argument("--fp32-steps", type=int, default=12,
                     help="also time K detection steps in fp32 (the <= 1e-3 mode; skipped when --dtype fp32 is the headline); 0 = skip")
+    ap.add_argument("--trained-steps", type=int, default=20,
+                    help="also time K detection steps with TRAINED-LIKE sampling offsets (tools/kbench.py TRAINED_SIGMA_PX: the "
+                         "random-init model samples the friendliest pattern a model can, a 1-4 px ring); 0 = skip")
     ap.add_argument("--micro-reps", type=int, default=10,
                     help="launches per SURVEY 8(d) kernel micro-benchmark (MSDA forward / backward on three sampling distributions); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,7 +105,9 @@ def parse():
     ap.add_argument("--panoptic-steps", type=int, default=25,
                     help="also time K steps of PanopticHead over DeformableDETR-R50 (BASELINE configs[4]: --batch frames "
                          "per GPU, --panoptic-queries kept queries per frame); 0 = skip")
-    ap.add_argument("--panoptic-queries", type=int, default=16)
+    ap.add_argument("--panoptic-queries", default="16,50,100",
+                    help="kept queries per frame, comma-separated: the mask head's cost is linear in it and the reference keeps "
+                         "whatever passes the threshold (detr_panoptic.py:110-200); the FIRST value is the leg's headline")
     ap.add_argument("--force-dist", action="store_true",
                     help="test only: create the RCCL process group (and wrap the training model in DDP) even with ONE rank, so the "
                          "N > 1 code path (nccl init on the device, GPU barriers, the timing all-reduce, DDP's bucketed all-reduce) "
@@ -110,6 +115,7 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 and the control collectives run on gloo — drives the N > 1 GPU branch "
                          "(sharding, fences, max-over-ranks, DDP) on a one-GPU box; RCCL needs one device per rank")
+    ap.add_argument("--no-affinity", action="store_true", help="N > 1: leave the ranks' CPU affinity to the launcher / the OS")
     ap.add_argument("--selftest", action="store_true",
                     help="CPU/gloo dry run of the launch, sharding, fencing and max-over-ranks logic (no GPU, no kernels)")
     return ap.parse_args()
@@ -161,6 +167,98 @@ def self_launch(a):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _core_of(cpu):
+    """The physical core a logical CPU belongs to (its lowest-numbered hardware thread); the CPU itself when sysfs does not say."""
+    try:
+        with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as f:
+            return min(_cpulist(f.read()))
+    except (OSError, ValueError):
+        return cpu
+
+
+def affinity_plan(avail, nlocal, gpu_nodes=None, node_cpus=None, core_of=_core_of):
+    """Disjoint CPU sets for the ``nlocal`` ranks of this host, whole physical cores each (a rank's Python launch thread, its
+    Hungarian matching and its OpenMP pool then never share a core with another rank's).  With the NUMA node of every rank's GPU
+    known (``gpu_nodes[i]``, -1 = unknown) and the nodes' CPU lists (``node_cpus``), a rank gets cores of ITS GPU's node — the host
+    memory its pinned buffers and launch queues live in is then local to the PCIe root the GPU hangs on; ranks of one node split
+    that node's cores evenly.  Whenever that cannot be done for every rank (unknown nodes, a node with fewer available cores than
+    ranks) ALL ranks fall back to an even split of the available cores in CPU order.  Returns ``nlocal`` sorted lists."""
+    avail = sorted(set(avail))
+    cores = {}
+    for c in avail:
+        cores.setdefault(core_of(c), []).append(c)
+    core_ids = sorted(cores)
+
+    def split(ids, n):
+        return [ids[i * len(ids) // n:(i + 1) * len(ids) // n] for i in range(n)]
+
+    plan = None
+    if gpu_nodes is not None and node_cpus and len(gpu_nodes) == nlocal and all(g >= 0 for g in gpu_nodes):
+        plan = [None] * nlocal
+        for node in sorted(set(gpu_nodes)):
+            ranks = [r for r in range(nlocal) if gpu_nodes[r] == node]
+            local_cores = [cid for cid in core_ids if cid in set(node_cpus.get(node, ()))]
+            if len(local_cores) < len(ranks):
+                plan = None
+                break
+            for r, share in zip(ranks, split(local_cores, len(ranks))):
+                plan[r] = share
+    if plan is None:
+        if len(core_ids) < nlocal:   # fewer cores than ranks: nothing disjoint to hand out
+            return [list(avail) for _ in range(nlocal)]
+        plan = split(core_ids, nlocal)
+    return [sorted(c for cid in share for c in cores[cid]) for share in plan]
+
+
+def gpu_numa_nodes(nlocal):
+    """NUMA node of each visible GPU from its PCI address (sysfs), -1 where unknown.  Needs no HIP context on the other devices."""
+    nodes = []
+    for i in range(nlocal):
+        node = -1
+        try:
+            pr = torch.cuda.get_device_properties(i)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                node = int(f.read().strip())
+        except Exception:   # noqa: BLE001  (no such property / no sysfs entry: unknown)
+            node = -1
+        nodes.append(node)
+    return nodes
+
+
+def bind_rank_to_cpus(local, nlocal, on_gpu):
+    """Pin this rank to its share of the host's cores (affinity_plan) and size its thread pools to it.  Returns the CPU list."""
+    if nlocal <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    avail = sorted(os.sched_getaffinity(0))
+    node_cpus = {}
+    try:
+        for name in os.listdir("/sys/devices/system/node"):
+            if name.startswith("node") and name[4:].isdigit():
+                with open(f"/sys/devices/system/node/{name}/cpulist") as f:
+                    node_cpus[int(name[4:])] = _cpulist(f.read())
+    except OSError:
+        node_cpus = {}
+    nodes = gpu_numa_nodes(nlocal) if on_gpu else None
+    mine = affinity_plan(avail, nlocal, nodes, node_cpus)[local]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(32, len({_core_of(c) for c in mine}))))
+    return mine
+
+
 def init_dist(n_gpus, on_gpu=True, share_gpu=False, force=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,12 +287,18 @@ def fence(world):
         torch.cuda.synchronize()
 
 
+LAST_RANK_SECONDS = []   # every rank's own time of the most recent timed region (the reported one is their maximum)
+
+
 def max_over_ranks(seconds, world, device):
+    LAST_RANK_SECONDS[:] = [seconds]
     if world == 1 and not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    LAST_RANK_SECONDS[:] = [float(x.item()) for x in every]
+    return max(LAST_RANK_SECONDS)
 
 
 def timed_steps(step_fn, steps, warmup, world, device):
@@ -218,10 +322,64 @@ def detection_inputs(batch, rank, device, dtype):
     return frames.to(dtype) if dtype != torch.float32 else frames
 
 
-def build_detector(device, dtype):
+def build_detector(device, dtype, trained_like=False):
     torch.manual_seed(0)
     model = DeformableDetrR50(num_classes=91, aux_loss=False, device=device).eval()
+    if trained_like:
+        make_trained_like(model)
     return model.to(dtype) if dtype != torch.float32 else model
+
+
+def make_trained_like(model, seed=11):
+    """Give every MSDeformAttn of ``model`` the sampling-offset statistics of tools/kbench.py's "trained" generator (checkpoints
+    cannot be fetched offline; a random-init module has ``sampling_offsets.weight == 0`` and therefore samples the bare 1-4 px
+    ring, ops/modules/ms_deform_attn.py:70-88 of the reference — the friendliest pattern a model can produce).  The bias keeps
+    the ring and gains a static heavy-tailed term, sigma_l / 2 x Student-t(3) per (head, level, point); the weight becomes
+    N(0, (sigma_l / |q|)^2) so that the query-dependent term has a standard deviation of about sigma_l pixels on level l
+    (|q|^2 = 256 x 1.5: LayerNorm-ed source + sine position code).  Returns nothing; the achieved spread is measured by
+    ``offset_spread_px`` on the running model and reported next to the frame rate."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kbench
+    from alonet.deformable_detr.ops.modules import MSDeformAttn
+
+    gen = torch.Generator().manual_seed(seed)
+    sigma = torch.tensor(kbench.TRAINED_SIGMA_PX)
+    for mod in model.modules():
+        if not isinstance(mod, MSDeformAttn):
+            continue
+        so = mod.sampling_offsets
+        M, L, P = mod.n_heads, mod.n_levels, mod.n_points
+        sg = sigma[:L].view(1, L, 1, 1).expand(M, L, P, 2)
+        z = torch.randn(M, L, P, 2, generator=gen)
+        chi = torch.randn(M, L, P, 2, 3, generator=gen).square().sum(-1)
+        with torch.no_grad():
+            so.bias.add_((0.5 * sg * z / (chi / 3.0).sqrt() / 3.0 ** 0.5).reshape(-1).to(so.bias))
+            w = torch.randn(M * L * P * 2, so.weight.shape[1], generator=gen) * (sg.reshape(-1, 1) / (1.5 * so.weight.shape[1]) ** 0.5)
+            so.weight.copy_(w.to(so.weight))
+    alo_hip.invalidate_caches(model)
+
+
+def offset_spread_px(model, frames):
+    """Standard deviation (pixels of the sampled level, per level) of the sampling offsets around the ring, measured on the first
+    encoder layer of the running model: what the "trained-like" leg really sampled."""
+    layer = model.transformer.encoder.layers[0].self_attn
+    seen = {}
+
+    def grab(mod, args, kwargs):
+        seen["q"] = (args[0] if args else kwargs["query"]).detach()
+
+    h = layer.register_forward_pre_hook(grab, with_kwargs=True)
+    try:
+        with torch.no_grad():
+            model(frames)
+    finally:
+        h.remove()
+    q = seen["q"][:1].float()
+    so = layer.sampling_offsets
+    off = torch.nn.functional.linear(q, so.weight.float(), so.bias.float()).view(-1, layer.n_heads, layer.n_levels, layer.n_points, 2)
+    ring = off.mean(0, keepdim=True)
+    return [round(float(x), 2) for x in (off - ring).pow(2).mean((0, 1, 3, 4)).sqrt().cpu()] + \
+           [round(float(ring.abs().amax()), 2)]
 
 
 def flow_inputs(batch, rank, device):
@@ -341,8 +499,9 @@ def micro_benchmarks(reps):
     """the MSDA kernels alone, B = 8 forward / B = 4 backward at the 1333x800 pyramid, on three synthetic
     sampling distributions (generators: tools/kbench.py) — `ring`: the module's initial head-direction ring of 1-4 px + jitter
     (what a randomly initialised model, i.e. bench.py's detection and training legs, produce); `survey`: own pixel centre +
-    U(-0.05, 0.05) in normalised units (SURVEY 8(d)'s encoder-like input: +-8 x +-5 px on level 0); `uniform`: U(0, 1) over the
-    whole map (decoder-like / worst case).  HIP events around `reps` back-to-back launches."""
+    U(-0.05, 0.05) in normalised units (SURVEY 8(d)'s encoder-like input: +-8 x +-5 px on level 0); `trained`: the ring + a heavy-tailed, level-dependent
+    spread of 1.5-3 px (tools/kbench.py TRAINED_SIGMA_PX: a stand-in for a trained model, whose checkpoints cannot be fetched
+    offline); `uniform`: U(0, 1) over the whole map (decoder-like / worst case).  HIP events around `reps` back-to-back launches."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kbench
 
@@ -355,12 +514,12 @@ def micro_benchmarks(reps):
 
     # the bench's own kernel (bf16, fused prologue, head-major value; LDS-resident coarse levels) and the plain head-major kernel
     # beside it, on all three distributions: the resident kernel's gain rests on ~190 consecutive queries sharing one slab's rows
-    for kind in ("ring", "survey", "uniform"):
+    for kind in ("ring", "survey", "trained", "uniform"):
         for resident in (True, False):
             r = kbench.bench_msda_fused_hm(8, reps, resident=resident, kind=kind)[1]
             out[f"msda_fwd_fused_hm[{kind}] bf16 N=8" + ("" if resident else " plain")] = entry(r)
         torch.cuda.empty_cache()
-    for kind, tag in (("encoder", "ring"), ("survey", "survey"), ("uniform", "uniform")):
+    for kind, tag in (("encoder", "ring"), ("survey", "survey"), ("trained", "trained"), ("uniform", "uniform")):
         for dt, dn in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
             out[f"msda_fwd[{tag}] {dn} N=8"] = entry(kbench.bench_msda_fwd(8, S, kind, dt, reps))
         out[f"msda_bwd[{tag}] f32 N=4"] = entry(kbench.bench_msda_bwd(4, S, kind, torch.float32, max(3, reps // 2)))
@@ -402,22 +561,40 @@ def offline_traffic(a):
         return json.load(f)
 
 
-def live_traffic(a):
-    """``roofline.traffic`` collected IN this run: FETCH_SIZE and WRITE_SIZE of the dominant kernel from two ``rocprofv3 --pmc``
-    passes (the two counters do not fit one pass; ``--kernel-trace`` only beside them) over ``tools/kbench.py --which msda_fused_hm``
-    — the same kernel, shape and sampling locations as the in-model encoder call — corrected with the gfx950 calibration of
-    tools/micro/fetch_calib.hip (tools/pmc_parse.py: coalesced streams are counted at half, 64-byte row gathers in full).  Rank 0 at
-    N = 1 only, after the timed legs; any failure (no rocprofv3, counters unavailable) leaves ``traffic`` null and the committed
-    offline collection rides along as before."""
+def _pmc_passes(which, extra_args=()):
+    """Two ``rocprofv3 --pmc`` passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass; ``--kernel-trace`` only beside them) over
+    ``tools/kbench.py --which <which>``; returns the two counter CSVs and the scratch directory (caller removes it)."""
     import glob
     import shutil
     import subprocess
     import tempfile
 
-    if a.dtype != "bf16" or a.batch != 8:
-        return None
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
+        return None, None
+    csvs, work = [], tempfile.mkdtemp(prefix="alo_pmc_", dir="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = os.path.join(work, counter)
+        cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.join(ROOT, "tools", "kbench.py"), "--which", which, "--reps", "3"] + list(extra_args)
+        subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, capture_output=True, check=True)
+        found = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if not found:
+            shutil.rmtree(work, ignore_errors=True)
+            return None, None
+        csvs.append(found[0])
+    return csvs, work
+
+
+def live_traffic(a):
+    """``roofline.traffic`` collected IN this run: FETCH_SIZE and WRITE_SIZE of the dominant kernel from two ``rocprofv3 --pmc``
+    passes over ``tools/kbench.py --which msda_fused_hm`` — the same kernel, shape and sampling locations as the in-model encoder
+    call — corrected with the gfx950 calibration of tools/micro/fetch_calib.hip (tools/pmc_parse.py: coalesced streams are counted
+    at half, 64-byte row gathers in full).  Rank 0 at N = 1 only, after the timed legs; any failure (no rocprofv3, counters
+    unavailable) leaves ``traffic`` null and the committed offline collection rides along as before."""
+    import shutil
+
+    if a.dtype != "bf16" or a.batch != 8:
         return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_parse
@@ -427,17 +604,11 @@ def live_traffic(a):
     wps = max(1, min(-(-cus // (N * M)), (Lq + 15) // 16 // 12)) if N * M < cus else 1
     # what the kernel reads as coalesced streams: bf16 offsets + logits, fp32 reference points, the coarse rows copied into LDS
     stream_bytes = 2.0 * N * Lq * M * 16 * 3 + 4.0 * N * Lq * 4 * 2 + 64.0 * (1050 + 273) * N * M * wps
-    csvs, work = [], tempfile.mkdtemp(prefix="alo_pmc_", dir="/tmp")
+    work = None
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(work, counter)
-            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "tools", "kbench.py"), "--which", "msda_fused_hm", "--reps", "3", "--N", str(N)]
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240, capture_output=True, check=True)
-            found = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if not found:
-                return None
-            csvs.append(found[0])
+        csvs, work = _pmc_passes("msda_fused_hm", ["--N", str(N)])
+        if csvs is None:
+            return None
         return pmc_parse.traffic(csvs, "msda_fwd_bf16_resident_kernel", 324278016.0, stream_bytes,
                                  "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/kbench.py --which msda_fused_hm, "
                                  "launched by bench.py after its timed legs")
@@ -445,7 +616,72 @@ def live_traffic(a):
         print(f"[bench] live PMC collection failed ({type(exc).__name__}: {exc}); roofline.traffic stays null", file=sys.stderr, flush=True)
         return None
     finally:
-        shutil.rmtree(work, ignore_errors=True)
+        if work:
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def live_traffic_bwd(N):
+    """The same for the training leg's kernel: ``tools/kbench.py --which msda_bwd`` (fp32, N = 4, Lq = S = 22223, the ring the
+    random-init model samples).  Coalesced streams of the tiled backward (counted at half by FETCH_SIZE): locations, attention
+    weights and the grad_out rows read as 128-byte rows for the MFMA B operand; the value rows and the second reading of grad_out
+    arrive as 64-byte pieces (counted in full).  WRITE_SIZE includes the write-through of every atomic row; the memset of grad_value
+    (a runtime fill kernel, 91 MB of writes at N = 4) is added as its algorithmic size."""
+    import shutil
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_parse
+
+    Lq, M = 22223, 8
+    alg = 4.0 * (2 * N * Lq * M * 32 + N * Lq * M * 32) + 4.0 * (N * Lq * M * 16 * 3 * 2)
+    stream_bytes = 4.0 * N * Lq * M * 16 * 3 + 4.0 * N * Lq * M * 32
+    work = None
+    try:
+        csvs, work = _pmc_passes("msda_bwd")
+        if csvs is None:
+            return None
+        out = pmc_parse.traffic(csvs, "msda_bwd_tiled_kernel", alg, stream_bytes,
+                                "two rocprofv3 --pmc passes over tools/kbench.py --which msda_bwd, launched by bench.py after its timed legs")
+        memset = 4.0 * N * Lq * M * 32
+        out["memset_bytes_added"] = memset
+        for k in ("bytes", "bytes_upper", "bytes_raw", "write_size"):
+            out[k] = round(out[k] + memset)
+        out["ratio_to_algorithmic"] = round(out["bytes"] / alg, 3)
+        out["ratio_to_algorithmic_upper"] = round(out["bytes_upper"] / alg, 3)
+        alg_writes = 4.0 * N * Lq * M * 32 + 4.0 * N * Lq * M * 16 * 3   # grad_value once + grad_loc + grad_attn
+        out["write_ratio_to_algorithmic_writes"] = round(out["write_size"] / alg_writes, 3)
+        return out
+    except (Exception, SystemExit) as exc:   # noqa: BLE001
+        print(f"[bench] live PMC collection (backward) failed ({type(exc).__name__}: {exc}); train.roofline.traffic stays null", file=sys.stderr, flush=True)
+        return None
+    finally:
+        if work:
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def live_traffic_corr(B):
+    """The same for alo_corr_build (B pairs at 720p): every kernel of the entry point summed per call (magnitude, split, pooled
+    copy, the two GEMM launches).  All of their reads are coalesced 16-byte-per-lane streams: fetch = 2 x FETCH_SIZE."""
+    import shutil
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_parse
+
+    HW, C = 90 * 160, 256
+    alg = 4.0 * B * (2 * C * HW + HW * (14400 + 3600 + 880 + 220))
+    work = None
+    try:
+        csvs, work = _pmc_passes("corr_build", ["--B", str(B)])
+        if csvs is None:
+            return None
+        return pmc_parse.traffic_sum(csvs, ["corr_gemm3_kernel<true>", "corr_gemm3_kernel<false>", "corr_split_kernel", "corr_absmax_kernel",
+                                            "pool2_kernel"], alg, None,
+                                     "two rocprofv3 --pmc passes over tools/kbench.py --which corr_build, launched by bench.py after its timed legs")
+    except (Exception, SystemExit) as exc:   # noqa: BLE001
+        print(f"[bench] live PMC collection (corr build) failed ({type(exc).__name__}: {exc}); raft.roofline.traffic stays null", file=sys.stderr, flush=True)
+        return None
+    finally:
+        if work:
+            shutil.rmtree(work, ignore_errors=True)
 
 
 def kernel_report(summary):
@@ -472,12 +708,13 @@ def kernel_report(summary):
     return rep
 
 
-def detection_leg(a, rank, world, device, dtype, steps, warmup, eager_steps, full_table):
+def detection_leg(a, rank, world, device, dtype, steps, warmup, eager_steps, full_table, trained_like=False):
     """DeformableDETR-R50 inference on one resident batch: ``steps`` timed steps (HIP-graph replay unless --no-graph), then
     ``eager_steps`` timed steps with eager launches whose MSDA-forward launches carry HIP-event pairs (the in-step roofline
     figure), then — ``full_table`` — two un-timed eager steps with an event pair around every launch of this library."""
-    model = build_detector(device, dtype)
+    model = build_detector(device, dtype, trained_like)
     frames = detection_inputs(a.batch, rank, device, dtype)
+    spread = offset_spread_px(model, frames) if trained_like else None
 
     def eager_step():
         with torch.no_grad():
@@ -512,6 +749,7 @@ def detection_leg(a, rank, world, device, dtype, steps, warmup, eager_steps, ful
     # then come from the eager steps timed right after them.
     with alo_hip.LaunchTimer(only="msda_fwd") as timer:
         seconds = timed_steps(det_step, steps, warmup, world, device)
+        rank_seconds = list(LAST_RANK_SECONDS)
         eager_seconds = None
         if graph and eager_steps > 0:
             eager_seconds = timed_steps(eager_step, eager_steps, 1, world, device)
@@ -535,28 +773,42 @@ def detection_leg(a, rank, world, device, dtype, steps, warmup, eager_steps, ful
     del model, frames
     torch.cuda.empty_cache()
     return {"seconds": seconds, "eager_seconds": eager_seconds, "kernels": kernels, "enc_b2b_ms": enc_b2b_ms,
-            "launch": "HIP graph replay" if graph else "eager", "graph": graph}
+            "launch": "HIP graph replay" if graph else "eager", "graph": graph, "offset_spread_px": spread, "rank_seconds": rank_seconds}
 
 
 def selftest(a):
     """Same launch / shard / fence / max-over-ranks code path as the real run, on CPU tensors over gloo."""
-    rank, world, _ = init_dist(a.gpus, on_gpu=False)
+    rank, world, local = init_dist(a.gpus, on_gpu=False)
     device = torch.device("cpu")
+    cpus = bind_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)), on_gpu=False)
     gen = torch.Generator().manual_seed(1234 + rank)  # every rank owns its own shard of the (synthetic) frames
     shard = torch.rand(a.batch, 64, generator=gen)
+    own = {"n": 0, "t": 0.0}
 
     def step():
+        t0 = time.perf_counter()
         time.sleep(0.01 * (rank + 1))  # uneven ranks: the slowest one must set the reported time
-        return shard.sum()
+        out = shard.sum()
+        own["n"] += 1
+        own["t"] += time.perf_counter() - t0
+        return out
 
     seconds = timed_steps(step, a.steps, a.warmup, world, device)
     checksum = torch.tensor([float(shard.sum())], dtype=torch.float64)
+    report = {"rank": rank, "cpus": cpus, "own_ms_per_step": round(own["t"] / max(own["n"], 1) * 1e3, 3)}
+    reports = [report]
     if world > 1:
         dist.all_reduce(checksum)
+        reports = [None] * world
+        dist.all_gather_object(reports, report)
     if rank == 0:
+        own_ms = [r["own_ms_per_step"] for r in reports]
         print(json.dumps({"metric": "selftest", "value": a.batch * world * a.steps / seconds, "unit": "frames/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": seconds / a.steps * 1e3,
-                          "scaling": "weak", "checksum": float(checksum.item())}), flush=True)
+                          "scaling": "weak", "checksum": float(checksum.item()),
+                          # what the first real N > 1 run needs to explain its own efficiency: who ran where, and how far apart the
+                          # ranks' own step times are (the reported time is the slowest rank's)
+                          "per_rank": reports, "rank_spread_ms": round(max(own_ms) - min(own_ms), 3)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -568,8 +820,12 @@ def main():
         return selftest(a)
     rank, world, local = init_dist(a.gpus, share_gpu=a.share_gpu, force=a.force_dist)
     device = torch.device("cuda", local)
-    if world > 1:   # N processes share the host: keep each one's CPU pools (Hungarian matching, launch glue) to its share of the cores
+    rank_cpus = None
+    if world > 1:   # N processes share the host: each one is pinned to its own cores, next to its GPU where the topology says which
         torch.set_num_threads(max(1, min(32, (os.cpu_count() or 32) // world)))
+        if not a.no_affinity:
+            rank_cpus = bind_rank_to_cpus(int(os.environ.get("LOCAL_RANK", str(local))), int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                                          on_gpu=not a.share_gpu)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
     # ---- detection: the headline workload ---------------------------------------------------------------------------
@@ -594,6 +850,29 @@ def main():
         except Exception as exc:
             print(f"[bench] fp32 leg failed ({type(exc).__name__}: {exc}); omitted from the line", file=sys.stderr, flush=True)
             fp32 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        torch.cuda.empty_cache()
+
+    # ---- the same workload with trained-like sampling offsets --------------------------------------------------------------
+    trained = None
+    if a.trained_steps > 0:
+        try:
+            dt = detection_leg(a, rank, world, device, dtype, a.trained_steps, 3, 0, full_table=False, trained_like=True)
+            et = next((v for k, v in dt["kernels"].items() if k.startswith("msda_fwd") and k.endswith("Lq=22223")), None)
+            trained = {"metric": "frames/sec (whole node) DeformableDETR-R50 inference, trained-like sampling offsets", "unit": "frames/s",
+                       "dtype": a.dtype if a.dtype != "fp32" else "f32",
+                       "value": round(a.batch * world * a.trained_steps / dt["seconds"], 3), "steps": a.trained_steps, "warmup": 3,
+                       "ms_per_step": round(dt["seconds"] / a.trained_steps * 1e3, 3), "launch": dt["launch"],
+                       "offset_std_px_levels_0_3_and_ring_max": dt["offset_spread_px"],
+                       "note": "same model, frames and launch as the headline; every MSDeformAttn's sampling_offsets re-drawn by "
+                               "make_trained_like (ring kept as the mean, query-dependent + heavy-tailed spread of 1.5-3 px per level); "
+                               "the headline's random-init model samples the bare ring"}
+            if et is not None:
+                trained["roofline"] = {"bound": "hbm", "achieved": et["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": et["hbm_frac"],
+                                       "traffic": None, "alg_bytes_per_launch": et["alg_bytes"], "ms_per_launch": et["ms_avg"],
+                                       "launches": et["launches"]}
+        except Exception as exc:
+            print(f"[bench] trained-like leg failed ({type(exc).__name__}: {exc}); omitted from the line", file=sys.stderr, flush=True)
+            trained = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         torch.cuda.empty_cache()
 
     # ---- flow -------------------------------------------------------------------------------------------------------
@@ -651,7 +930,11 @@ def main():
             kernels.update(rk_all)
             raft = {"metric": "frame pairs/sec (whole node) RAFT 32-iter inference", "value": round(a.raft_batch * world * a.raft_steps / raft_seconds, 3),
                     "unit": "pairs/s", "steps": a.raft_steps, "warmup": a.raft_warmup, "ms_per_step": round(raft_seconds / a.raft_steps * 1e3, 2),
-                    "dtype": "f32", "config": {"workload": f"alonet.raft.RAFT 32 iters, batch {a.raft_batch} synthetic 1280x720 pairs per GPU",
+                    "dtype": "f32",
+                    "dtype_note": "fp32 everywhere except the all-pairs contraction, which accumulates in fp32 over 22-bit operands "
+                                  "(two fp16 terms per feature after a power-of-two scaling, hi*hi + hi*lo + lo*hi; the dropped lo*lo is "
+                                  "<= 2^-22 relative): accurate to 3e-6 of an item's largest entry, not per element like torch.matmul",
+                    "config": {"workload": f"alonet.raft.RAFT 32 iters, batch {a.raft_batch} synthetic 1280x720 pairs per GPU",
                                                "launch": "eager" if raft_step is raft_eager else "HIP graph replay",
                                                "per_gpu_batch": a.raft_batch}}
             cb = rk_all.get("corr_build")  # median of re-launches on the last call's buffers (above)
@@ -736,22 +1019,30 @@ def main():
             torch.manual_seed(0)
             pmodel = DeformableDetrR50Panoptic(num_classes=250, device=device).eval().to(dtype).to(memory_format=torch.channels_last)
             pframes = detection_inputs(a.batch, rank, device, dtype)
-            keep = [torch.zeros(300, dtype=torch.bool, device=device) for _ in range(a.batch)]
-            for k in keep:  # random-init scores never pass the detector's threshold: keep a fixed, realistic query count
-                k[torch.arange(a.panoptic_queries, device=device) * (300 // a.panoptic_queries)] = True
+            counts = [int(x) for x in str(a.panoptic_queries).split(",") if x.strip()]
+            sweep = {}
+            for nq in counts:
+                keep = [torch.zeros(300, dtype=torch.bool, device=device) for _ in range(a.batch)]
+                for k in keep:  # random-init scores never pass the detector's threshold: keep a fixed query count, swept over
+                    k[torch.arange(nq, device=device) * (300 // nq)] = True   # a realistic range (the cost is linear in it)
 
-            def pan_step():
-                with torch.no_grad():
-                    out = pmodel(pframes, filters=keep)
-                    return pmodel.inference(out, filters=keep)
+                def pan_step():
+                    with torch.no_grad():
+                        out = pmodel(pframes, filters=keep)
+                        return pmodel.inference(out, filters=keep)
 
-            psec = timed_steps(pan_step, a.panoptic_steps, 1, world, device)
+                steps_q = a.panoptic_steps if nq == counts[0] else max(5, a.panoptic_steps // 3)
+                psec = timed_steps(pan_step, steps_q, 1, world, device)
+                sweep[str(nq)] = {"value": round(a.batch * world * steps_q / psec, 3), "ms_per_step": round(psec / steps_q * 1e3, 2), "steps": steps_q}
+            head = sweep[str(counts[0])]
             panoptic = {"metric": "frames/sec (whole node) PanopticHead on DeformableDETR-R50", "unit": "frames/s",
-                        "value": round(a.batch * world * a.panoptic_steps / psec, 3), "steps": a.panoptic_steps, "warmup": 1,
-                        "ms_per_step": round(psec / a.panoptic_steps * 1e3, 2), "dtype": a.dtype if a.dtype != "fp32" else "f32",
+                        "value": head["value"], "steps": head["steps"], "warmup": 1,
+                        "ms_per_step": head["ms_per_step"], "dtype": a.dtype if a.dtype != "fp32" else "f32",
+                        "kept_queries_sweep": sweep,
                         "config": {"workload": f"PanopticHead (MHAttentionMap + FPNstyleCNN) over DeformableDETR-R50, forward + "
                                                f"inference() to aloscene.Mask, batch {a.batch} synthetic 1333x800 frames per GPU, "
-                                               f"{a.panoptic_queries} kept queries per frame",
+                                               f"{counts[0]} kept queries per frame (sweep over {counts} in kept_queries_sweep: the "
+                                               f"reference keeps whatever passes the threshold)",
                                    "per_gpu_batch": a.batch}}
             del pmodel, pframes
             torch.cuda.empty_cache()
@@ -812,14 +1103,46 @@ def main():
             "frac_back_to_back": round(enc["alg_bytes"] / (enc_b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if enc_b2b_ms else None},
         "kernels": kernels,
     }
+    if world > 1:   # who ran where and how far apart the ranks' own step times are: the reported time is the slowest rank's
+        per = [round(x / a.steps * 1e3, 3) for x in det["rank_seconds"]]
+        line["per_rank"] = {"ms_per_step": per, "spread_ms": round(max(per) - min(per), 3), "rank0_cpus": rank_cpus,
+                            "affinity": "one disjoint set of whole cores per rank, on its GPU's NUMA node where sysfs tells (affinity_plan)"
+                                        if rank_cpus else "left to the launcher"}
     if det["eager_seconds"]:
         line["eager"] = {"value": round(a.batch * world * a.eager_steps / det["eager_seconds"], 3), "unit": "frames/s", "steps": a.eager_steps,
                          "warmup": 1, "ms_per_step": round(det["eager_seconds"] / a.eager_steps * 1e3, 3),
                          "launch": "eager (every launch from the host; the dominant kernel's launches carry HIP-event pairs)"}
     if fp32 is not None:
         line["fp32"] = fp32
+    if trained is not None:
+        line["trained_like"] = trained
     if micro is not None:
         line["micro"] = micro
+        # the roofline entries above are measured INSIDE the model step, i.e. on the sampling pattern a random-init model produces (the
+        # 1-4 px ring, the friendliest one); the same kernels on SURVEY 8(d)'s prescribed micro-benchmark distribution, on the
+        # trained-like one and on the worst case ride along inside the roofline objects (stand-alone launches, tools/kbench.py)
+        if "error" not in micro:
+            def other(prefix, suffix):
+                got = {}
+                for kind in ("ring", "survey", "trained", "uniform"):
+                    e = micro.get(f"{prefix}[{kind}] {suffix}")
+                    if e is not None:
+                        got[kind] = {"frac": e["hbm_frac"], "ms_per_launch": e["ms"]}
+                return got
+            if line["roofline"] is not None and a.dtype == "bf16" and a.batch == 8:
+                by = other("msda_fwd_fused_hm", "bf16 N=8")
+                line["roofline"]["distribution"] = "ring (what the random-init model of this run samples)"
+                line["roofline"]["by_distribution_standalone"] = by
+                for kind in ("survey", "trained", "uniform"):
+                    if kind in by:
+                        line["roofline"]["frac_" + kind] = by[kind]["frac"]
+            if train is not None and train.get("roofline") and a.train_batch == 4:
+                by = other("msda_bwd", "f32 N=4")
+                train["roofline"]["distribution"] = "ring (what the random-init model of this run samples)"
+                train["roofline"]["by_distribution_standalone"] = by
+                for kind in ("survey", "trained", "uniform"):
+                    if kind in by:
+                        train["roofline"]["frac_" + kind] = by[kind]["frac"]
     if raft is not None:
         line["raft"] = raft
     if train is not None:
@@ -831,6 +1154,17 @@ def main():
         if live is not None:
             line["roofline"]["traffic"] = live["bytes"]          # per launch, like `achieved`; calibrated lower bound
             line["roofline"]["traffic_detail"] = live
+    if world == 1 and not a.no_pmc:
+        if train is not None and train.get("roofline") and a.train_batch == 4:
+            live = live_traffic_bwd(a.train_batch)
+            if live is not None:
+                train["roofline"]["traffic"] = live["bytes"]
+                train["roofline"]["traffic_detail"] = live
+        if raft is not None and raft.get("roofline"):
+            live = live_traffic_corr(a.raft_batch)
+            if live is not None:
+                raft["roofline"]["traffic"] = live["bytes"]
+                raft["roofline"]["traffic_detail"] = live
     if world == 1 and not a.no_cpu_baseline:
         line["plumbing"] = plumbing_config0()
         line["cpu_baseline"] = cpu_baseline(a.cpu_frames)

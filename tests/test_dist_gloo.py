@@ -98,3 +98,43 @@ def test_scale_script_builds_the_curve_from_per_n_lines(tmp_path):
     assert rec["points"][0]["efficiency"] == 1.0
     # rank r sleeps 10 (r + 1) ms per step: two ranks deliver 2 x 8 frames in 20 ms against 8 in 10 ms -> efficiency ~0.5
     assert 0.35 < rec["points"][1]["efficiency"] < 0.65
+
+
+def test_ranks_are_pinned_to_disjoint_cores_and_report_their_own_step_times():
+    """Round-4 verdict item 7: with N ranks on one host every rank binds itself to its own whole cores (bench.affinity_plan) and the
+    line says who ran where and how far apart the ranks' own step times are."""
+    r2 = run_selftest(2, 29617)
+    per = r2["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1]
+    masks = [set(p["cpus"]) for p in per]
+    assert all(masks) and not (masks[0] & masks[1]), masks
+    assert masks[0] | masks[1] <= set(os.sched_getaffinity(0))
+    # rank 1 sleeps 10 ms longer per step than rank 0: the spread the line reports
+    assert 8.0 <= r2["rank_spread_ms"] <= 14.0 and per[1]["own_ms_per_step"] > per[0]["own_ms_per_step"]
+
+
+def test_affinity_plan_keeps_whole_cores_together_and_follows_the_gpus_numa_nodes():
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    bench = importlib.import_module("bench")
+    # 2 sockets x 8 cores x 2 threads: cpu c and c + 16 share a core; node 0 = cores 0-7, node 1 = cores 8-15
+    core_of = lambda c: c % 16  # noqa: E731
+    node_cpus = {0: list(range(0, 8)) + list(range(16, 24)), 1: list(range(8, 16)) + list(range(24, 32))}
+    avail = list(range(32))
+    # GPUs 0-3 on node 0, 4-7 on node 1
+    plan = bench.affinity_plan(avail, 8, [0, 0, 0, 0, 1, 1, 1, 1], node_cpus, core_of)
+    assert len(plan) == 8 and all(len(p) == 4 for p in plan)
+    flat = [c for p in plan for c in p]
+    assert len(flat) == len(set(flat)) == 32                                  # disjoint, nothing left over
+    for r, p in enumerate(plan):
+        assert {core_of(c) for c in p} == {c for c in p if c < 16}              # both threads of every core it owns
+        assert set(p) <= set(node_cpus[0 if r < 4 else 1])                      # on its GPU's node
+    # unknown topology: even split in CPU order, still whole cores, still disjoint
+    even = bench.affinity_plan(avail, 4, None, None, core_of)
+    assert [sorted({core_of(c) for c in p}) for p in even] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    # a node without enough cores for its ranks: everybody falls back to the even split (never an empty or shared set)
+    starved = bench.affinity_plan(list(range(0, 4)) + list(range(8, 16)), 4, [0, 0, 0, 1], {0: [0, 1], 1: list(range(8, 16))}, lambda c: c)
+    assert all(starved) and len({c for p in starved for c in p}) == sum(len(p) for p in starved)
+    # fewer cores than ranks: nothing disjoint to hand out, every rank keeps the whole set
+    assert bench.affinity_plan([0, 1], 4, None, None, lambda c: c) == [[0, 1]] * 4

@@ -217,3 +217,40 @@ def test_panoptic_head_over_detr_r50_cpu():
     boxes, masks = model.inference(out, filters=keep)
     assert [m.shape for m in masks] == [(3, 128, 160), (1, 128, 160)] and isinstance(masks[0], aloscene.Mask)
     assert boxes[0].shape == (3, 4) and int(masks[0].as_tensor().sum(0).max()) <= 1  # one-hot across queries
+
+
+def test_finetune_variants_rehead_like_the_reference(tmp_path):
+    """alonet/deformable_detr/deformable_detr_r50_finetune.py:10-136: base model with the checkpoint's 91 classes, then a new
+    classification head (+1 background output under softmax, bias at the 0.01 prior) — ONE module shared by the six decoder
+    layers for the plain model, six independent clones for the refinement model — and a fine-tuned checkpoint loaded on top."""
+    import math
+
+    from alonet.deformable_detr import DeformableDetrR50Finetune, DeformableDetrR50RefinementFinetune
+
+    with pytest.raises(Exception, match="sigmoid"):
+        DeformableDetrR50Finetune(num_classes=2, activation_fn="tanh", base_weights=None, device=None)
+    with pytest.raises(FileNotFoundError, match="deformable-detr-r50"):   # the default base checkpoint is looked up, not downloaded
+        DeformableDetrR50Finetune(num_classes=2, device=None)
+    m = DeformableDetrR50Finetune(num_classes=2, base_weights=None, device=None, aux_loss=False)
+    assert len(m.class_embed) == 6 and all(h is m.class_embed[0] for h in m.class_embed)
+    assert m.class_embed[0].weight.shape == (2, 256) and m.background_class is None and m.activation_fn == "sigmoid"
+    assert torch.allclose(m.class_embed[0].bias, torch.full((2,), -math.log(99.0)))
+    sm = DeformableDetrR50Finetune(num_classes=2, activation_fn="softmax", base_weights=None, device=None, aux_loss=False)
+    assert sm.class_embed[0].weight.shape == (3, 256) and sm.background_class == 2
+    r = DeformableDetrR50RefinementFinetune(num_classes=5, base_weights=None, device=None, aux_loss=False)
+    assert len({id(h) for h in r.class_embed}) == 6 and r.class_embed[3].weight.shape == (5, 256)
+    assert r.transformer.decoder.bbox_embed is r.bbox_embed   # the decoder still refines with the model's box heads
+    # a fine-tuned checkpoint (re-headed layout) loads on top of the base model
+    with torch.no_grad():
+        m.class_embed[0].weight.fill_(0.25)
+    path = str(tmp_path / "finetuned.pth")
+    torch.save({"model": m.state_dict()}, path)
+    again = DeformableDetrR50Finetune(num_classes=2, base_weights=None, weights=path, device=None, aux_loss=False)
+    assert torch.equal(again.class_embed[5].weight, torch.full((2, 256), 0.25))
+    with pytest.raises(ValueError, match="Unknown weights"):
+        DeformableDetrR50Finetune(num_classes=2, base_weights=None, weights="nonsense", device=None)
+    # and the re-headed model runs: logits carry the new class count
+    frames = aloscene.Frame.batch_list([aloscene.Frame(torch.rand(3, 64, 96) * 255, normalization="255").norm_resnet()])
+    with torch.no_grad():
+        out = m.eval()(frames, is_tracing=None)   # the reference's CPU-runnable branch (pure-torch op)
+    assert out["pred_logits"].shape == (1, 300, 2)

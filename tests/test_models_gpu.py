@@ -351,8 +351,8 @@ def test_graphed_forward_replays_raft(golden):
 # ---- stated bf16 end-to-end tolerances -------------------------------------------------------------------
 # measured on MI355X (round 2): G5 0.077 / G12 0.042 on hs; full model 0.039 on logits, 0.004 on boxes
 BF16_TRANSFORMER_TOL = 0.1    # max-abs on hs / memory (LayerNorm-ed, O(1) values) through the bf16 layers vs the reference's fp64 outputs
-BF16_MODEL_LOGIT_TOL = 0.1    # max-abs on the raw class logits of the full R50 model, bf16 vs fp32 (same weights, same frames)
-BF16_MODEL_BOX_TOL = 0.02     # max-abs on the (sigmoid) boxes in [0, 1]
+BF16_MODEL_LOGIT_TOL = 0.08   # max-abs on the raw class logits of the full R50 model, bf16 vs fp32 (same weights, same frames): 2 x measured
+BF16_MODEL_BOX_TOL = 0.01     # max-abs on the (sigmoid) boxes in [0, 1]: 2.5 x measured
 
 
 @pytest.mark.parametrize("fixture", ["g5_deformable_transformer.npz", "g12_deformable_transformer_d256.npz"])
@@ -656,13 +656,13 @@ def test_g14_deformable_detr_on_hip_matches_the_reference_model(golden, tag, dty
         M.check_inference(model, out, g, tag, tol)
 
 
-@pytest.mark.parametrize("dtype,tol_logits,tol_boxes,channels_last", [(torch.float32, 1e-3, 1e-3, False), (torch.bfloat16, 0.1, 0.02, False),
-                                                                      (torch.bfloat16, 0.1, 0.02, True)])
+@pytest.mark.parametrize("dtype,tol_logits,tol_boxes,channels_last", [(torch.float32, 1e-3, 1e-3, False), (torch.bfloat16, 0.08, 0.01, False),
+                                                                      (torch.bfloat16, 0.08, 0.01, True)])
 def test_g14b_deformable_detr_d256_on_hip_matches_the_reference_model(golden, dtype, tol_logits, tol_boxes, channels_last):
     """DETR-family width (d_model 256, 8 heads x 32 channels, 4 levels x 4 points): in bf16 this is the configuration of the
     headline number — lazily fused positional encodings, projections normalised straight into the flattened source, the mask
     pyramid kernel, merged projections, head-major fused MSDA, add_layernorm, ffn256 — against the REFERENCE model's outputs.
-    bf16 bars as stated in DESIGN.md section 3 (logits 0.1, boxes 0.02); fp32 at the north-star 1e-3."""
+    bf16 bars as stated in DESIGN.md section 3 (logits 0.08, boxes 0.01: twice what was measured); fp32 at the north-star 1e-3."""
     M = _golden_builders()
     g = golden("g14b_deformable_detr_d256.npz")
     model = M.build_g14b().to(DEV, dtype)

@@ -465,12 +465,13 @@ def test_bench_kernel_direct_vs_oracle_full_size_batch8():
     assert np.all(err <= np.abs(exact) * 2.0 ** -8 + 2e-5)
 
 
-@pytest.mark.parametrize("kind", ["survey", "uniform"])
+@pytest.mark.parametrize("kind", ["survey", "trained", "uniform"])
 def test_bench_kernel_full_size_on_the_wider_sampling_distributions(kind):
     """The kernel bench.py times, at N = 8, S = Lq = 22223, AWAY from the init-time ring the benchmark's random-init model samples:
     SURVEY 8(d)'s micro-benchmark locations (own pixel centre + U(-0.05, 0.05) of the map: +-8 x +-5 px on level 0) and locations
     uniform over the whole map (no locality between neighbouring queries: where the resident kernel's ~190-consecutive-queries
-    locality is gone).  Resident == plain head-major kernel bit for bit, and a strided query subset + the tail within half a bf16
+    locality is gone), and the trained-like offsets of tools/kbench.py (ring + heavy-tailed 1.5-3 px spread per level: what the
+    `trained_like` leg of bench.py samples).  Resident == plain head-major kernel bit for bit, and a strided query subset + the tail within half a bf16
     ulp of the float64 oracle (tools/kbench.py generates the same inputs for the `micro` entries of the bench line)."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -514,15 +515,22 @@ def _encoder_like_loc(N, shapes_l, rng, spread_px=4.0):
     return (ref[None, :, None, None, None, :] + off).astype(np.float32)
 
 
-@pytest.mark.parametrize("kind", ["encoder", "uniform"])
-def test_full_size_backward_vs_oracle(kind):
-    """alo_msda_backward at N = 1, S = Lq = 22223 (fp32) against the C oracle: encoder-like locations (the tiled path) and
-    uniformly random ones (no locality at all: the per-corner path)."""
+@pytest.mark.parametrize("kind,N", [("encoder", 1), ("uniform", 1), ("encoder", 4), ("trained", 4)])
+def test_full_size_backward_vs_oracle(kind, N):
+    """alo_msda_backward at S = Lq = 22223 (fp32) against the C oracle: encoder-like locations (the tiled path) and uniformly
+    random ones (no locality at all: the per-corner path) at N = 1; at N = 4 — BASELINE configs[3]'s per-GPU batch, the launch
+    bench.py's training leg times — encoder-like locations and the trained-like offsets of tools/kbench.py."""
     rng = np.random.default_rng(21)
-    c = _full_size_case(1, 22223, 13)
+    c = _full_size_case(N, 22223, 13)
     if kind == "encoder":
-        c["loc"] = _encoder_like_loc(1, DETR_SHAPES, rng)
-    c["grad_out"] = rng.standard_normal((1, 22223, 256)).astype(np.float32)
+        c["loc"] = _encoder_like_loc(N, DETR_SHAPES, rng)
+    elif kind == "trained":
+        import sys, os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import kbench
+
+        c["loc"] = kbench.msda_inputs(N, 22223, "trained", torch.float32, seed=3)[3].cpu().numpy()
+    c["grad_out"] = rng.standard_normal((N, 22223, 256)).astype(np.float32)
     gv, gl, ga = (x.cpu().numpy() for x in hip_backward(c, torch.float32))
     rgv, rgl, rga = O.msda_backward(c["value"].astype(np.float64), c["shapes"], c["level_start"], c["loc"].astype(np.float64),
                                     c["attn"].astype(np.float64), c["grad_out"].astype(np.float64))

@@ -78,6 +78,43 @@ def encoder_like_locations(N, M=8, L=4, P=4, jitter=0.5, seed=0, device=DEV):
     return loc
 
 
+# "trained-like" sampling offsets — a stand-in for a trained Deformable-DETR, whose checkpoints cannot be fetched offline.  What the
+# module guarantees by construction (ops/modules/ms_deform_attn.py:70-88,119-133 of the reference): offsets are a linear function
+# of the query plus a bias that starts as the head-direction ring (head m looks along angle 2 pi m / 8, point p sits (p + 1) px
+# out), they are measured in PIXELS OF THE LEVEL THEY SAMPLE (divided by (W_l, H_l)), so the same spread in pixels is 2^l times
+# wider in the image on level l.  What training does to them (Deformable-DETR paper, fig. 5 / the released checkpoints' bias and
+# weight norms): the ring survives as the mean direction, a query-dependent term of a few pixels is added, and a minority of
+# points reaches far across the object.  Modelled as
+#     offset_px[l, m, p] = ring[m] * (p + 1)  +  sigma_l * t3 / sqrt(3),      sigma = (1.5, 2.0, 2.5, 3.0) px on levels 0..3,
+# t3 a Student-t with 3 degrees of freedom per coordinate (unit variance after the division; 0.6 % of the draws beyond 4 sigma
+# against 0.006 % for a Gaussian): in image pixels the per-level spread grows 12 -> 192 px from level 0 to level 3, and one
+# coordinate in 160 lands more than 4 sigma out.  Between "ring" (what a random-init model produces) and "survey" / "uniform".
+TRAINED_SIGMA_PX = (1.5, 2.0, 2.5, 3.0)
+
+
+def trained_like_offsets_px(N, S, gen, device=DEV, M=8, L=4, P=4):
+    """(N, S, M, L, P, 2) float32 offsets in level pixels, see the comment above."""
+    ang = torch.arange(M, device=device, dtype=torch.float32) * (2 * torch.pi / M)
+    ring = torch.stack([ang.cos(), ang.sin()], -1)
+    ring = ring / ring.abs().max(-1, keepdim=True)[0]
+    steps = torch.arange(1, P + 1, device=device, dtype=torch.float32)
+    mean = (ring[:, None, None, :] * steps[None, None, :, None]).expand(M, L, P, 2)
+    z = torch.randn(N, S, M, L, P, 2, generator=gen, device=device)
+    chi = torch.randn(N, S, M, L, P, 2, 3, generator=gen, device=device).square().sum(-1)
+    t3 = z / (chi / 3.0).sqrt() / 3.0 ** 0.5
+    sigma = torch.tensor(TRAINED_SIGMA_PX, device=device, dtype=torch.float32)[None, None, None, :, None, None]
+    return mean[None, None] + sigma * t3
+
+
+def pyramid_refs(device=DEV):
+    """(S, 2) normalised (x, y) centre of every pixel of every level, pyramid order."""
+    refs = []
+    for (h, w) in DETR_SHAPES:
+        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+        refs.append(torch.stack([(xs.reshape(-1) + 0.5) / w, (ys.reshape(-1) + 0.5) / h], -1))
+    return torch.cat(refs, 0)
+
+
 def msda_inputs(N, Lq, kind, dtype, seed=0):
     shapes, start, S = detr_geometry()
     gen = torch.Generator(device=DEV).manual_seed(seed)
@@ -91,6 +128,10 @@ def msda_inputs(N, Lq, kind, dtype, seed=0):
                          for (h, w) in DETR_SHAPES
                          for ys, xs in [torch.meshgrid(torch.arange(h, device=DEV), torch.arange(w, device=DEV), indexing="ij")]], 0)
         loc = ref[None, :, None, None, None, :] + (torch.rand(N, S, 8, 4, 4, 2, generator=gen, device=DEV) - 0.5) * 0.1
+    elif kind == "trained":   # see TRAINED_SIGMA_PX above
+        assert Lq == S
+        wh = torch.tensor([[w, h] for h, w in DETR_SHAPES], device=DEV, dtype=torch.float32)[None, None, None, :, None, :]
+        loc = pyramid_refs()[None, :, None, None, None, :] + trained_like_offsets_px(N, S, gen) / wh
     else:
         loc = torch.rand(N, Lq, 8, 4, 4, 2, generator=gen, device=DEV)
     attn = torch.softmax(torch.randn(N, Lq, 8, 16, generator=gen, device=DEV), -1).view(N, Lq, 8, 4, 4)
@@ -115,7 +156,7 @@ def bench_msda_fwd(N, Lq, kind, dtype, reps):
 
 def fused_inputs(N, dtype, seed=0, kind="ring"):
     """Raw module tensors for the fused-prologue entry point, encoder-like (reference points = every pixel's own centre on every
-    level).  ``kind`` = where the samples fall: "ring" = the module's initial offsets (head direction x 1..4 px, + sub-pixel
+    level).  ``kind`` = where the samples fall: "trained" = TRAINED_SIGMA_PX above; "ring" = the module's initial offsets (head direction x 1..4 px, + sub-pixel
     jitter: what bench.py's random-init model produces); "survey" = SURVEY 8(d)'s micro-benchmark inputs, loc = own centre +
     U(-0.05, 0.05) of the map (+-8 x +-5 px on level 0); "uniform" = loc ~ U(0, 1) over the whole map (worst case)."""
     shapes, start, S = detr_geometry()
@@ -133,6 +174,8 @@ def fused_inputs(N, dtype, seed=0, kind="ring"):
     off = (ring[:, None, None, :] * steps[None, None, :, None]).expand(8, 4, 4, 2)
     if kind == "ring":
         offsets = off[None, None].expand(N, S, 8, 4, 4, 2) + (torch.rand(N, S, 8, 4, 4, 2, generator=gen, device=DEV) - 0.5)
+    elif kind == "trained":
+        offsets = trained_like_offsets_px(N, S, gen)
     else:
         wh = torch.tensor([[w, h] for h, w in DETR_SHAPES], device=DEV, dtype=torch.float32)[None, None, None, :, None, :]
         span = 0.1 if kind == "survey" else 1.0
@@ -282,7 +325,7 @@ def main():
             res = bench_msda_fused_hm(a.N, a.reps)
         elif w == "msda_fused_hm_plain":   # the plain head-major kernel (no LDS-resident levels), for A/B
             res = bench_msda_fused_hm(a.N, a.reps, resident=False)
-        elif w in ("msda_fused_hm_survey", "msda_fused_hm_uniform"):   # the headline kernel away from the init-time ring
+        elif w in ("msda_fused_hm_survey", "msda_fused_hm_uniform", "msda_fused_hm_trained"):   # the headline kernel away from the init-time ring
             kind = w.rsplit("_", 1)[1]
             res = bench_msda_fused_hm(a.N, a.reps, kind=kind)[1:] + bench_msda_fused_hm(a.N, a.reps, resident=False, kind=kind)[1:]
         elif w == "msda_rand":
@@ -293,6 +336,8 @@ def main():
             res = [bench_msda_bwd(4, S, "encoder", torch.float32, max(3, a.reps // 4))]
         elif w == "msda_survey":   # forward (fp32 / bf16 values) and backward on SURVEY 8(d)'s U(-0.05, 0.05) locations
             res = [bench_msda_fwd(a.N, S, "survey", dt, a.reps) for dt in dts] + [bench_msda_bwd(4, S, "survey", torch.float32, max(3, a.reps // 4))]
+        elif w == "msda_trained":   # forward + backward on the trained-like offsets (TRAINED_SIGMA_PX)
+            res = [bench_msda_fwd(a.N, S, "trained", dt, a.reps) for dt in dts] + [bench_msda_bwd(4, S, "trained", torch.float32, max(3, a.reps // 4))]
         elif w == "msda_bwd_rand":
             res = [bench_msda_bwd(4, S, "uniform", torch.float32, max(3, a.reps // 4))]
         elif w == "corr_build":

@@ -94,5 +94,38 @@ def traffic(csv_paths, kernel, alg_bytes, stream_bytes=0.0, source=""):
                     "HBM alone"}
 
 
+def traffic_sum(csv_paths, kernels, alg_bytes, stream_bytes=None, source=""):
+    """The same for an ENTRY POINT made of several kernels (alo_corr_build: magnitude, split, pooling and the two GEMM launches):
+    FETCH_SIZE / WRITE_SIZE summed over every dispatch of every kernel whose name starts with one of ``kernels``, divided by the
+    number of dispatches of ``kernels[0]`` (one per call of the entry point).  ``stream_bytes`` None = every read of these kernels
+    is a coalesced stream of 8 / 16 bytes per lane (counted at half by FETCH_SIZE on gfx950): fetch = 2 x raw, no upper bound."""
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    calls = {}
+    for path in csv_paths:
+        for k, cs in per_kernel(path).items():
+            if any(k.startswith(pref) for pref in kernels):
+                for c in tot:
+                    if c in cs:
+                        tot[c] += sum(cs[c]) * 1024.0
+                        if k.startswith(kernels[0]):
+                            calls[c] = calls.get(c, 0) + len(cs[c])
+    if set(calls) != {"FETCH_SIZE", "WRITE_SIZE"} or not all(calls.values()):
+        raise SystemExit(f"need FETCH_SIZE and WRITE_SIZE of {kernels} in the given passes, found {sorted(calls)}")
+    fetch, write = tot["FETCH_SIZE"] / calls["FETCH_SIZE"], tot["WRITE_SIZE"] / calls["WRITE_SIZE"]
+    if stream_bytes is None:
+        lower = upper = 2.0 * fetch + write
+    else:
+        gathers = max(fetch - 0.5 * stream_bytes, 0.0)
+        lower, upper = stream_bytes + gathers + write, stream_bytes + 2.0 * gathers + write
+    return {"bytes": round(lower), "bytes_upper": round(upper), "bytes_raw": round(fetch + write), "fetch_size_raw": round(fetch),
+            "write_size": round(write), "stream_bytes": stream_bytes, "alg_bytes": alg_bytes, "kernels": list(kernels),
+            "calls_averaged": calls["FETCH_SIZE"],
+            "ratio_to_algorithmic": round(lower / alg_bytes, 3) if alg_bytes else None,
+            "ratio_to_algorithmic_upper": round(upper / alg_bytes, 3) if alg_bytes else None,
+            "write_ratio_to_algorithmic_writes": None, "source": source,
+            "note": "per call of the entry point, summed over its kernels; FETCH_SIZE corrected with the gfx950 calibration of "
+                    "tools/micro/fetch_calib (coalesced streams are counted at half); Infinity-Cache hits count as fetches"}
+
+
 if __name__ == "__main__":
     main()
