@@ -335,8 +335,7 @@ def make_trained_like(model, seed=11):
     cannot be fetched offline; a random-init module has ``sampling_offsets.weight == 0`` and therefore samples the bare 1-4 px
     ring, ops/modules/ms_deform_attn.py:70-88 of the reference — the friendliest pattern a model can produce).  The bias keeps
     the ring and gains a static heavy-tailed term, sigma_l / 2 x Student-t(3) per (head, level, point); the weight becomes
-    N(0, (sigma_l / |q|)^2) so that the query-dependent term has a standard deviation of about sigma_l pixels on level l
-    (|q|^2 = 256 x 1.5: LayerNorm-ed source + sine position code).  Returns nothing; the achieved spread is measured by
+    N(0, (sigma_l / |q|)^2) so that the query-dependent term has a standard deviation of about sigma_l pixels on level l.  Returns nothing; the achieved spread is measured by
     ``offset_spread_px`` on the running model and reported next to the frame rate."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kbench
@@ -354,7 +353,9 @@ def make_trained_like(model, seed=11):
         chi = torch.randn(M, L, P, 2, 3, generator=gen).square().sum(-1)
         with torch.no_grad():
             so.bias.add_((0.5 * sg * z / (chi / 3.0).sqrt() / 3.0 ** 0.5).reshape(-1).to(so.bias))
-            w = torch.randn(M * L * P * 2, so.weight.shape[1], generator=gen) * (sg.reshape(-1, 1) / (1.5 * so.weight.shape[1]) ** 0.5)
+            # |q|^2 = 0.84 x 256 on the first encoder layer of the random-init model (measured: a weight scale of sigma / sqrt(1.5 x 256)
+            # gave 0.75 sigma): GroupNorm-ed projection + sine code, before any LayerNorm
+            w = torch.randn(M * L * P * 2, so.weight.shape[1], generator=gen) * (sg.reshape(-1, 1) / (0.84 * so.weight.shape[1]) ** 0.5)
             so.weight.copy_(w.to(so.weight))
     alo_hip.invalidate_caches(model)
 
@@ -376,7 +377,7 @@ def offset_spread_px(model, frames):
         h.remove()
     q = seen["q"][:1].float()
     so = layer.sampling_offsets
-    off = torch.nn.functional.linear(q, so.weight.float(), so.bias.float()).view(-1, layer.n_heads, layer.n_levels, layer.n_points, 2)
+    off = torch.nn.functional.linear(q, so.weight.detach().float(), so.bias.detach().float()).view(-1, layer.n_heads, layer.n_levels, layer.n_points, 2)
     ring = off.mean(0, keepdim=True)
     return [round(float(x), 2) for x in (off - ring).pow(2).mean((0, 1, 3, 4)).sqrt().cpu()] + \
            [round(float(ring.abs().amax()), 2)]
