@@ -473,6 +473,22 @@ def cpu_kernel_baselines():
     nbytes = alo_hip.msda_forward_bytes(N, S, M, D, L, S, P, 4, 4)
     out["msda_fwd/Lq=22223"] = {"ms": round(spent * 1e3, 1), "alg_bytes": nbytes, "GBps": round(nbytes / spent / 1e9, 2), "cores": cores,
                                 "kind": "port", "sample": f"one encoder-size call, N = 8, S = Lq = {S}, fp32 (oracle/torch_ref.msda_core)"}
+    # SURVEY 8(d) prescribes torch.set_num_threads(os.cpu_count()); this file uses at most 32 threads because more run these small-
+    # tensor graphs SLOWER.  Shown, not asserted: the same call on ONE image with `cores` threads and with every hardware thread.
+    if avail > cores:
+        one = (value[:1].contiguous(), loc[:1].contiguous(), attn[:1].contiguous())
+        check = {}
+        for nthreads in (cores, avail):
+            torch.set_num_threads(nthreads)
+            with torch.no_grad():
+                torch_ref.msda_core(one[0], torch.tensor(shapes), one[1], one[2])   # pool start-up
+                t0 = time.perf_counter()
+                torch_ref.msda_core(one[0], torch.tensor(shapes), one[1], one[2])
+                check[str(nthreads)] = round((time.perf_counter() - t0) * 1e3, 1)
+        torch.set_num_threads(cores)
+        out["msda_fwd/Lq=22223"]["ms_one_image_by_threads"] = check
+        out["msda_fwd/Lq=22223"]["threads_note"] = ("SURVEY 8(d) asks for os.cpu_count() threads; %d of the host's %d are used because the same "
+                                                    "call is slower with all of them (ms_one_image_by_threads)" % (cores, avail))
     del value, loc, attn
     B, C, H, W = 4, 256, 90, 160
     f1, f2 = torch.randn(B, C, H, W, generator=gen), torch.randn(B, C, H, W, generator=gen)
@@ -653,6 +669,32 @@ def live_traffic_bwd(N):
         return out
     except (Exception, SystemExit) as exc:   # noqa: BLE001
         print(f"[bench] live PMC collection (backward) failed ({type(exc).__name__}: {exc}); train.roofline.traffic stays null", file=sys.stderr, flush=True)
+        return None
+    finally:
+        if work:
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def live_traffic_fwd_f32(N):
+    """The same for the fp32 leg's kernel (`msda_fwd_kernel<float>`, fused prologue, generic): ``tools/kbench.py --which msda_fused
+    --dtype f32``.  Every read of this kernel is counted at half by FETCH_SIZE on gfx950 — its offsets / logits / reference points
+    are 16-byte-per-lane streams and its value rows are 128-byte rows (8 lanes x 16 B) — so fetch = 2 x FETCH_SIZE."""
+    import shutil
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_parse
+
+    Lq, M = 22223, 8
+    alg = 4.0 * (N * Lq * 256 * 2 + N * Lq * M * 16 * 3) + 4.0 * N * Lq * 4 * 2
+    work = None
+    try:
+        csvs, work = _pmc_passes("msda_fused", ["--N", str(N), "--dtype", "f32"])
+        if csvs is None:
+            return None
+        return pmc_parse.traffic_sum(csvs, ["msda_fwd_kernel<float"], alg, None,
+                                     "two rocprofv3 --pmc passes over tools/kbench.py --which msda_fused --dtype f32, launched by bench.py after its timed legs")
+    except (Exception, SystemExit) as exc:   # noqa: BLE001
+        print(f"[bench] live PMC collection (fp32 forward) failed ({type(exc).__name__}: {exc}); fp32.roofline.traffic stays null", file=sys.stderr, flush=True)
         return None
     finally:
         if work:
@@ -1156,6 +1198,11 @@ def main():
             line["roofline"]["traffic"] = live["bytes"]          # per launch, like `achieved`; calibrated lower bound
             line["roofline"]["traffic_detail"] = live
     if world == 1 and not a.no_pmc:
+        if fp32 is not None and fp32.get("roofline") and a.batch == 8:
+            live = live_traffic_fwd_f32(a.batch)
+            if live is not None:
+                fp32["roofline"]["traffic"] = live["bytes"]
+                fp32["roofline"]["traffic_detail"] = live
         if train is not None and train.get("roofline") and a.train_batch == 4:
             live = live_traffic_bwd(a.train_batch)
             if live is not None:
