@@ -82,7 +82,7 @@ class FPNstyleCNN(nn.Module):
     def _norm_relu(gn, y, fast=True):
         """relu(gn(y)); channels-last in and out on the GroupNorm kernel of this library when it covers the layer (2, 4 or 8k
         channels per group) — ATen's works on NCHW, a layout copy either side on a channels-last activation."""
-        if fast and alo_hip.groupnorm_nhwc_supported(y, gn):
+        if fast and isinstance(gn, nn.GroupNorm) and alo_hip.groupnorm_nhwc_supported(y, gn):   # (a fine-tuning variant may swap in BatchNorm2d)
             return alo_hip.groupnorm_nhwc(y, gn, relu=True)
         return F.relu(gn(y))
 

@@ -254,3 +254,38 @@ def test_finetune_variants_rehead_like_the_reference(tmp_path):
     with torch.no_grad():
         out = m.eval()(frames, is_tracing=None)   # the reference's CPU-runnable branch (pure-torch op)
     assert out["pred_logits"].shape == (1, 300, 2)
+
+
+def test_premade_detr_and_panoptic_variants_follow_the_reference():
+    """alonet/detr/detr_r50_finetune.py:12-57, detr_panoptic/detr_r50_panoptic{,_finetune}.py, deformable_detr_panoptic/
+    deformable_detr_r50_panoptic_finetune.py, deformable_detr/deformable_detr_r50_refinement.py: import paths, constructor
+    arguments, head replacement, background ids, the GroupNorm -> BatchNorm switch of the mask head, checkpoint loading."""
+    from alonet.deformable_detr.deformable_detr_r50_refinement import DeformableDetrR50Refinement as ByPath
+    from alonet.deformable_detr import DeformableDetrR50Refinement
+    from alonet.deformable_detr_panoptic import DeformableDetrR50PanopticFinetune
+    from alonet.detr import DetrR50Finetune
+    from alonet.detr_panoptic import DetrR50Panoptic, DetrR50PanopticFinetune
+
+    assert ByPath is DeformableDetrR50Refinement
+    with pytest.raises(FileNotFoundError, match="detr-r50"):
+        DetrR50Finetune(num_classes=2)
+    d = DetrR50Finetune(num_classes=2, base_weights=None, aux_loss=False)
+    assert d.class_embed.weight.shape == (3, 256) and d.background_class == 2 and d.num_classes == 3
+    assert DetrR50Finetune(num_classes=2, background_class=0, base_weights=None).background_class == 0
+    p = DetrR50Panoptic(num_classes=7)
+    assert p.detr.background_class == 7 and p.detr.class_embed.weight.shape == (8, 256)       # None -> the last id, not DetrR50's 91
+    assert p.detr.return_dec_outputs and not any(q.requires_grad for q in p.detr.parameters())
+    pf = DetrR50PanopticFinetune(num_classes=4, base_weights=None, use_bn_layers=True)
+    assert pf.detr.class_embed.weight.shape == (5, 256) and pf.detr.background_class == 4
+    assert all(isinstance(getattr(pf.mask_head, f"gn{i}"), torch.nn.BatchNorm2d) for i in range(1, 6))
+    assert isinstance(DetrR50PanopticFinetune(num_classes=4, base_weights=None).mask_head.gn3, torch.nn.GroupNorm)
+    dp = DeformableDetrR50PanopticFinetune(num_classes=3, base_weights=None, device=None)
+    assert len(dp.detr.class_embed) == 6 and all(h is dp.detr.class_embed[0] for h in dp.detr.class_embed)
+    assert dp.detr.class_embed[0].weight.shape == (3, 256) and dp.detr.background_class is None
+    with pytest.raises(ValueError, match="Unknown weights"):
+        DetrR50PanopticFinetune(num_classes=4, base_weights=None, weights="nonsense")
+    # the BatchNorm variant runs (the mask head's fast paths only take GroupNorm layers)
+    frames = aloscene.Frame.batch_list([aloscene.Frame(torch.rand(3, 64, 96) * 255, normalization="255").norm_resnet()])
+    with torch.no_grad():
+        out = pf.eval()(frames)
+    assert out["pred_masks"].shape[:2] == (1, 100) and torch.isfinite(out["pred_masks"]).all()
