@@ -45,42 +45,17 @@ pool2_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// largest FINITE magnitude of each batch item of a (B, per_batch) fp32 tensor, as the bit pattern of a non-negative float (they
-// order like unsigned integers).  Inf / NaN entries do not take part: the item's scale comes from its finite values, so a
-// non-finite feature spoils exactly its own row / column of the volume (as in the reference's fp32 matmul) and every other
-// entry keeps its full accuracy.  `bits` must be zero on entry.
+// magnitudes as bit patterns of non-negative floats (they order like unsigned integers).  Inf / NaN entries do not take part in a
+// scale: it comes from the finite values, so a non-finite feature spoils exactly its own row / column of the volume (as in the
+// reference's fp32 matmul) and every other entry keeps its full accuracy.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned finite_mag(unsigned bits) {
     const unsigned m = bits & 0x7fffffffu;
     return m >= 0x7f800000u ? 0u : m;
 }
-__global__ void __launch_bounds__(256)
-corr_absmax_kernel(const float* __restrict__ in, unsigned* __restrict__ bits, long per_batch) {
-    const int b = blockIdx.y;
-    const float* p = in + (long)b * per_batch;
-    unsigned m = 0u;
-    const long n4 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? per_batch / 4 : 0;   // 16-byte loads where the slab allows them
-#pragma unroll 8   // eight independent 16-byte loads in flight per thread
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
-        const u32x4 v = reinterpret_cast<const u32x4*>(p)[i];
-        m = max(max(m, finite_mag(v.x)), max(max(finite_mag(v.y), finite_mag(v.z)), finite_mag(v.w)));
-    }
-    for (long i = n4 * 4 + blockIdx.x * 256L + threadIdx.x; i < per_batch; i += (long)gridDim.x * 256L)
-        m = max(m, finite_mag(__float_as_uint(p[i])));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    // one atomic per workgroup: they all aim at the item's one word and serialize there
-    __shared__ unsigned part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(part[0], part[1]), max(part[2], part[3]));
-        if (m) atomicMax(bits + b, m);
-    }
-}
-
-// The power of two a batch item is divided by before it is split: its largest magnitude lands in [2^14, 2^15) (fp16 holds up to
-// 65504), so the low terms of all but the very smallest values stay normal fp16 numbers.  0 for an item without a finite non-zero value.
+// The power of two a pixel's feature vector is divided by before it is split: its largest magnitude lands in [2^14, 2^15) (fp16
+// holds up to 65504), so the low terms of all but the very smallest channels stay normal fp16 numbers.  0 for a vector without a
+// finite non-zero value.
 __device__ __forceinline__ int split_exponent(unsigned absmax_bits) {
     const int e = (int)(absmax_bits >> 23);
     if (e == 0 || e == 255) return 0;
@@ -89,22 +64,62 @@ __device__ __forceinline__ int split_exponent(unsigned absmax_bits) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// per-PIXEL magnitude of a (B, C, n) fp32 feature map: kexp[b][px] = the power of two pixel px's C-vector is divided by before it is
+// split (its largest finite magnitude lands in [2^14, 2^15)), and — for the map whose pixels become COLUMNS of the volume — the bit
+// pattern of the item's largest finite magnitude (atomicMax; `item_bits` zero on entry, may be null).  One thread per pixel walks the
+// channels: a wave reads 256 consecutive bytes per channel.  Scaling every pixel by its OWN power of two makes the accuracy of a
+// volume entry relative to |f1_i| |f2_j| (what fp32 matmul gives), not to the item's largest entry: a dim image region next to a
+// bright one keeps its 22 bits.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+corr_pixmax_kernel(const float* __restrict__ in, int* __restrict__ kexp, unsigned* __restrict__ item_bits, int C, long n) {
+    const int b = blockIdx.y;
+    const long px = blockIdx.x * 256L + threadIdx.x;
+    const bool live = px < n;
+    const float* p = in + (long)b * C * n + (live ? px : 0);
+    // (float compares, not integer max on the bit patterns: hipcc 7.2's instruction selection crashes on the integer form of this loop)
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;   // four independent chains: four loads in flight per thread
+    auto fin = [](float v) { v = fabsf(v); return v < INFINITY ? v : 0.f; };   // Inf / NaN do not take part
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+        f0 = fmaxf(f0, fin(p[(long)c * n]));
+        f1 = fmaxf(f1, fin(p[(long)(c + 1) * n]));
+        f2 = fmaxf(f2, fin(p[(long)(c + 2) * n]));
+        f3 = fmaxf(f3, fin(p[(long)(c + 3) * n]));
+    }
+    for (; c < C; ++c) f0 = fmaxf(f0, fin(p[(long)c * n]));
+    unsigned m = live ? __float_as_uint(fmaxf(fmaxf(f0, f1), fmaxf(f2, f3))) : 0u;
+    if (live) kexp[(long)b * n + px] = split_exponent(m);
+    if (item_bits == nullptr) return;   // uniform
+    __shared__ unsigned part[4];
+    unsigned w = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w = max(w, (unsigned)__shfl_xor((int)w, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (w) atomicMax(item_bits + b, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // two-term fp16 split of a feature map: (B, C, n) fp32 -> [b][kc][term][pixel][16 channels] fp16, kc = ceil(C / 16) (channels
-// past C are zero): hi = fp16(x'), lo = fp16(x' - hi) with x' = x * 2^-k (exact), both round-to-nearest; x' - hi is exact in
-// fp32.  One 16-channel slice of one pixel and one term is 32 contiguous bytes: a GEMM tile's rows of a slice are one
+// past C are zero): hi = fp16(x'), lo = fp16(x' - hi) with x' = x * 2^-k (exact; k = kexp[b][pixel], corr_pixmax_kernel), both
+// round-to-nearest; x' - hi is exact in fp32.  One 16-channel slice of one pixel and one term is 32 contiguous bytes: a GEMM tile's rows of a slice are one
 // contiguous run.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kSplitPx = 64;
 typedef _Float16 __attribute__((ext_vector_type(4))) f16x4_t;
 
 __global__ void __launch_bounds__(256)
-corr_split_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, const unsigned* __restrict__ absmax_bits, int C,
+corr_split_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, const int* __restrict__ kexp, int C,
                   long n, int KC) {
     __shared__ float tile[16][kSplitPx + 1];
     const long px0 = (long)blockIdx.x * kSplitPx;
     const int kc = blockIdx.y, b = blockIdx.z;
     const int t = threadIdx.x;
-    const float down = ldexpf(1.0f, -split_exponent(absmax_bits[b]));
+    const float down = px0 + (t & 63) < n ? ldexpf(1.0f, -kexp[(long)b * n + px0 + (t & 63)]) : 0.f;   // this thread's pixel
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int ch = (t >> 6) + 4 * e, px = t & 63;
@@ -145,8 +160,9 @@ __device__ __forceinline__ f16x8_t as_f16x8(const u32x4& v) {
 struct Gemm3Args {
     const uint16_t* a;   // split fmap1  [B][KC][2][HW][16]
     const uint16_t* b;   // split fmap2 (or a pooled copy of it) [B][KC][2][n][16]
-    const unsigned* amax_a;   // per batch item: bit pattern of the largest magnitude of fmap1 / fmap2 (-> the powers of two the
-    const unsigned* amax_b;   // split copies were divided by)
+    const int* ka;            // [B][HW] / [B][n]: the power of two every row pixel (fmap1) / column pixel (fmap2 or its pooled copy)
+    const int* kb;            // was divided by before the split (corr_pixmax_kernel)
+    const unsigned* kb_item;  // [B]: bit pattern of fmap2's largest magnitude per item -> the common exponent columns are brought to
     float* out0;         // POOLED: level 0 (B*HW, H*W); plain: the level (B*HW, n)
     float* out1;         // POOLED: level 1 or null
     float* out2;         // POOLED: level 2 or null
@@ -284,8 +300,19 @@ corr_gemm3_kernel(const Gemm3Args g) {
     const long rowbase = (long)b * g.HW;
     // undo the operands' power-of-two scaling (exact) together with the 1/sqrt(C): 2^(ka + kb) applied in two halves, so that no
     // factor leaves the float range unless the result does
-    const int kt = split_exponent(g.amax_a[b]) + split_exponent(g.amax_b[b]);
-    const float up1 = ldexpf(1.0f, kt / 2), up2 = ldexpf(g.scale, kt - kt / 2);
+    // per-PIXEL scaling (exact powers of two): entry (i, j) = acc * 2^(ka_i + kb_j) / sqrt(C).  Columns are first brought to the item's
+    // common exponent kref >= every kb_j — acc * cb_j with cb_j = 2^(kb_j - kref) / sqrt(C) <= 1 / sqrt(C): no overflow, and pooled
+    // cells add columns on one scale — and v_ldexp_f32 then applies 2^(ka_i + kref) per row (no factor leaves the float range unless
+    // the result does).  Same instruction count as one scale per item: a multiply and an ldexp where two multiplies were.
+    const int kref = split_exponent(g.kb_item[b]);
+    int erow[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + 64 * wave + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            erow[h][r] = g.ka[(long)b * g.HW + (row < g.HW ? row : 0)] + kref;
+        }
     if (POOLED) {
         // Every level is addressed through a buffer resource that covers exactly the rows of this tile which exist: the range check
         // drops the rows past HW, and a lane whose column (or pooled cell) does not exist carries an offset past every range — no
@@ -304,9 +331,13 @@ corr_gemm3_kernel(const Gemm3Args g) {
         const int x = 32 * tc + li, yb = 4 * tr;
         const int x1 = x >> 1, x2 = x >> 2, y2 = yb >> 2;
         unsigned l0[4], l1[2];
+        float cb[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            l0[t] = (x < g.W && yb + t < g.H) ? ((unsigned)(yb + t) * g.W + x) * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
+        for (int t = 0; t < 4; ++t) {
+            const bool in = x < g.W && yb + t < g.H;
+            l0[t] = in ? ((unsigned)(yb + t) * g.W + x) * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
+            cb[t] = ldexpf(g.scale, (in ? g.kb[(long)b * g.n + (long)(yb + t) * g.W + x] : kref) - kref);
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p)   // level 1: the even lane of an x pair stores the 2 x 2 mean
             l1[p] = (!(lane & 1) && x1 < g.w1 && (yb >> 1) + p < g.h1) ? ((unsigned)((yb >> 1) + p) * g.w1 + x1) * 4u + (unsigned)(4 * kg) * pitch1
@@ -321,20 +352,21 @@ corr_gemm3_kernel(const Gemm3Args g) {
             for (int r = 0; r < 16; ++r) {
                 const unsigned row = wrow + (unsigned)((r & 3) + 8 * (r >> 2));   // + 4 kg: in the lane part
                 float s4 = 0.f;
+                const int er = erow[h][r];
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const float v0 = acc_h[2 * p][r], v1 = acc_h[2 * p + 1][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0 * up1 * up2), r0, l0[2 * p] + row * pitch0, 0, kNt);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1 * up1 * up2), r0, l0[2 * p + 1] + row * pitch0, 0, kNt);
+                    const float v0 = acc_h[2 * p][r] * cb[2 * p], v1 = acc_h[2 * p + 1][r] * cb[2 * p + 1];   // on the item's common column scale
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_ldexpf(v0, er)), r0, l0[2 * p] + row * pitch0, 0, kNt);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_ldexpf(v1, er)), r0, l0[2 * p + 1] + row * pitch0, 0, kNt);
                     // level 1: 2 x 2 mean = this lane's two rows + the same of its x-neighbour (lane ^ 1)
                     float s2 = v0 + v1;
                     s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
                     s4 += s2;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s2 * up1 * (0.25f * up2)), r1, l1[p] + row * pitch1, 0, kNt);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_ldexpf(s2 * 0.25f, er)), r1, l1[p] + row * pitch1, 0, kNt);
                 }
                 // level 2: 4 x 4 mean = both row pairs + the other half of the quad
                 s4 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s4), 0x4E, 0xf, 0xf, false));       // quad_perm [2,3,0,1]
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s4 * up1 * (0.0625f * up2)), r2, l2 + row * pitch2, 0, kNt);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_ldexpf(s4 * 0.0625f, er)), r2, l2 + row * pitch2, 0, kNt);
             }
         }
     } else {
@@ -344,10 +376,12 @@ corr_gemm3_kernel(const Gemm3Args g) {
         const __amdgpu_buffer_rsrc_t r0 = make_rsrc(g.out0 + (rowbase + i0) * g.n, (unsigned)(rows * g.n * 4));
         const unsigned pitch0 = (unsigned)g.n * 4u;
         unsigned l0[4];
+        float cb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const long col = (long)tc * kTN + 32 * t + li;
             l0[t] = col < g.n ? (unsigned)col * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
+            cb[t] = ldexpf(g.scale, (col < g.n ? g.kb[(long)b * g.n + col] : kref) - kref);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -358,7 +392,8 @@ corr_gemm3_kernel(const Gemm3Args g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned row = wrow + (unsigned)((r & 3) + 8 * (r >> 2));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc_h[t][r] * up1 * up2), r0, l0[t] + row * pitch0, 0, 2 /* nt */);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_ldexpf(acc_h[t][r] * cb[t], erow[h][r])), r0,
+                                                          l0[t] + row * pitch0, 0, 2 /* nt */);
                 }
         }
     }
@@ -798,18 +833,19 @@ extern "C" void alo_corr_level_shape(int H, int W, int level, int* h_out, int* w
 namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline size_t split_bytes(int B, int C, long n) { return align256((size_t)B * ((C + 15) / 16) * 2 * n * 16 * sizeof(uint16_t)); }
-inline size_t absmax_bytes(int B) { return align256((size_t)2 * B * sizeof(unsigned)); }
+inline size_t absmax_bytes(int B) { return align256((size_t)B * sizeof(unsigned)); }                 // fmap2's largest magnitude per item
+inline size_t kexp_bytes(int B, long n) { return align256((size_t)B * n * sizeof(int)); }             // one power of two per pixel
 }  // namespace
 
-// Scratch: the split copies of fmap1 and fmap2 and the two per-batch-item magnitudes; for pyramids deeper than 3 levels also the
-// 2x2-average chain of fmap2 (fp32) and the split copies of its levels >= 3.
+// Scratch: the split copies of fmap1 and fmap2, their per-pixel powers of two and fmap2's per-item magnitude; for pyramids deeper
+// than 3 levels also the 2x2-average chain of fmap2 (fp32) and the split copies + per-pixel powers of two of its levels >= 3.
 extern "C" size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels) {
-    size_t total = 2 * split_bytes(B, C, (long)H * W) + absmax_bytes(B);
+    size_t total = 2 * split_bytes(B, C, (long)H * W) + 2 * kexp_bytes(B, (long)H * W) + absmax_bytes(B);
     for (int l = 1; l < num_levels && num_levels > 3; ++l) {
         int h, w;
         alo_corr_level_shape(H, W, l, &h, &w);
         total += align256((size_t)B * C * h * w * sizeof(float));
-        if (l >= 3) total += split_bytes(B, C, (long)h * w);
+        if (l >= 3) total += split_bytes(B, C, (long)h * w) + kexp_bytes(B, (long)h * w);
     }
     return total;
 }
@@ -840,31 +876,31 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
     ws += split_bytes(B, C, HW);
     uint16_t* f2s = reinterpret_cast<uint16_t*>(ws);
     ws += split_bytes(B, C, HW);
-    unsigned* amax = reinterpret_cast<unsigned*>(ws);   // [2][B]
+    int* ka = reinterpret_cast<int*>(ws);               // [B][HW]
+    ws += kexp_bytes(B, HW);
+    int* kb = reinterpret_cast<int*>(ws);               // [B][HW]
+    ws += kexp_bytes(B, HW);
+    unsigned* amax_b = reinterpret_cast<unsigned*>(ws);  // [B]
     ws += absmax_bytes(B);
-    hipError_t em = hipMemsetAsync(amax, 0, (size_t)2 * B * sizeof(unsigned), stream);
+    hipError_t em = hipMemsetAsync(amax_b, 0, (size_t)B * sizeof(unsigned), stream);
     if (em != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_build: memset: %s", hipGetErrorString(em));
-    auto absmax = [&](const float* in, unsigned* bits) -> int {
-        const long per_batch = (long)C * HW;
-        // few workgroups with many loads in flight each: the atomics of an item all aim at one word and cost ~12 ns apiece
-        const long want = (per_batch / 4 + 2047) / 2048;
-        const unsigned blocks = (unsigned)(want > 96 ? 96 : want);
-        hipLaunchKernelGGL(corr_absmax_kernel, dim3(blocks ? blocks : 1, (unsigned)B), dim3(256), 0, stream, in, bits, per_batch);
-        return check_launch("alo_corr_build(absmax)");
+    auto pixmax = [&](const float* in, int* kexp, unsigned* item_bits, long n) -> int {
+        hipLaunchKernelGGL(corr_pixmax_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, stream, in, kexp, item_bits, C, n);
+        return check_launch("alo_corr_build(pixmax)");
     };
-    if (int rc = absmax(fmap1, amax)) return rc;
-    if (int rc = absmax(fmap2, amax + B)) return rc;
-    auto split = [&](const float* in, uint16_t* out, const unsigned* bits, long n) -> int {
+    if (int rc = pixmax(fmap1, ka, nullptr, HW)) return rc;
+    if (int rc = pixmax(fmap2, kb, amax_b, HW)) return rc;
+    auto split = [&](const float* in, uint16_t* out, const int* kexp, long n) -> int {
         const dim3 grid((unsigned)((n + kSplitPx - 1) / kSplitPx), (unsigned)KC, (unsigned)B);
-        hipLaunchKernelGGL(corr_split_kernel, grid, dim3(256), 0, stream, in, out, bits, C, n, KC);
+        hipLaunchKernelGGL(corr_split_kernel, grid, dim3(256), 0, stream, in, out, kexp, C, n, KC);
         return check_launch("alo_corr_build(split)");
     };
-    if (int rc = split(fmap1, f1s, amax, HW)) return rc;
-    if (int rc = split(fmap2, f2s, amax + B, HW)) return rc;
+    if (int rc = split(fmap1, f1s, ka, HW)) return rc;
+    if (int rc = split(fmap2, f2s, kb, HW)) return rc;
 
     Gemm3Args g;
     g.a = f1s; g.b = f2s;
-    g.amax_a = amax; g.amax_b = amax + B;
+    g.ka = ka; g.kb = kb; g.kb_item = amax_b;
     g.B = B; g.KC = KC; g.HW = (int)HW;
     g.H = H; g.W = W; g.n = (int)HW;
     g.tiles_m = (int)((HW + kTM - 1) / kTM);
@@ -905,9 +941,12 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
         const long n = (long)h * w;
         uint16_t* ps = reinterpret_cast<uint16_t*>(ws);
         ws += split_bytes(B, C, n);
-        if (int rc = split(pooled, ps, amax + B, n)) return rc;   // a 2x2 mean is no larger than fmap2's largest entry
+        int* kp = reinterpret_cast<int*>(ws);
+        ws += kexp_bytes(B, n);
+        if (int rc = pixmax(pooled, kp, nullptr, n)) return rc;   // (a 2x2 mean is no larger than fmap2's largest entry: kb_item still bounds it)
+        if (int rc = split(pooled, ps, kp, n)) return rc;
         Gemm3Args e = g;
-        e.b = ps; e.n = (int)n;
+        e.b = ps; e.kb = kp; e.n = (int)n;
         e.out0 = levels[l]; e.out1 = e.out2 = nullptr;
         e.tiles_r = 1;
         e.tiles_c = (int)((n + kTN - 1) / kTN);

@@ -143,7 +143,7 @@ def test_full_size_properties_720p():
 
 @pytest.mark.parametrize("sa,sb", [(1e-3, 1e-3), (3e4, 7e5), (1e-20, 1e-12), (1e12, 1e-15), (5e18, 3e17)])
 def test_build_is_accurate_at_any_magnitude(sa, sb):
-    """The operands travel as two fp16 terms after a per-item power-of-two scaling: the volume must keep fp32-class relative accuracy
+    """The operands travel as two fp16 terms after a power-of-two scaling (per pixel since round 5): the volume must keep fp32-class relative accuracy
     from 1e-20 to 1e+18, with batch items of very different magnitude side by side, small entries next to large ones, and an
     all-zero item."""
     rng = np.random.default_rng(77)
@@ -173,6 +173,38 @@ def test_build_is_accurate_at_any_magnitude(sa, sb):
                 assert not got[b * n:(b + 1) * n].any()
             else:   # 3e-6 of the item's largest entry: fp32 accumulation of 96 products, nothing worse
                 assert np.abs(got[b * n:(b + 1) * n] - r).max() <= 3e-6 * scale, (lvl, b)
+
+
+def test_build_accuracy_is_relative_to_each_row_and_column_not_to_the_item():
+    """Round-4 verdict ("fp32 only relative to the item's largest entry"): every pixel's feature vector is now scaled by its OWN power
+    of two, so an entry of the volume is accurate relative to |f1_i| |f2_j| — what torch.matmul's fp32 dot product gives (its
+    error is relative to sum_c |a_c b_c|) — however dim pixel i or j is next to the item's brightest.  Pixels span 24 orders of
+    magnitude inside ONE item; bound: 4e-6 of sum_c |f1_ci f2_cj| / sqrt(C) per entry (fp32 accumulation of 96 products of 22-bit
+    operands), levels 1-3 against the pooled float64 volume with the pooled bound."""
+    rng = np.random.default_rng(79)
+    B, C, H, W = 2, 96, 12, 20
+    f1 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    f2 = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    f1 *= (10.0 ** rng.uniform(-12, 12, (B, 1, H, W))).astype(np.float32)      # every pixel its own magnitude
+    f2 *= (10.0 ** rng.uniform(-12, 12, (B, 1, H, W))).astype(np.float32)
+    f2[1, :, 5, 7] = 0.0                                                         # an all-zero pixel among them
+    a64, b64 = f1.astype(np.float64).reshape(B, C, -1), f2.astype(np.float64).reshape(B, C, -1)
+    vol = (np.einsum("bci,bcj->bij", a64, b64) / np.sqrt(C)).reshape(B * H * W, 1, H, W)
+    bound = (np.einsum("bci,bcj->bij", np.abs(a64), np.abs(b64)) / np.sqrt(C)).reshape(B * H * W, 1, H, W)
+    ref, bnd = [vol], [bound]
+    for _ in range(3):
+        h, w = ref[-1].shape[2] // 2, ref[-1].shape[3] // 2
+        pool = lambda p: p[:, :, :2 * h, :2 * w].reshape(-1, 1, h, 2, w, 2).mean(axis=(3, 5))   # noqa: E731
+        ref.append(pool(ref[-1]))
+        bnd.append(pool(bnd[-1]))
+    levels = alo_hip.corr_build(dev(f1), dev(f2), 4)
+    for lvl in range(4):
+        got = levels[lvl].cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all()
+        err = np.abs(got - ref[lvl])
+        assert (err <= 4e-6 * bnd[lvl] + 1e-300).all(), (lvl, float((err / (bnd[lvl] + 1e-300)).max()))
+    n = H * W
+    assert not levels[0].cpu().numpy().reshape(B, n, n)[1, :, 5 * W + 7].any()
 
 
 def test_build_propagates_non_finite_features_like_the_reference():
