@@ -66,41 +66,44 @@ __device__ __forceinline__ int split_exponent(unsigned absmax_bits) {
 // ------------------------------------------------------------------------------------------------------------------
 // per-PIXEL magnitude of a (B, C, n) fp32 feature map: kexp[b][px] = the power of two pixel px's C-vector is divided by before it is
 // split (its largest finite magnitude lands in [2^14, 2^15)), and — for the map whose pixels become COLUMNS of the volume — the bit
-// pattern of the item's largest finite magnitude (atomicMax; `item_bits` zero on entry, may be null).  One thread per pixel walks the
-// channels: a wave reads 256 consecutive bytes per channel.  Scaling every pixel by its OWN power of two makes the accuracy of a
+// pattern of the item's largest finite magnitude (atomicMax; `item_bits` zero on entry, may be null).  A workgroup serves 64 consecutive pixels, each of its four
+// waves a quarter of the channels (256 contiguous bytes per load, eight loads in flight per thread).  Scaling every pixel by its OWN power of two makes the accuracy of a
 // volume entry relative to |f1_i| |f2_j| (what fp32 matmul gives), not to the item's largest entry: a dim image region next to a
 // bright one keeps its 22 bits.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int kPixPx = 64, kPixGroups = 4;   // a workgroup: 64 consecutive pixels x 4 channel groups
 __global__ void __launch_bounds__(256)
 corr_pixmax_kernel(const float* __restrict__ in, int* __restrict__ kexp, unsigned* __restrict__ item_bits, int C, long n) {
     const int b = blockIdx.y;
-    const long px = blockIdx.x * 256L + threadIdx.x;
+    const int lp = threadIdx.x & (kPixPx - 1), cg = threadIdx.x >> 6;   // a wave = one channel group: 256 contiguous bytes per load
+    const long px = (long)blockIdx.x * kPixPx + lp;
     const bool live = px < n;
     const float* p = in + (long)b * C * n + (live ? px : 0);
     // (float compares, not integer max on the bit patterns: hipcc 7.2's instruction selection crashes on the integer form of this loop)
-    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;   // four independent chains: four loads in flight per thread
     auto fin = [](float v) { v = fabsf(v); return v < INFINITY ? v : 0.f; };   // Inf / NaN do not take part
-    int c = 0;
-    for (; c + 4 <= C; c += 4) {
-        f0 = fmaxf(f0, fin(p[(long)c * n]));
-        f1 = fmaxf(f1, fin(p[(long)(c + 1) * n]));
-        f2 = fmaxf(f2, fin(p[(long)(c + 2) * n]));
-        f3 = fmaxf(f3, fin(p[(long)(c + 3) * n]));
+    float f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) f[u] = 0.f;
+    // channels cg, cg + 4, cg + 8, ...: eight independent loads in flight per thread
+    int c = cg;
+    for (; c + 7 * kPixGroups < C; c += 8 * kPixGroups) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) f[u] = fmaxf(f[u], fin(p[(long)(c + u * kPixGroups) * n]));
     }
-    for (; c < C; ++c) f0 = fmaxf(f0, fin(p[(long)c * n]));
-    unsigned m = live ? __float_as_uint(fmaxf(fmaxf(f0, f1), fmaxf(f2, f3))) : 0u;
-    if (live) kexp[(long)b * n + px] = split_exponent(m);
+    for (; c < C; c += kPixGroups) f[0] = fmaxf(f[0], fin(p[(long)c * n]));
+    float m = fmaxf(fmaxf(fmaxf(f[0], f[1]), fmaxf(f[2], f[3])), fmaxf(fmaxf(f[4], f[5]), fmaxf(f[6], f[7])));
+    __shared__ float part[kPixGroups][kPixPx];
+    part[cg][lp] = live ? m : 0.f;
+    __syncthreads();
+    if (cg != 0) return;   // wave-uniform
+    m = fmaxf(fmaxf(part[0][lp], part[1][lp]), fmaxf(part[2][lp], part[3][lp]));
+    const unsigned bits = __float_as_uint(m);
+    if (live) kexp[(long)b * n + px] = split_exponent(bits);
     if (item_bits == nullptr) return;   // uniform
-    __shared__ unsigned part[4];
-    unsigned w = m;
+    unsigned w = bits;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w = max(w, (unsigned)__shfl_xor((int)w, o, 64));
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        w = max(max(part[0], part[1]), max(part[2], part[3]));
-        if (w) atomicMax(item_bits + b, w);
-    }
+    if (lp == 0 && w) atomicMax(item_bits + b, w);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -254,6 +257,44 @@ corr_gemm3_kernel(const Gemm3Args g) {
         for (int e = 0; e < 2; ++e) dma16(bsrc[e] + kc * b_step, ldsB(stage) + (wave + 4 * e) * 64);
     };
 
+    // per-PIXEL scaling (exact powers of two): entry (i, j) = acc * 2^(ka_i + kb_j) / sqrt(C).  Columns are first brought to the item's
+    // common exponent kref >= every kb_j — acc * cb_j with cb_j = 2^(kb_j - kref) / sqrt(C) <= 1 / sqrt(C): no overflow, and pooled
+    // cells add columns on one scale — and v_ldexp_f32 then applies 2^(ka_i + kref) per row (no factor leaves the float range unless
+    // the result does).  Same instruction count as one scale per item: a multiply and an ldexp where two multiplies were.
+    const int kref = split_exponent(g.kb_item[b]);
+    int erow[2][16];
+    {
+        // registers r = 4 q .. 4 q + 3 of a lane are four CONSECUTIVE rows: one 16-byte load per (h, q) (4-byte aligned: HW is arbitrary);
+        // rows past HW read the padding behind the array (kexp_bytes) — their stores are dropped by the range check
+        typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+        const int* kap = g.ka + (long)b * g.HW + i0 + 64 * wave + 4 * (lane >> 5);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const i32x4_u v = *reinterpret_cast<const i32x4_u*>(kap + 32 * h + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) erow[h][4 * q + e] = v[e] + kref;
+            }
+    }
+    // (requested HERE, before the K loop: 36 loads whose latency would otherwise stand exposed at the head of the epilogue — measured
+    // + 7 % on the kernel when they were issued there)
+    float cb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        long col;
+        bool in;
+        if (POOLED) {
+            const int y = 4 * tr + t, x = 32 * tc + (lane & 31);
+            in = y < g.H && x < g.W;
+            col = (long)y * g.W + x;
+        } else {
+            col = (long)tc * kTN + 32 * t + (lane & 31);
+            in = col < g.n;
+        }
+        cb[t] = ldexpf(g.scale, (in ? g.kb[(long)b * g.n + col] : kref) - kref);
+    }
+
     f32x16 acc[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -300,19 +341,6 @@ corr_gemm3_kernel(const Gemm3Args g) {
     const long rowbase = (long)b * g.HW;
     // undo the operands' power-of-two scaling (exact) together with the 1/sqrt(C): 2^(ka + kb) applied in two halves, so that no
     // factor leaves the float range unless the result does
-    // per-PIXEL scaling (exact powers of two): entry (i, j) = acc * 2^(ka_i + kb_j) / sqrt(C).  Columns are first brought to the item's
-    // common exponent kref >= every kb_j — acc * cb_j with cb_j = 2^(kb_j - kref) / sqrt(C) <= 1 / sqrt(C): no overflow, and pooled
-    // cells add columns on one scale — and v_ldexp_f32 then applies 2^(ka_i + kref) per row (no factor leaves the float range unless
-    // the result does).  Same instruction count as one scale per item: a multiply and an ldexp where two multiplies were.
-    const int kref = split_exponent(g.kb_item[b]);
-    int erow[2][16];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = i0 + 64 * wave + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            erow[h][r] = g.ka[(long)b * g.HW + (row < g.HW ? row : 0)] + kref;
-        }
     if (POOLED) {
         // Every level is addressed through a buffer resource that covers exactly the rows of this tile which exist: the range check
         // drops the rows past HW, and a lane whose column (or pooled cell) does not exist carries an offset past every range — no
@@ -331,13 +359,9 @@ corr_gemm3_kernel(const Gemm3Args g) {
         const int x = 32 * tc + li, yb = 4 * tr;
         const int x1 = x >> 1, x2 = x >> 2, y2 = yb >> 2;
         unsigned l0[4], l1[2];
-        float cb[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool in = x < g.W && yb + t < g.H;
-            l0[t] = in ? ((unsigned)(yb + t) * g.W + x) * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
-            cb[t] = ldexpf(g.scale, (in ? g.kb[(long)b * g.n + (long)(yb + t) * g.W + x] : kref) - kref);
-        }
+        for (int t = 0; t < 4; ++t)
+            l0[t] = (x < g.W && yb + t < g.H) ? ((unsigned)(yb + t) * g.W + x) * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
 #pragma unroll
         for (int p = 0; p < 2; ++p)   // level 1: the even lane of an x pair stores the 2 x 2 mean
             l1[p] = (!(lane & 1) && x1 < g.w1 && (yb >> 1) + p < g.h1) ? ((unsigned)((yb >> 1) + p) * g.w1 + x1) * 4u + (unsigned)(4 * kg) * pitch1
@@ -355,7 +379,10 @@ corr_gemm3_kernel(const Gemm3Args g) {
                 const int er = erow[h][r];
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    const float v0 = acc_h[2 * p][r] * cb[2 * p], v1 = acc_h[2 * p + 1][r] * cb[2 * p + 1];   // on the item's common column scale
+                    float v0 = acc_h[2 * p][r] * cb[2 * p], v1 = acc_h[2 * p + 1][r] * cb[2 * p + 1];   // on the item's common column scale
+                    // (keeps the SLP vectoriser from pairing these into v_pk_mul / v_pk_add: the register shuffles around the packed
+                    // forms cost more instructions than they save — 1 562 against 1 370 VALU for the kernel)
+                    asm volatile("" : "+v"(v0), "+v"(v1));
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_ldexpf(v0, er)), r0, l0[2 * p] + row * pitch0, 0, kNt);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_ldexpf(v1, er)), r0, l0[2 * p + 1] + row * pitch0, 0, kNt);
                     // level 1: 2 x 2 mean = this lane's two rows + the same of its x-neighbour (lane ^ 1)
@@ -376,12 +403,10 @@ corr_gemm3_kernel(const Gemm3Args g) {
         const __amdgpu_buffer_rsrc_t r0 = make_rsrc(g.out0 + (rowbase + i0) * g.n, (unsigned)(rows * g.n * 4));
         const unsigned pitch0 = (unsigned)g.n * 4u;
         unsigned l0[4];
-        float cb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const long col = (long)tc * kTN + 32 * t + li;
             l0[t] = col < g.n ? (unsigned)col * 4u + (unsigned)(4 * kg) * pitch0 : kDrop;
-            cb[t] = ldexpf(g.scale, (col < g.n ? g.kb[(long)b * g.n + col] : kref) - kref);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -834,7 +859,7 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline size_t split_bytes(int B, int C, long n) { return align256((size_t)B * ((C + 15) / 16) * 2 * n * 16 * sizeof(uint16_t)); }
 inline size_t absmax_bytes(int B) { return align256((size_t)B * sizeof(unsigned)); }                 // fmap2's largest magnitude per item
-inline size_t kexp_bytes(int B, long n) { return align256((size_t)B * n * sizeof(int)); }             // one power of two per pixel
+inline size_t kexp_bytes(int B, long n) { return align256(((size_t)B * n + kTM + 4) * sizeof(int)); }   // one power of two per pixel (+ a row tile of padding: the last tile reads whole)
 }  // namespace
 
 // Scratch: the split copies of fmap1 and fmap2, their per-pixel powers of two and fmap2's per-item magnitude; for pyramids deeper
@@ -885,7 +910,7 @@ extern "C" int alo_corr_build(const float* fmap1, const float* fmap2, float* con
     hipError_t em = hipMemsetAsync(amax_b, 0, (size_t)B * sizeof(unsigned), stream);
     if (em != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_corr_build: memset: %s", hipGetErrorString(em));
     auto pixmax = [&](const float* in, int* kexp, unsigned* item_bits, long n) -> int {
-        hipLaunchKernelGGL(corr_pixmax_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, stream, in, kexp, item_bits, C, n);
+        hipLaunchKernelGGL(corr_pixmax_kernel, dim3((unsigned)((n + kPixPx - 1) / kPixPx), (unsigned)B), dim3(256), 0, stream, in, kexp, item_bits, C, n);
         return check_launch("alo_corr_build(pixmax)");
     };
     if (int rc = pixmax(fmap1, ka, nullptr, HW)) return rc;

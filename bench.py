@@ -975,8 +975,9 @@ def main():
                     "unit": "pairs/s", "steps": a.raft_steps, "warmup": a.raft_warmup, "ms_per_step": round(raft_seconds / a.raft_steps * 1e3, 2),
                     "dtype": "f32",
                     "dtype_note": "fp32 everywhere except the all-pairs contraction, which accumulates in fp32 over 22-bit operands "
-                                  "(two fp16 terms per feature after a power-of-two scaling, hi*hi + hi*lo + lo*hi; the dropped lo*lo is "
-                                  "<= 2^-22 relative): accurate to 3e-6 of an item's largest entry, not per element like torch.matmul",
+                                  "(two fp16 terms per feature after a per-pixel power-of-two scaling, hi*hi + hi*lo + lo*hi; the dropped "
+                                  "lo*lo is <= 2^-22 relative): an entry is accurate to 4e-6 of sum_c |f1_ci f2_cj| / sqrt(C), the yardstick "
+                                  "of an fp32 dot product",
                     "config": {"workload": f"alonet.raft.RAFT 32 iters, batch {a.raft_batch} synthetic 1280x720 pairs per GPU",
                                                "launch": "eager" if raft_step is raft_eager else "HIP graph replay",
                                                "per_gpu_batch": a.raft_batch}}

@@ -190,8 +190,8 @@ int alo_msda_backward_hinted(const void* value, const int32_t* spatial_shapes, c
  * (F.avg_pool2d(2, stride=2), corr.py:25-27). */
 void alo_corr_level_shape(int H, int W, int level, int* h_out, int* w_out);
 
-/* Bytes of scratch alo_corr_build needs (fp16-split copies of the feature maps and their per-item magnitudes; the 2x2-average
- * chain of fmap2 for pyramids deeper than 3 levels). */
+/* Bytes of scratch alo_corr_build needs (fp16-split copies of the feature maps, one power of two per pixel of each, fmap2's
+ * per-item magnitude; the 2x2-average chain of fmap2 for pyramids deeper than 3 levels). */
 size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels);
 
 /*
@@ -200,10 +200,12 @@ size_t alo_corr_build_workspace_bytes(int B, int C, int H, int W, int num_levels
  *   level_0[b*HW + i, 0, y, x] = <fmap1[b,:,i], fmap2[b,:,y*W + x]> / sqrt(C)
  *   level_{l+1}                = avg_pool2d(level_l, 2, stride 2)        over the last two dims
  *
- * Level 0 is one dense contraction on the fp16 matrix cores at fp32 accuracy (every batch item scaled by a power of two taken
- * from its largest magnitude, every feature split into two fp16 terms hi + lo = 22 significant bits, the cross products hi*hi,
- * hi*lo, lo*hi accumulated in fp32: error < 2^-21 relative per product at any input magnitude, fp32 accumulation; non-finite
- * features propagate to the rows / columns the reference makes non-finite);
+ * Level 0 is one dense contraction on the fp16 matrix cores at fp32 accuracy (every PIXEL's feature vector scaled by a power of
+ * two taken from its own largest magnitude, every feature split into two fp16 terms hi + lo = 22 significant bits, the cross
+ * products hi*hi, hi*lo, lo*hi accumulated in fp32 and the two powers of two undone exactly per entry: error < 2^-21 relative
+ * per product at any input magnitude, i.e. an entry is accurate relative to sum_c |f1_ci f2_cj| like an fp32 dot product, however
+ * dim its pixels are next to the brightest of the item; non-finite features propagate to the rows / columns the reference makes
+ * non-finite);
  * levels 1 and 2 are pooled from the accumulators in the same launch; deeper levels are the same contraction against the
  * 2x2-average chain of fmap2 (average pooling commutes with the inner product).  Results agree with the reference's
  * matmul + avg_pool2d chain to fp32 rounding.
