@@ -46,12 +46,16 @@ def test_pyramid_shape_helpers():
     assert alo_hip.corr_level_shapes(90, 160, 4) == [(90, 160), (45, 80), (22, 40), (11, 20)]
     assert alo_hip.corr_level_shapes(17, 18, 4) == [(17, 18), (8, 9), (4, 4), (2, 2)]
     lib = alo_hip.lib()
-    # fp16-split copies of both feature maps (2 terms x 2 bytes per channel, 16-channel slices) + the per-item magnitudes (256 bytes)
-    # + the fp32 pooled chain and the split copy of level 3 for a 4-level pyramid; every piece rounded up to 256 bytes
+    # fp16-split copies of both feature maps (2 terms x 2 bytes per channel, 16-channel slices) + one int32 power of two per pixel of
+    # each map (padded by a row tile of 256 + 4 entries: the last tile reads whole) + fmap2's per-item magnitudes (256 bytes) + the fp32
+    # pooled chain, the split copy and the per-pixel exponents of level 3 for a 4-level pyramid; every piece rounded up to 256 bytes
+    up = lambda x: (x + 255) // 256 * 256  # noqa: E731
+    kexp = lambda B, n: up((B * n + 256 + 4) * 4)  # noqa: E731
     split0 = 4 * 16 * 2 * 14400 * 16 * 2
-    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 3) == 2 * split0 + 256
-    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 4) == 2 * split0 + 256 + 4 * 256 * (3600 + 880 + 220) * 4 + 4 * 16 * 2 * 220 * 16 * 2
-    assert lib.alo_corr_build_workspace_bytes(1, 8, 16, 16, 1) == 2 * 1 * 1 * 2 * 256 * 16 * 2 + 256
+    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 3) == 2 * split0 + 2 * kexp(4, 14400) + 256
+    assert lib.alo_corr_build_workspace_bytes(4, 256, 90, 160, 4) == (2 * split0 + 2 * kexp(4, 14400) + 256 + 4 * 256 * (3600 + 880 + 220) * 4
+                                                                     + 4 * 16 * 2 * 220 * 16 * 2 + kexp(4, 220))
+    assert lib.alo_corr_build_workspace_bytes(1, 8, 16, 16, 1) == 2 * 1 * 1 * 2 * 256 * 16 * 2 + 2 * kexp(1, 256) + 256
 
 
 def test_argument_errors_are_reported_before_any_launch():
