@@ -741,3 +741,29 @@ def test_get_mask_queries_single_transfer_form_equals_the_per_image_form():
     none_kept = [torch.zeros(9, dtype=torch.bool, device=DEV) for _ in range(4)]
     rows0, _ = get_mask_queries(frames=None, m_outputs={"dec_outputs": dec}, model=None, filters=none_kept)
     assert rows0.shape == (4, 0, 16)
+
+
+def test_finetune_variants_run_on_the_hip_path():
+    """The re-headed pre-made models of round 5 (alonet/deformable_detr/deformable_detr_r50_finetune.py and its panoptic
+    counterpart, reference lines in their docstrings) through the HIP op: new class counts in the logits, the bf16 fast path sees
+    the NEW head (its merged / packed copies are invalidated on re-heading), and the mask head with BatchNorm layers (the fast
+    GroupNorm kernel must not be handed a BatchNorm) gives finite masks."""
+    from alonet.deformable_detr import DeformableDetrR50Finetune
+    from alonet.deformable_detr_panoptic import DeformableDetrR50PanopticFinetune
+
+    torch.manual_seed(3)
+    frames = aloscene.Frame.batch_list([aloscene.Frame(torch.rand(3, 256, 320) * 255, normalization="255").norm_resnet()
+                                        for _ in range(2)]).to(DEV)
+    m = DeformableDetrR50Finetune(num_classes=5, base_weights=None, aux_loss=False, device=torch.device(DEV)).eval()
+    with torch.no_grad():
+        out32 = m(frames)
+        hip = out32["pred_logits"]
+        ref = m(frames, is_tracing=None)["pred_logits"]          # the reference's pure-torch branch, same weights
+        out16 = m.to(torch.bfloat16)(frames.to(torch.bfloat16))
+    assert hip.shape == (2, 300, 5) and (hip - ref).abs().max().item() <= 1e-3
+    assert out16["pred_logits"].shape == (2, 300, 5) and (out16["pred_logits"].float() - hip).abs().max().item() <= 0.08
+    assert len(m.inference(out32, threshold=0.0)) == 2
+    p = DeformableDetrR50PanopticFinetune(num_classes=4, base_weights=None, use_bn_layers=True, device=torch.device(DEV)).eval()
+    with torch.no_grad():
+        po = p.to(torch.bfloat16).to(memory_format=torch.channels_last)(frames.to(torch.bfloat16))
+    assert po["pred_logits"].shape == (2, 300, 4) and torch.isfinite(po["pred_masks"].float()).all()
