@@ -16,6 +16,7 @@
 //   * backward: lanes reduce d/d(loc), d/d(attn) over channels with wave shuffles (no LDS, no block barriers, no
 //     serial thread-0 sum), grad_value goes out through hardware fp32/fp64 atomics.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "common.hpp"
@@ -1861,6 +1862,12 @@ extern "C" int alo_msda_resident_levels(const int32_t* host_spatial_shapes, int 
 }
 
 namespace {
+// ALO_MSDA_BWD = "tiled" keeps msda_bwd_tiled_kernel for the encoder-shaped launches the wide path would take (measurement knob)
+int bwd_policy() {   // read per call: a test flips it inside one process
+    const char* e = getenv("ALO_MSDA_BWD");
+    return (e && !strcmp(e, "tiled")) ? 1 : 0;
+}
+
 int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_t* level_start_index,
                   const void* sampling_loc, const void* attn_weight, const void* grad_out, void* grad_value,
                   void* grad_sampling_loc, void* grad_attn_weight, int N, int S, int M, int D, int L, int Lq, int P,
@@ -1878,7 +1885,15 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
     const bool aligned = (((uintptr_t)value | (uintptr_t)grad_out) & 15) == 0;
     const bool all_aligned = aligned && (((uintptr_t)sampling_loc | (uintptr_t)attn_weight | (uintptr_t)grad_value |
                                           (uintptr_t)grad_sampling_loc | (uintptr_t)grad_attn_weight) & 15) == 0;
-    if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && all_aligned && (double)S * M * 128 < 4.0e9 && (double)Lq * M * 32 < 2.0e9) {   // 32-bit byte offsets inside one frame
+    const bool frame32 = (double)S * M * 128 < 4.0e9 && (double)Lq * M * 32 < 2.0e9;   // 32-bit byte offsets inside one frame
+    if ((value_dtype == ALO_F32 || value_dtype == ALO_BF16) && D == 32 && L == 4 && P == 4 && all_aligned && frame32 && host_shapes &&
+        Lq == S && bwd_policy() != 1) {
+        // queries = the pyramid's own pixels: 16x16 query blocks, sorted on chip (msda_bwd_wide.hip)
+        const int rc = msda_backward_wide(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
+                                          grad_sampling_loc, grad_attn_weight, N, S, M, Lq, value_dtype, host_shapes, stream);
+        if (rc != ALO_ERR_UNSUPPORTED) return rc;
+    }
+    if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && all_aligned && frame32) {
         // the DETR-family shape: tiled, window-dense backward on the fp32 matrix cores (msda_bwd_tiled_kernel)
         TileDims td;
         td.S = S; td.M = M; td.Lq = Lq;

@@ -1,0 +1,535 @@
+// Multi-scale deformable attention, backward — the WIDE path: one workgroup owns a 16x16 block of encoder queries of one head.
+//
+// Replaces (with msda.hip's kernels) alonet_custom::ms_deform_attn_backward: /root/reference
+// alonet/deformable_detr/ops/src/cuda/ms_deform_attn_cuda.cu:83-153, cuda/ms_deform_im2col_cuda.cuh:87-159 (bilinear
+// adjoint), :301-403 (one thread per (query, head, level, point), one atomicAdd per corner and channel).
+//
+// Why it exists.  The chip retires ~10.5 G 128-byte atomic rows per second whatever the pattern (tools/micro/atomic_scope.hip), so
+// the time of a scatter-formulated backward is its number of atomic rows / 10.5 G.  msda_bwd_tiled_kernel forms the sums of a
+// 4x4 query tile on chip (one row per touched pixel per tile): 6.3 M rows on the random-init ring, but 12-13 M on the survey and
+// trained-like spreads, where neighbouring queries share fewer pixels per tile (profiles/r05_bwd_rows_sim.txt).  A 16x16 block
+// shares 3-4 x more (2.9 / 4.0 / 4.3 M rows).  The sums of a block this wide do not fit a dense A[row][query] matrix, and LDS float
+// atomics are slow (ds_add_f32: 194 clocks per wave instruction, tools/micro/lds_atomic.hip) — so the block SORTS instead:
+//
+//   per target level (4 passes over the block's 256 queries x 4 points x 4 corners = 4096 corner entries):
+//   1. insert   thread (query, point pair) turns its two sampling points into taps.  A corner inside the block's WINDOW on that
+//               level (a <= 56 x 56 clip box around the block's own footprint) is pushed on the linked list of its window row:
+//               ds_wrxchg_rtn_b32 on head[row] (integer LDS atomics are fast), next[entry] = previous head, and the scalar
+//               tbl[entry] = bilinear weight x attention weight.  No counting, no prefix sum, no second pass.
+//   2. gather   8 lanes own ONE touched row (8 rows per wave at a time): they hold value[row] (read from memory exactly once per
+//               block) and walk the row's list; per entry ONE 128-byte LDS read of the query's grad_out row feeds both sums:
+//                 grad_value[row] += tbl[entry] * grad_out[q]                  (registers; ONE atomic row per touched row at the end)
+//                 d[entry]         = <value[row], grad_out[q]>                  (3 DPP adds over the 8 lanes; overwrites tbl[entry])
+//   3. finish   the thread that owns the sample reads its four d's back: grad_attn = sum_k w_k d_k, grad_loc = attn * (W, H) * (...)
+//               — the same expressions as msda_bwd_tiled_kernel's stage 3.
+//   A sample with a corner outside the window (far outliers; every sample of a uniform distribution) goes on an overflow list and
+//   takes the per-corner route of msda_bwd_kernel at the end: same results, old cost.
+//
+// Shapes served: value / grad_out fp32 or bf16 (gradients fp32), D = 32, L = P = 4, queries = the pyramid's own pixels (Lq == S).
+// The host copy of the shapes sizes the grid AND travels by value; a launch whose device shapes differ from it sends every
+// sample down the per-corner route with the queries grouped 256 in a row (correct, slow — the Python host never caches shapes).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace alo {
+namespace {
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kSlots = 256;              // query slots of a block (16 x 16 on the fine levels)
+constexpr int kWThreads = 512;           // 8 waves: thread = (query slot, point pair)
+constexpr int kClip = 56;                // window side limit: footprint (<= 32) + 12 px of halo either side
+constexpr int kRowsMax = kClip * kClip;  // 3136 window rows
+constexpr unsigned kNil = 0xffffu;
+constexpr unsigned kDrop = 0xffffff00u;  // a byte offset past any frame slab: the buffer range check drops the lane
+
+constexpr int kOffG = 0;                              // float  G[256][32]      grad_out rows of the block's queries
+constexpr int kOffTbl = kOffG + kSlots * 32 * 4;      // float  tbl[4096]       w * attn per corner entry, then d
+constexpr int kOffCnt = kOffTbl + 4096 * 4;           // u32    cnt[3140]       entries per window row, then their exclusive prefix sum
+constexpr int kOffList = kOffCnt + 3140 * 4;          // u16    list[4096]      entries sorted by window row
+constexpr int kOffOvf = kOffList + 4096 * 2;          // u32    ovf[128]        bit per (level, sample): takes the per-corner route
+constexpr int kOffItems = kOffOvf + 128 * 4;          // u16    items[3168]     work items of the gather: row | (32-entry segment << 12)
+constexpr int kOffMisc = kOffItems + 3168 * 2;        // u32    wsum[8], total  wave totals of the prefix sum
+constexpr int kWideLds = kOffMisc + 64;               // 76,848 bytes: two workgroups per CU
+
+struct WideDims {
+    int S, M, Lq;
+    int h[4], w[4];     // host copy of the shapes
+    int start[4];       // first pixel of every level, from the host copy
+    int sh[4];          // log2 of the block side per level (footprint on the finest level <= 32 px)
+    int nbx[4];         // blocks per row of blocks
+    int first[5];       // first block of every level; first[4] = blocks per (batch item, head)
+    unsigned nblocks;
+    int dbg;            // timing experiments only (ALO_WIDE_DBG): 1 no flush, 2 no list walk, 4 no value rows, 8 no insert
+};
+
+template <typename T>
+struct Row4;   // four consecutive channels of a value / grad_out row -> fp32
+template <>
+struct Row4<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, elem_off == kDrop ? kDrop : elem_off * 4u, 0, 0);
+        return f32x4{__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
+    }
+    static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem_off == kDrop ? kDrop : elem_off * 4u, 0, 0));
+    }
+};
+template <>
+struct Row4<bf16_t> {
+    static __device__ __forceinline__ f32x4 widen(u32x2 x) {
+        return f32x4{__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xffff0000u), __uint_as_float(x.y << 16),
+                     __uint_as_float(x.y & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ f32x4 load(const bf16_t* p) { return widen(*reinterpret_cast<const u32x2*>(p)); }
+    static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
+        return widen(__builtin_amdgcn_raw_buffer_load_b64(r, elem_off == kDrop ? kDrop : elem_off * 2u, 0, 0));
+    }
+    static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
+        return bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, elem_off == kDrop ? kDrop : elem_off * 2u, 0, 0));
+    }
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dppc(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over aligned groups of 8 lanes, valid in every lane of the group
+__device__ __forceinline__ float sum8(float v) {
+    v += dppc<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dppc<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dppc<0x141>(v);   // row_half_mirror: lane i <-> 7 - i inside each half row
+    return v;
+}
+// sum over each 32-lane half; valid in lanes 16-31 / 48-63
+__device__ __forceinline__ float half_sum(float v) {
+    v += dppc<0x128>(v);
+    v += dppc<0x124>(v);
+    v += dppc<0x122>(v);
+    v += dppc<0x121>(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+    return v;
+}
+
+struct Tap {
+    int h_low, w_low;
+    float lh, lw;
+    unsigned flags;   // bit k: corner k inside the map; bit 4: the sample counts (cuh:285-291, :38-78)
+};
+__device__ __forceinline__ Tap make_tap_w(float x, float y, int Hl, int Wl, bool live) {
+    Tap t;
+    const float h_im = y * (float)Hl - 0.5f, w_im = x * (float)Wl - 0.5f;
+    const bool valid = live && (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
+    const float hs = valid ? h_im : 0.f, ws = valid ? w_im : 0.f;
+    const float hf = floorf(hs), wf = floorf(ws);
+    t.h_low = (int)hf;
+    t.w_low = (int)wf;
+    t.lh = hs - hf;
+    t.lw = ws - wf;
+    const bool hl = t.h_low >= 0, hh = t.h_low + 1 <= Hl - 1, wl = t.w_low >= 0, wh = t.w_low + 1 <= Wl - 1;
+    t.flags = valid ? ((hl && wl ? 1u : 0u) | (hl && wh ? 2u : 0u) | (hh && wl ? 4u : 0u) | (hh && wh ? 8u : 0u) | 16u) : 0u;
+    return t;
+}
+
+#define ALO_WAVE_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+template <typename T>
+__global__ void __launch_bounds__(kWThreads, 4)
+msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
+                     const float* __restrict__ loc, const float* __restrict__ attn, const T* __restrict__ grad_out,
+                     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
+                     const WideDims wd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* G = reinterpret_cast<float*>(smem + kOffG);
+    float* tbl = reinterpret_cast<float*>(smem + kOffTbl);
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem + kOffCnt);
+    unsigned short* list = reinterpret_cast<unsigned short*>(smem + kOffList);
+    unsigned* ovf = reinterpret_cast<unsigned*>(smem + kOffOvf);
+    unsigned short* items = reinterpret_cast<unsigned short*>(smem + kOffItems);
+    unsigned* wsum = reinterpret_cast<unsigned*>(smem + kOffMisc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = wd.M, S = wd.S, Lq = wd.Lq;
+    const unsigned lb = xcd_contiguous_block(blockIdx.x, wd.nblocks);
+    const int m = lb % M;
+    const int nblk = wd.first[4];
+    const int blk = (int)((lb / M) % nblk);
+    const int b = (int)(lb / ((unsigned)M * nblk));
+
+    // the device copy of the geometry must be the host's: the block table below was sized from the host's
+    bool same = true;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+        same = same && shapes[2 * l] == wd.h[l] && shapes[2 * l + 1] == wd.w[l] && lstart[l] == wd.start[l];
+    if (!same && blk * kSlots >= Lq) return;   // linear grouping: ceil(Lq / 256) blocks hold every query (block-uniform exit)
+
+    int ls = 0;
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+        if (blk >= wd.first[l]) ls = l;
+    const int shq = wd.sh[ls];
+    const int by = (blk - wd.first[ls]) / wd.nbx[ls], bx = (blk - wd.first[ls]) - by * wd.nbx[ls];
+    const int Hq = wd.h[ls], Wq = wd.w[ls], Sq = wd.start[ls];
+    auto query_of = [&](int slot) -> int {   // slot of the block -> query index, -1 when the slot is empty
+        if (same) {
+            const int qy = (by << shq) + (slot >> shq), qx = (bx << shq) + (slot & ((1 << shq) - 1));
+            return (slot < (1 << (2 * shq)) && qy < Hq && qx < Wq) ? Sq + qy * Wq + qx : -1;
+        }
+        const int q = blk * kSlots + slot;
+        return q < Lq ? q : -1;
+    };
+    const long bq0 = (long)b * Lq;
+
+    // ---- set-up: grad_out rows of the block, empty counters ----------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = (tid >> 3) + 64 * j, c4 = tid & 7;
+        const int q = query_of(slot);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (q >= 0 && !(wd.dbg & 32)) g = Row4<T>::load(grad_out + ((bq0 + q) * M + m) * 32 + 4 * c4);
+        *reinterpret_cast<f32x4*>(G + slot * 32 + 4 * c4) = g;
+    }
+    for (int r = tid; r < 3140; r += kWThreads) cnt[r] = 0;
+    if (tid < 128) ovf[tid] = same ? 0u : 0xffffffffu;
+
+    const int slot = tid >> 1, ph = tid & 1;   // neighbouring lanes hold the two point pairs of a query: 32 contiguous bytes of loc / grad_loc
+    const int q_own = query_of(slot);
+    const bool live = q_own >= 0;
+    const long qm = (bq0 + (live ? q_own : 0)) * M + m;
+
+    const size_t slab = (size_t)b * S * M * 32;
+    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(value + slab, (unsigned)((size_t)S * M * 32 * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t gv_rsrc = make_rsrc(grad_value + slab, (unsigned)((size_t)S * M * 128));
+    const unsigned head_elems = (unsigned)m * 32u, pix_elems = (unsigned)M * 32u;
+
+    // normalised centre of the block on its own level: the window of every level is a clip box around it
+    const float cxn = ((float)(bx << shq) + 0.5f * (float)(1 << shq)) / (float)Wq;
+    const float cyn = ((float)(by << shq) + 0.5f * (float)(1 << shq)) / (float)Hq;
+
+    f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
+    float a2[2] = {0.f, 0.f};
+    if (live && same && !(wd.dbg & 64)) {
+        l4 = *reinterpret_cast<const f32x4*>(loc + (qm * 4 + 0) * 8 + ph * 4);
+        const f32x2_t av = *reinterpret_cast<const f32x2_t*>(attn + (qm * 4 + 0) * 4 + ph * 2);
+        a2[0] = av[0];
+        a2[1] = av[1];
+    }
+    __syncthreads();
+
+    if (same) {
+        for (int lt = 0; lt < 4; ++lt) {
+            const int Hl = wd.h[lt], Wl = wd.w[lt], Sl = wd.start[lt];
+            // window: the block's footprint on this level + 13 px either side, at most 55 x 55
+            const int cxl = (int)floorf(cxn * (float)Wl), cyl = (int)floorf(cyn * (float)Hl);
+            const int fx = ((Wl << shq) + Wq - 1) / Wq, fy = ((Hl << shq) + Hq - 1) / Hq;
+            const int hx = min((fx >> 1) + 13, kClip / 2 - 1), hy = min((fy >> 1) + 13, kClip / 2 - 1);
+            const int wx0 = max(cxl - hx, 0), wx1 = min(cxl + hx, Wl - 1);
+            const int wy0 = max(cyl - hy, 0), wy1 = min(cyl + hy, Hl - 1);
+            const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+            const int rows = ww * wh;
+
+            // ---- 1. count: every in-window corner takes a slot in its row ---------------------------------------------------------
+            Tap t[2];
+            bool inwin[2];
+            unsigned rs[2][4];   // (row << 16) | slot of the corner in its row
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                t[j] = make_tap_w(l4[2 * j], l4[2 * j + 1], Hl, Wl, live);
+                if (wd.dbg & 8) t[j].flags = 0;
+                // every in-map corner inside the window?  (in-map corners have coordinates in [0, W-1] x [0, H-1])
+                const int xa = max(t[j].w_low, 0), xb = min(t[j].w_low + 1, Wl - 1);
+                const int ya = max(t[j].h_low, 0), yb = min(t[j].h_low + 1, Hl - 1);
+                inwin[j] = xa >= wx0 && xb <= wx1 && ya >= wy0 && yb <= wy1;
+                const int s = slot * 4 + ph * 2 + j;
+                if (t[j].flags & 16u) {
+                    if (inwin[j]) {
+                        const float hh = 1.f - t[j].lh, hw = 1.f - t[j].lw, at = a2[j];
+                        const float w4[4] = {hh * hw * at, hh * t[j].lw * at, t[j].lh * hw * at, t[j].lh * t[j].lw * at};
+                        const int base = (t[j].h_low - wy0) * ww + (t[j].w_low - wx0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if ((t[j].flags >> k) & 1u) {
+                                const int row = base + (k >> 1) * ww + (k & 1);
+                                const unsigned pos = __hip_atomic_fetch_add(&cnt[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                rs[j][k] = ((unsigned)row << 16) | pos;
+                            }
+                        *reinterpret_cast<f32x4*>(tbl + s * 4) = f32x4{w4[0], w4[1], w4[2], w4[3]};   // entries of out-of-map corners are never read
+                    } else {
+                        __hip_atomic_fetch_or(&ovf[lt * 32 + (s >> 5)], 1u << (s & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            // the next level's locations and weights travel while this level is sorted and gathered
+            f32x4 l4n = {0.f, 0.f, 0.f, 0.f};
+            float a2n[2] = {0.f, 0.f};
+            if (live && lt < 3 && !(wd.dbg & 64)) {
+                l4n = *reinterpret_cast<const f32x4*>(loc + (qm * 4 + lt + 1) * 8 + ph * 4);
+                const f32x2_t av = *reinterpret_cast<const f32x2_t*>(attn + (qm * 4 + lt + 1) * 4 + ph * 2);
+                a2n[0] = av[0];
+                a2n[1] = av[1];
+            }
+            __syncthreads();
+
+            // ---- 2. exclusive prefix sum of the counts, in place (cnt[rows] = number of entries), and the gather's work items: one per
+            //         32 entries of a row, so that no half wave is handed a long row alone -------------------------------------------------
+            {
+                const int per = (rows + kWThreads) / kWThreads;   // rows + 1 counters over 512 threads: at most 7 each
+                const int r0 = tid * per;
+                unsigned c7[7], sum = 0;   // low half: entries; high half: work items
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const int r = r0 + i;
+                    const unsigned n = (i < per && r < rows) ? cnt[r] : 0u;
+                    c7[i] = n | (min((n + 31u) >> 5, 16u) << 16);
+                    sum += c7[i];
+                }
+                unsigned incl = sum;
+                incl += (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+                incl += (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+                incl += (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+                incl += (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+                incl += (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+                incl += (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+                if (lane == 63) wsum[wave] = incl;
+                __syncthreads();
+                unsigned base = 0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) base += w < wave ? wsum[w] : 0u;
+                unsigned excl = base + incl - sum;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const int r = r0 + i;
+                    if (i < per && r <= rows) cnt[r] = excl & 0xffffu;
+                    const unsigned ni = c7[i] >> 16;
+                    for (unsigned sg = 0; sg < ni; ++sg) items[(excl >> 16) + sg] = (unsigned short)((unsigned)r | (sg << 12));
+                    excl += c7[i];
+                }
+                if (tid == kWThreads - 1) wsum[8] = excl >> 16;   // number of work items
+            }
+            __syncthreads();
+
+            // ---- 3. the sorted list ---------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if ((t[j].flags & 16u) && inwin[j]) {
+                    const int s = slot * 4 + ph * 2 + j;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((t[j].flags >> k) & 1u) list[cnt[rs[j][k] >> 16] + (rs[j][k] & 0xffffu)] = (unsigned short)(s * 4 + k);
+                }
+            __syncthreads();
+
+            // ---- 4. gather: a half wave per work item (a row, or 32 entries of a long row); its four 8-lane groups share the entries ------
+            {
+                const int hw = tid >> 5, g = (lane >> 3) & 3, c = lane & 7;
+                const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
+                const int n_items = (int)wsum[8];
+                auto item_of = [&](int k, int& first, int& len) -> unsigned {   // -> element offset of the row inside the slab, kDrop past the end
+                    first = 0;
+                    len = 0;
+                    if (k >= n_items) return kDrop;
+                    const unsigned it = items[k];
+                    const int row = (int)(it & 0xfffu), sg = (int)(it >> 12);
+                    const int o0 = (int)cnt[row] + sg * 32, o1 = (int)cnt[row + 1];
+                    first = o0;
+                    len = sg == 15 ? o1 - o0 : min(o1 - o0, 32);
+                    // (row + 0.5) / ww is at least 0.5 / ww away from an integer (ww <= 55): rcp's rounding cannot move its floor
+                    const int ry = (int)(((float)row + 0.5f) * inv_ww), rx = row - ry * ww;
+                    return (unsigned)(Sl + (wy0 + ry) * Wl + wx0 + rx) * pix_elems + head_elems;
+                };
+                int first, len;
+                unsigned eoff = item_of(hw, first, len);
+                f32x4 v = Row4<T>::load(v_rsrc, (eoff != kDrop && !(wd.dbg & 4)) ? eoff + 4u * c : kDrop);
+                for (int kb = hw & ~1; kb < n_items; kb += 16) {   // wave-uniform bound: the two halves' items are kb and kb + 1
+                    // the next item's value row travels while this one is walked
+                    int first_n, len_n;
+                    const unsigned eoff_n = item_of(kb + (hw & 1) + 16, first_n, len_n);
+                    const f32x4 v_n = Row4<T>::load(v_rsrc, (eoff_n != kDrop && !(wd.dbg & 4)) ? eoff_n + 4u * c : kDrop);
+                    if (wd.dbg & 2) len = 0;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const int other = __shfl_xor(len, 32, 64);
+                    const int steps = (max(len, other) + 3) >> 2;   // wave-uniform
+                    for (int s0 = 0; s0 < steps; s0 += 4) {
+                        unsigned e[4];
+                        bool ok[4];
+                        float w[4];
+                        f32x4 gq[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = (s0 + u) * 4 + g;
+                            ok[u] = i < len;
+                            e[u] = list[first + (ok[u] ? i : 0)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            w[u] = tbl[e[u]];
+                            gq[u] = *reinterpret_cast<const f32x4*>(G + (e[u] >> 4) * 32 + 4 * c);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc += (ok[u] ? w[u] : 0.f) * gq[u];
+                            float dp = v[0] * gq[u][0] + v[1] * gq[u][1] + v[2] * gq[u][2] + v[3] * gq[u][3];
+                            dp = sum8(dp);
+                            if (ok[u] && c == 0) tbl[e[u]] = dp;
+                        }
+                    }
+                    // reduce-scatter over the four groups: group g ends with the full sum of ONE of its four registers, so that the
+                    // 32 lanes of the half wave cover the row's 32 channels: ONE atomic row per work item
+                    const bool g1 = g & 1, g2 = g & 2;
+                    const float x0 = g1 ? acc[0] : acc[2], x1 = g1 ? acc[1] : acc[3];
+                    const float k0 = g1 ? acc[2] : acc[0], k1 = g1 ? acc[3] : acc[1];
+                    const float b0 = k0 + dppc<0x128>(x0), b1 = k1 + dppc<0x128>(x1);   // row_ror:8 = lane ^ 8 inside a 16-lane row
+                    const float x2 = g2 ? b0 : b1, k2 = g2 ? b1 : b0;
+                    const float tot = k2 + __shfl_xor(x2, 16, 64);
+                    const int reg = (g1 ? 2 : 0) + (g2 ? 1 : 0);   // which channel of its four the lane now holds
+                    const unsigned boff = (eoff != kDrop && !(wd.dbg & 1)) ? (eoff + 4u * c + reg) * 4u : kDrop;
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, gv_rsrc, boff, 0, 0);
+                    eoff = eoff_n;
+                    first = first_n;
+                    len = len_n;
+                    v = v_n;
+                }
+            }
+            __syncthreads();
+
+            // ---- 5. finish: the sample's owner combines its four d's; the counters are cleared for the next level -------------------------
+            if (live && !(wd.dbg & 16)) {
+                f32x4 gl = {0.f, 0.f, 0.f, 0.f};
+                f32x2_t ga = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int s = slot * 4 + ph * 2 + j;
+                    if ((t[j].flags & 16u) && inwin[j]) {   // (samples on the per-corner route are written again at the end, after this store)
+                        const f32x4 d4 = *reinterpret_cast<const f32x4*>(tbl + s * 4);
+                        float dk[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dk[k] = (t[j].flags >> k) & 1u ? d4[k] : 0.f;
+                        const float lh = t[j].lh, lw = t[j].lw, hh = 1.f - lh, hw = 1.f - lw;
+                        ga[j] = hh * hw * dk[0] + hh * lw * dk[1] + lh * hw * dk[2] + lh * lw * dk[3];
+                        const float gww = -hh * dk[0] + hh * dk[1] - lh * dk[2] + lh * dk[3];
+                        const float ghw = -hw * dk[0] - lw * dk[1] + hw * dk[2] + lw * dk[3];
+                        gl[2 * j] = (float)Wl * gww * a2[j];
+                        gl[2 * j + 1] = (float)Hl * ghw * a2[j];
+                    }
+                }
+                const long gidx = (qm * 4 + lt) * 4 + ph * 2;
+                *reinterpret_cast<f32x2_t*>(grad_attn + gidx) = ga;
+                *reinterpret_cast<f32x4*>(grad_loc + 2 * gidx) = gl;
+            }
+            for (int r = tid; r <= rows; r += kWThreads) cnt[r] = 0;
+            l4 = l4n;
+            a2[0] = a2n[0];
+            a2[1] = a2n[1];
+            __syncthreads();
+        }
+    }
+
+    // ---- 6. the per-corner route: one sample per half wave, one 128-byte row per corner (msda_bwd_kernel's way) ---------------------
+    {
+        const int ch = lane & 31, half = lane >> 5;
+        for (int wi = wave; wi < 128; wi += 8) {
+            unsigned word = ovf[wi];   // wave-uniform
+            word = __builtin_amdgcn_readfirstlane(word);
+            while (word) {
+                const int b0 = __builtin_ctz(word);
+                word &= word - 1;
+                int b1 = -1;
+                if (word) { b1 = __builtin_ctz(word); word &= word - 1; }
+                const int bit = half ? b1 : b0;
+                const int lv = wi >> 5, s = ((wi & 31) << 5) + bit, sl = s >> 2, p = s & 3;
+                const int q = bit >= 0 ? query_of(sl) : -1;
+                const int Hlv = shapes[2 * lv], Wlv = shapes[2 * lv + 1], Slv = lstart[lv];
+                float s_attn = 0.f, s_w = 0.f, s_h = 0.f;
+                long gidx = 0;
+                if (q >= 0) {
+                    gidx = (((bq0 + q) * M + m) * 4 + lv) * 4 + p;
+                    const float x = loc[2 * gidx], y = loc[2 * gidx + 1], at = attn[gidx];
+                    const Tap tp = make_tap_w(x, y, Hlv, Wlv, true);
+                    if (tp.flags & 16u) {
+                        const float top = G[sl * 32 + ch], tgv = top * at;
+                        const float lh = tp.lh, lw = tp.lw, hh = 1.f - lh, hw = 1.f - lw;
+                        const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                        const long pix0 = (long)Slv + (long)tp.h_low * Wlv + tp.w_low;
+                        const long px[4] = {pix0, pix0 + 1, pix0 + Wlv, pix0 + Wlv + 1};
+                        float v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[k] = Row4<T>::load1(v_rsrc, (tp.flags >> k) & 1u ? (unsigned)px[k] * pix_elems + head_elems + ch : kDrop);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                                w4[k] * tgv, gv_rsrc, (tp.flags >> k) & 1u ? ((unsigned)px[k] * pix_elems + head_elems + ch) * 4u : kDrop, 0, 0);
+                        s_attn = top * (w4[0] * v[0] + w4[1] * v[1] + w4[2] * v[2] + w4[3] * v[3]);
+                        s_w = tgv * (-hh * v[0] + hh * v[1] - lh * v[2] + lh * v[3]);
+                        s_h = tgv * (-hw * v[0] - lw * v[1] + hw * v[2] + lw * v[3]);
+                    }
+                }
+                s_attn = half_sum(s_attn);
+                s_w = half_sum(s_w);
+                s_h = half_sum(s_h);
+                if (ch == 16 && q >= 0) {
+                    grad_attn[gidx] = s_attn;
+                    grad_loc[2 * gidx] = (float)Wlv * s_w;
+                    grad_loc[2 * gidx + 1] = (float)Hlv * s_h;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Host side of the wide path.  Returns ALO_OK after enqueuing, or ALO_ERR_UNSUPPORTED (nothing enqueued) when the geometry is not
+// one the block table can describe — the caller then takes msda_bwd_tiled_kernel.
+int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* lstart, const void* loc, const void* attn,
+                       const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M, int Lq,
+                       int value_dtype, const int32_t* host_shapes, hipStream_t stream) {
+    if (!host_shapes || Lq != S) return ALO_ERR_UNSUPPORTED;
+    if (value_dtype != ALO_F32 && value_dtype != ALO_BF16) return ALO_ERR_UNSUPPORTED;
+    WideDims wd;
+    wd.S = S; wd.M = M; wd.Lq = Lq;
+    long total = 0;
+    int hmax = 1, wmax = 1;
+    for (int l = 0; l < 4; ++l) {
+        wd.h[l] = host_shapes[2 * l];
+        wd.w[l] = host_shapes[2 * l + 1];
+        if (wd.h[l] <= 0 || wd.w[l] <= 0 || wd.h[l] >= 32768 || wd.w[l] >= 32768) return ALO_ERR_UNSUPPORTED;
+        wd.start[l] = (int)total;
+        total += (long)wd.h[l] * wd.w[l];
+        hmax = wd.h[l] > hmax ? wd.h[l] : hmax;
+        wmax = wd.w[l] > wmax ? wd.w[l] : wmax;
+    }
+    if (total != S) return ALO_ERR_UNSUPPORTED;
+    int blocks = 0;
+    for (int l = 0; l < 4; ++l) {
+        // the block's footprint on the finest level stays within 32 px (5 % slack: 167 / 84, 100 / 13 are not powers of two)
+        const double r = std::max((double)hmax / wd.h[l], (double)wmax / wd.w[l]);
+        int sh = 4;
+        while (sh > 0 && (double)(1 << sh) * r > 32.0 * 1.05) --sh;
+        wd.sh[l] = sh;
+        const int bs = 1 << sh;
+        wd.nbx[l] = (wd.w[l] + bs - 1) / bs;
+        wd.first[l] = blocks;
+        blocks += wd.nbx[l] * ((wd.h[l] + bs - 1) / bs);
+    }
+    wd.first[4] = blocks;
+    if (blocks * kSlots < Lq) return ALO_ERR_UNSUPPORTED;   // cannot happen (a block holds at most 256 queries)
+    const long nb = (long)N * blocks * M;
+    if (nb >= 0x7fffffffL) return ALO_ERR_UNSUPPORTED;
+    wd.nblocks = (unsigned)nb;
+    wd.dbg = getenv("ALO_WIDE_DBG") ? atoi(getenv("ALO_WIDE_DBG")) : 0;
+    void* args[] = {&value, &shapes, &lstart, &loc, &attn, &grad_out, &grad_value, &grad_loc, &grad_attn, &wd};
+    const void* fn = value_dtype == ALO_F32 ? reinterpret_cast<const void*>(msda_bwd_wide_kernel<float>)
+                                            : reinterpret_cast<const void*>(msda_bwd_wide_kernel<bf16_t>);
+    static unsigned long long attr_done[2] = {0, 0};   // one bit per device
+    hipError_t ea = ensure_dynamic_lds(fn, kWideLds, &attr_done[value_dtype == ALO_F32 ? 0 : 1]);
+    if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward (wide): %s", hipGetErrorString(ea));
+    hipError_t el = hipLaunchKernel(fn, dim3(wd.nblocks), dim3(kWThreads), args, kWideLds, stream);
+    if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward (wide): %s", hipGetErrorString(el));
+    return check_launch("alo_msda_backward (wide)");
+}
+
+}  // namespace alo
