@@ -49,7 +49,7 @@ constexpr int kOffG = 0;                              // float  G[256][32]      
 constexpr int kOffTbl = kOffG + kSlots * 32 * 4;      // float  tbl[4096]       w * attn per corner entry, then d
 constexpr int kOffCnt = kOffTbl + 4096 * 4;           // u32    cnt[3140]       entries per window row, then their exclusive prefix sum
 constexpr int kOffList = kOffCnt + 3140 * 4;          // u16    list[4096]      entries sorted by window row
-constexpr int kOffOvf = kOffList + 4096 * 2;          // u32    ovf[128]        bit per (level, sample): takes the per-corner route
+constexpr int kOffOvf = kOffList + (4096 + 32) * 2;          // u32    ovf[128]        bit per (level, sample): takes the per-corner route
 constexpr int kOffItems = kOffOvf + 128 * 4;          // u16    items[3168]     work items of the gather: row | (32-entry segment << 12)
 constexpr int kOffMisc = kOffItems + 3168 * 2;        // u32    wsum[8], total  wave totals of the prefix sum
 constexpr int kWideLds = kOffMisc + 64;               // 76,848 bytes: two workgroups per CU
@@ -77,6 +77,10 @@ struct Row4<float> {
     static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem_off == kDrop ? kDrop : elem_off * 4u, 0, 0));
     }
+    static __device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t r, unsigned elem_off, f32x4& lo, f32x4& hi) {   // eight channels
+        lo = load(r, elem_off);
+        hi = load(r, elem_off == kDrop ? kDrop : elem_off + 4u);
+    }
 };
 template <>
 struct Row4<bf16_t> {
@@ -90,6 +94,11 @@ struct Row4<bf16_t> {
     }
     static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
         return bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, elem_off == kDrop ? kDrop : elem_off * 2u, 0, 0));
+    }
+    static __device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t r, unsigned elem_off, f32x4& lo, f32x4& hi) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, elem_off == kDrop ? kDrop : elem_off * 2u, 0, 0);
+        lo = widen(u32x2{x.x, x.y});
+        hi = widen(u32x2{x.z, x.w});
     }
 };
 
@@ -322,9 +331,9 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 }
             __syncthreads();
 
-            // ---- 4. gather: a half wave per work item (a row, or 32 entries of a long row); its four 8-lane groups share the entries ------
+            // ---- 4. gather: a half wave per work item (a row, or 32 entries of a long row); 4 lanes x 8 channels per entry, 8 entries a step ----
             {
-                const int hw = tid >> 5, g = (lane >> 3) & 3, c = lane & 7;
+                const int hw = tid >> 5, g = (lane >> 2) & 7, c = lane & 3;
                 const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
                 const int n_items = (int)wsum[8];
                 auto item_of = [&](int k, int& first, int& len) -> unsigned {   // -> element offset of the row inside the slab, kDrop past the end
@@ -342,55 +351,74 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 };
                 int first, len;
                 unsigned eoff = item_of(hw, first, len);
-                f32x4 v = Row4<T>::load(v_rsrc, (eoff != kDrop && !(wd.dbg & 4)) ? eoff + 4u * c : kDrop);
+                f32x4 v0, v1;
+                Row4<T>::load8(v_rsrc, (eoff != kDrop && !(wd.dbg & 4)) ? eoff + 8u * c : kDrop, v0, v1);
+                const float* Gc = G + 8 * c;
                 for (int kb = hw & ~1; kb < n_items; kb += 16) {   // wave-uniform bound: the two halves' items are kb and kb + 1
                     // the next item's value row travels while this one is walked
                     int first_n, len_n;
                     const unsigned eoff_n = item_of(kb + (hw & 1) + 16, first_n, len_n);
-                    const f32x4 v_n = Row4<T>::load(v_rsrc, (eoff_n != kDrop && !(wd.dbg & 4)) ? eoff_n + 4u * c : kDrop);
+                    f32x4 vn0, vn1;
+                    Row4<T>::load8(v_rsrc, (eoff_n != kDrop && !(wd.dbg & 4)) ? eoff_n + 8u * c : kDrop, vn0, vn1);
                     if (wd.dbg & 2) len = 0;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
                     const int other = __shfl_xor(len, 32, 64);
-                    const int steps = (max(len, other) + 3) >> 2;   // wave-uniform
-                    for (int s0 = 0; s0 < steps; s0 += 4) {
-                        unsigned e[4];
-                        bool ok[4];
-                        float w[4];
-                        f32x4 gq[4];
+                    const int steps = (max(len, other) + 7) >> 3;   // wave-uniform
+                    for (int s0 = 0; s0 < steps; s0 += 2) {
+                        unsigned e[2];
+                        bool ok[2];
+                        float w[2];
+                        f32x4 g0[2], g1[2];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = (s0 + u) * 4 + g;
+                        for (int u = 0; u < 2; ++u) {
+                            const int i = (s0 + u) * 8 + g;
                             ok[u] = i < len;
-                            e[u] = list[first + (ok[u] ? i : 0)];
+                            e[u] = list[first + i];   // (past the item's end: some other entry, or the pad behind the list — weight forced to 0)
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            w[u] = tbl[e[u]];
-                            gq[u] = *reinterpret_cast<const f32x4*>(G + (e[u] >> 4) * 32 + 4 * c);
+                        for (int u = 0; u < 2; ++u) {
+                            w[u] = tbl[e[u] & 4095u];
+                            const float* gp = Gc + ((e[u] >> 4) & 255u) * 32;
+                            g0[u] = *reinterpret_cast<const f32x4*>(gp);
+                            g1[u] = *reinterpret_cast<const f32x4*>(gp + 4);
                         }
+                        float dp[2];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            acc += (ok[u] ? w[u] : 0.f) * gq[u];
-                            float dp = v[0] * gq[u][0] + v[1] * gq[u][1] + v[2] * gq[u][2] + v[3] * gq[u][3];
-                            dp = sum8(dp);
-                            if (ok[u] && c == 0) tbl[e[u]] = dp;
+                        for (int u = 0; u < 2; ++u) {
+                            const float wu = ok[u] ? w[u] : 0.f;
+                            a0 += wu * g0[u];
+                            a1 += wu * g1[u];
+                            const f32x4 pr = v0 * g0[u] + v1 * g1[u];
+                            float d = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+                            d += dppc<0xB1>(d);    // quad_perm [1,0,3,2]
+                            d += dppc<0x4E>(d);    // quad_perm [2,3,0,1]
+                            dp[u] = d;
+                        }
+                        if (c == 0) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                if (ok[u]) tbl[e[u]] = dp[u];
                         }
                     }
-                    // reduce-scatter over the four groups: group g ends with the full sum of ONE of its four registers, so that the
-                    // 32 lanes of the half wave cover the row's 32 channels: ONE atomic row per work item
-                    const bool g1 = g & 1, g2 = g & 2;
-                    const float x0 = g1 ? acc[0] : acc[2], x1 = g1 ? acc[1] : acc[3];
-                    const float k0 = g1 ? acc[2] : acc[0], k1 = g1 ? acc[3] : acc[1];
-                    const float b0 = k0 + dppc<0x128>(x0), b1 = k1 + dppc<0x128>(x1);   // row_ror:8 = lane ^ 8 inside a 16-lane row
-                    const float x2 = g2 ? b0 : b1, k2 = g2 ? b1 : b0;
-                    const float tot = k2 + __shfl_xor(x2, 16, 64);
-                    const int reg = (g1 ? 2 : 0) + (g2 ? 1 : 0);   // which channel of its four the lane now holds
-                    const unsigned boff = (eoff != kDrop && !(wd.dbg & 1)) ? (eoff + 4u * c + reg) * 4u : kDrop;
+                    // reduce-scatter over the eight groups: every lane ends with the full sum of ONE of its eight channels, the 32 lanes of
+                    // the half wave cover the row's 32 channels: ONE atomic row per work item
+                    const bool t1 = g & 1, t2 = g & 2, t4 = g & 4;
+                    const f32x4 keep1 = t1 ? a1 : a0, send1 = t1 ? a0 : a1;
+                    f32x4 r1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r1[i] = keep1[i] + dppc<0x1B>(dppc<0x141>(send1[i]));   // half mirror, then reversed quads: lane ^ 4
+                    const float k2a = t2 ? r1[2] : r1[0], k2b = t2 ? r1[3] : r1[1], s2a = t2 ? r1[0] : r1[2], s2b = t2 ? r1[1] : r1[3];
+                    const float r2a = k2a + dppc<0x128>(s2a), r2b = k2b + dppc<0x128>(s2b);              // row_ror:8 = lane ^ 8 inside a 16-lane row
+                    const float k3 = t4 ? r2b : r2a, s3 = t4 ? r2a : r2b;
+                    const float tot = k3 + __shfl_xor(s3, 16, 64);
+                    const int reg = (t1 ? 4 : 0) + (t2 ? 2 : 0) + (t4 ? 1 : 0);   // which channel of its eight the lane now holds
+                    const unsigned boff = (eoff != kDrop && !(wd.dbg & 1)) ? (eoff + 8u * c + reg) * 4u : kDrop;
                     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, gv_rsrc, boff, 0, 0);
                     eoff = eoff_n;
                     first = first_n;
                     len = len_n;
-                    v = v_n;
+                    v0 = vn0;
+                    v1 = vn1;
                 }
             }
             __syncthreads();
