@@ -30,6 +30,7 @@
 // sample down the per-corner route with the queries grouped 256 in a row (correct, slow — the Python host never caches shapes).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -47,8 +48,9 @@ constexpr unsigned kDrop = 0xffffff00u;  // a byte offset past any frame slab: t
 
 constexpr int kOffG = 0;                              // float  G[256][32]      grad_out rows of the block's queries
 constexpr int kOffTbl = kOffG + kSlots * 32 * 4;      // float  tbl[4096]       w * attn per corner entry, then d
-constexpr int kOffCnt = kOffTbl + 4096 * 4;           // u32    cnt[3140]       entries per window row, then their exclusive prefix sum
-constexpr int kOffList = kOffCnt + 3140 * 4;          // u16    list[4096]      entries sorted by window row
+constexpr int kCnt = 55 * 64 + 8;                     // window rows are numbered 64 * y + x (y, x < 55): no division on the way back
+constexpr int kOffCnt = kOffTbl + 4096 * 4;           // u32    cnt[kCnt]       entries per window row, then their exclusive prefix sum
+constexpr int kOffList = kOffCnt + kCnt * 4;          // u16    list[4096]      entries sorted by window row
 constexpr int kOffOvf = kOffList + (4096 + 32) * 2;          // u32    ovf[128]        bit per (level, sample): takes the per-corner route
 constexpr int kOffItems = kOffOvf + 128 * 4;          // u16    items[3168]     work items of the gather: row | (32-entry segment << 12)
 constexpr int kOffMisc = kOffItems + 3168 * 2;        // u32    wsum[8], total  wave totals of the prefix sum
@@ -77,9 +79,11 @@ struct Row4<float> {
     static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem_off == kDrop ? kDrop : elem_off * 4u, 0, 0));
     }
-    static __device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t r, unsigned elem_off, f32x4& lo, f32x4& hi) {   // eight channels
-        lo = load(r, elem_off);
-        hi = load(r, elem_off == kDrop ? kDrop : elem_off + 4u);
+    // eight channels at a BYTE offset (kDrop, and kDrop + 16, are past the slab: zeros)
+    static __device__ __forceinline__ void load8b(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4& lo, f32x4& hi) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0), y = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u, 0, 0);
+        lo = f32x4{__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
+        hi = f32x4{__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(y.z), __uint_as_float(y.w)};
     }
 };
 template <>
@@ -95,8 +99,8 @@ struct Row4<bf16_t> {
     static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
         return bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, elem_off == kDrop ? kDrop : elem_off * 2u, 0, 0));
     }
-    static __device__ __forceinline__ void load8(__amdgpu_buffer_rsrc_t r, unsigned elem_off, f32x4& lo, f32x4& hi) {
-        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, elem_off == kDrop ? kDrop : elem_off * 2u, 0, 0);
+    static __device__ __forceinline__ void load8b(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4& lo, f32x4& hi) {
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
         lo = widen(u32x2{x.x, x.y});
         hi = widen(u32x2{x.z, x.w});
     }
@@ -201,8 +205,11 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
         if (q >= 0 && !(wd.dbg & 32)) g = Row4<T>::load(grad_out + ((bq0 + q) * M + m) * 32 + 4 * c4);
         *reinterpret_cast<f32x4*>(G + slot * 32 + 4 * c4) = g;
     }
-    for (int r = tid; r < 3140; r += kWThreads) cnt[r] = 0;
+    for (int r = tid; r < kCnt; r += kWThreads) cnt[r] = 0;
     if (tid < 128) ovf[tid] = same ? 0u : 0xffffffffu;
+    // the walk reads up to 15 entries past an item's end: every list slot always holds a valid entry number (weights are masked, the
+    // grad_out row it names is finite)
+    for (int i = tid; i < (4096 + 32) / 2; i += kWThreads) reinterpret_cast<unsigned*>(list)[i] = 0;
 
     const int slot = tid >> 1, ph = tid & 1;   // neighbouring lanes hold the two point pairs of a query: 32 contiguous bytes of loc / grad_loc
     const int q_own = query_of(slot);
@@ -238,7 +245,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
             const int wx0 = max(cxl - hx, 0), wx1 = min(cxl + hx, Wl - 1);
             const int wy0 = max(cyl - hy, 0), wy1 = min(cyl + hy, Hl - 1);
             const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
-            const int rows = ww * wh;
+            const int rows = wh * 64;   // row numbers in use: 64 * y + x, x < ww <= 55
 
             // ---- 1. count: every in-window corner takes a slot in its row ---------------------------------------------------------
             Tap t[2];
@@ -257,11 +264,11 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     if (inwin[j]) {
                         const float hh = 1.f - t[j].lh, hw = 1.f - t[j].lw, at = a2[j];
                         const float w4[4] = {hh * hw * at, hh * t[j].lw * at, t[j].lh * hw * at, t[j].lh * t[j].lw * at};
-                        const int base = (t[j].h_low - wy0) * ww + (t[j].w_low - wx0);
+                        const int base = (t[j].h_low - wy0) * 64 + (t[j].w_low - wx0);
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if ((t[j].flags >> k) & 1u) {
-                                const int row = base + (k >> 1) * ww + (k & 1);
+                                const int row = base + (k >> 1) * 64 + (k & 1);
                                 const unsigned pos = __hip_atomic_fetch_add(&cnt[row], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 rs[j][k] = ((unsigned)row << 16) | pos;
                             }
@@ -334,57 +341,61 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
             // ---- 4. gather: a half wave per work item (a row, or 32 entries of a long row); 4 lanes x 8 channels per entry, 8 entries a step ----
             {
                 const int hw = tid >> 5, g = (lane >> 2) & 7, c = lane & 3;
-                const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
-                const int n_items = (int)wsum[8];
-                auto item_of = [&](int k, int& first, int& len) -> unsigned {   // -> element offset of the row inside the slab, kDrop past the end
-                    first = 0;
-                    len = 0;
+                const int n_items = (wd.dbg & 128) ? 0 : (int)wsum[8];
+                const unsigned lane_b = (head_elems + 8u * c) * (unsigned)sizeof(T);   // byte offset of the lane's 8 channels inside a pixel
+                const unsigned pix_b = pix_elems * (unsigned)sizeof(T);
+                const unsigned base_pix = (unsigned)(Sl + wy0 * Wl + wx0);
+                // item k -> byte offset of (row's pixel, this lane's channels) in `value`; first entry and entry count in `fl`
+                auto item_of = [&](int k, unsigned& fl) -> unsigned {
+                    fl = 0;
                     if (k >= n_items) return kDrop;
                     const unsigned it = items[k];
-                    const int row = (int)(it & 0xfffu), sg = (int)(it >> 12);
-                    const int o0 = (int)cnt[row] + sg * 32, o1 = (int)cnt[row + 1];
-                    first = o0;
-                    len = sg == 15 ? o1 - o0 : min(o1 - o0, 32);
-                    // (row + 0.5) / ww is at least 0.5 / ww away from an integer (ww <= 55): rcp's rounding cannot move its floor
-                    const int ry = (int)(((float)row + 0.5f) * inv_ww), rx = row - ry * ww;
-                    return (unsigned)(Sl + (wy0 + ry) * Wl + wx0 + rx) * pix_elems + head_elems;
+                    const unsigned row = it & 0xfffu, sg = it >> 12;
+                    const unsigned o0 = cnt[row] + sg * 32u, o1 = cnt[row + 1];
+                    const unsigned len = sg == 15u ? o1 - o0 : min(o1 - o0, 32u);
+                    fl = o0 | (len << 16);
+                    const unsigned pix = base_pix + __umul24(row >> 6, (unsigned)Wl) + (row & 63u);
+                    return __umul24(pix, pix_b) + lane_b;
                 };
-                int first, len;
-                unsigned eoff = item_of(hw, first, len);
+                unsigned fl;
+                unsigned voff = item_of(hw, fl);
                 f32x4 v0, v1;
-                Row4<T>::load8(v_rsrc, (eoff != kDrop && !(wd.dbg & 4)) ? eoff + 8u * c : kDrop, v0, v1);
+                Row4<T>::load8b(v_rsrc, (wd.dbg & 4) ? kDrop : voff, v0, v1);
                 const float* Gc = G + 8 * c;
+                const bool t1 = g & 1, t2 = g & 2, t4 = g & 4;
+                const unsigned reg_b = ((t1 ? 4u : 0u) + (t2 ? 2u : 0u) + (t4 ? 1u : 0u)) * 4u;   // the channel (of the lane's eight) it flushes
                 for (int kb = hw & ~1; kb < n_items; kb += 16) {   // wave-uniform bound: the two halves' items are kb and kb + 1
                     // the next item's value row travels while this one is walked
-                    int first_n, len_n;
-                    const unsigned eoff_n = item_of(kb + (hw & 1) + 16, first_n, len_n);
+                    unsigned fl_n;
+                    const unsigned voff_n = item_of(kb + (hw & 1) + 16, fl_n);
                     f32x4 vn0, vn1;
-                    Row4<T>::load8(v_rsrc, (eoff_n != kDrop && !(wd.dbg & 4)) ? eoff_n + 8u * c : kDrop, vn0, vn1);
-                    if (wd.dbg & 2) len = 0;
+                    Row4<T>::load8b(v_rsrc, (wd.dbg & 4) ? kDrop : voff_n, vn0, vn1);
+                    const int first = (int)(fl & 0xffffu), len = (wd.dbg & 2) ? 0 : (int)(fl >> 16);
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                    const int other = __shfl_xor(len, 32, 64);
-                    const int steps = (max(len, other) + 7) >> 3;   // wave-uniform
-                    for (int s0 = 0; s0 < steps; s0 += 2) {
-                        unsigned e[2];
-                        bool ok[2];
-                        float w[2];
-                        f32x4 g0[2], g1[2];
+                    const int steps = (max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32)) + 7) >> 3;
+                    // (entries past the item's end are other entries, or the zeroed pad behind the list: their weight is forced to 0)
+                    auto walk = [&](int s0, auto nsteps) {
+                        constexpr int NS = decltype(nsteps)::value;
+                        unsigned e[NS];
+                        bool ok[NS];
+                        float w[NS];
+                        f32x4 g0[NS], g1[NS];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < NS; ++u) {
                             const int i = (s0 + u) * 8 + g;
                             ok[u] = i < len;
-                            e[u] = list[first + i];   // (past the item's end: some other entry, or the pad behind the list — weight forced to 0)
+                            e[u] = list[first + i];
                         }
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            w[u] = tbl[e[u] & 4095u];
-                            const float* gp = Gc + ((e[u] >> 4) & 255u) * 32;
+                        for (int u = 0; u < NS; ++u) {
+                            w[u] = tbl[e[u]];
+                            const float* gp = Gc + (e[u] >> 4) * 32;
                             g0[u] = *reinterpret_cast<const f32x4*>(gp);
                             g1[u] = *reinterpret_cast<const f32x4*>(gp + 4);
                         }
-                        float dp[2];
+                        float dp[NS];
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < NS; ++u) {
                             const float wu = ok[u] ? w[u] : 0.f;
                             a0 += wu * g0[u];
                             a1 += wu * g1[u];
@@ -396,27 +407,32 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                         }
                         if (c == 0) {
 #pragma unroll
-                            for (int u = 0; u < 2; ++u)
+                            for (int u = 0; u < NS; ++u)
                                 if (ok[u]) tbl[e[u]] = dp[u];
                         }
+                    };
+                    if (steps == 1) {   // most rows of the fine levels: at most 8 entries
+                        walk(0, std::integral_constant<int, 1>{});
+                    } else {
+                        for (int s0 = 0; s0 < steps; s0 += 2) walk(s0, std::integral_constant<int, 2>{});
                     }
                     // reduce-scatter over the eight groups: every lane ends with the full sum of ONE of its eight channels, the 32 lanes of
-                    // the half wave cover the row's 32 channels: ONE atomic row per work item
-                    const bool t1 = g & 1, t2 = g & 2, t4 = g & 4;
+                    // the half wave cover the row's 32 channels: ONE atomic row per work item.  Lane ^ 4 and lane ^ 16 travel on the LDS
+                    // crossbar (ds_swizzle: no memory, no address register), lane ^ 8 on DPP.
                     const f32x4 keep1 = t1 ? a1 : a0, send1 = t1 ? a0 : a1;
                     f32x4 r1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) r1[i] = keep1[i] + dppc<0x1B>(dppc<0x141>(send1[i]));   // half mirror, then reversed quads: lane ^ 4
+                    for (int i = 0; i < 4; ++i)
+                        r1[i] = keep1[i] + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send1[i]), 0x101F));   // xor 4
                     const float k2a = t2 ? r1[2] : r1[0], k2b = t2 ? r1[3] : r1[1], s2a = t2 ? r1[0] : r1[2], s2b = t2 ? r1[1] : r1[3];
                     const float r2a = k2a + dppc<0x128>(s2a), r2b = k2b + dppc<0x128>(s2b);              // row_ror:8 = lane ^ 8 inside a 16-lane row
                     const float k3 = t4 ? r2b : r2a, s3 = t4 ? r2a : r2b;
-                    const float tot = k3 + __shfl_xor(s3, 16, 64);
-                    const int reg = (t1 ? 4 : 0) + (t2 ? 2 : 0) + (t4 ? 1 : 0);   // which channel of its eight the lane now holds
-                    const unsigned boff = (eoff != kDrop && !(wd.dbg & 1)) ? (eoff + 8u * c + reg) * 4u : kDrop;
+                    const float tot = k3 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s3), 0x401F));   // xor 16
+                    // value is T, grad_value fp32: the same pixel and channels are at byte offset (voff / sizeof(T)) * 4
+                    const unsigned boff = (voff == kDrop || (wd.dbg & 1)) ? kDrop : voff * (4u / (unsigned)sizeof(T)) + reg_b;
                     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, gv_rsrc, boff, 0, 0);
-                    eoff = eoff_n;
-                    first = first_n;
-                    len = len_n;
+                    voff = voff_n;
+                    fl = fl_n;
                     v0 = vn0;
                     v1 = vn1;
                 }

@@ -690,8 +690,10 @@ def test_tiled_backward_survives_a_host_hint_that_disagrees_with_the_device_shap
         torch.cuda.synchronize()
         outs.append((gv, gl, ga))
     assert torch.isfinite(outs[1][1]).all() and torch.isfinite(outs[1][2]).all()   # every query was served
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
-    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-4 * outs[0][0].abs().max().item()   # atomics: order-dependent bits
+    # the wide path (msda_bwd_wide.hip) answers a disagreeing hint by sending every sample down the per-corner route: the same sums
+    # in another order, so the comparison is to fp32 rounding, not to the bit
+    for i in (0, 1, 2):
+        assert (outs[0][i] - outs[1][i]).abs().max().item() <= 1e-5 * max(1.0, outs[0][i].abs().max().item())
 
 
 def test_tiled_backward_with_a_host_hint_that_under_counts_the_device_tiles():
