@@ -57,7 +57,7 @@ constexpr int kOffMisc = kOffItems + 3168 * 2;        // u32    wsum[8], total  
 constexpr int kWideLds = kOffMisc + 64;               // 76,848 bytes: two workgroups per CU
 
 struct WideDims {
-    int S, M, Lq;
+    int N, S, M, Lq;
     int h[4], w[4];     // host copy of the shapes
     int start[4];       // first pixel of every level, from the host copy
     int sh[4];          // log2 of the block side per level (footprint on the finest level <= 32 px)
@@ -166,11 +166,13 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = wd.M, S = wd.S, Lq = wd.Lq;
-    const unsigned lb = xcd_contiguous_block(blockIdx.x, wd.nblocks);
+    // launch order: head fastest (block i runs on XCD i % 8: with M = 8 every XCD serves one head), then the batch item, then the
+    // block — the full 16x16 blocks of the finest level of EVERY item first, the small blocks of the coarse levels fill the tail
+    const unsigned lb = blockIdx.x;
     const int m = lb % M;
     const int nblk = wd.first[4];
-    const int blk = (int)((lb / M) % nblk);
-    const int b = (int)(lb / ((unsigned)M * nblk));
+    const int b = (int)((lb / M) % (unsigned)wd.N);
+    const int blk = (int)(lb / ((unsigned)M * wd.N));
 
     // the device copy of the geometry must be the host's: the block table below was sized from the host's
     bool same = true;
@@ -534,7 +536,7 @@ int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* 
     if (!host_shapes || Lq != S) return ALO_ERR_UNSUPPORTED;
     if (value_dtype != ALO_F32 && value_dtype != ALO_BF16) return ALO_ERR_UNSUPPORTED;
     WideDims wd;
-    wd.S = S; wd.M = M; wd.Lq = Lq;
+    wd.N = N; wd.S = S; wd.M = M; wd.Lq = Lq;
     long total = 0;
     int hmax = 1, wmax = 1;
     for (int l = 0; l < 4; ++l) {
