@@ -164,6 +164,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
     unsigned short* items = reinterpret_cast<unsigned short*>(smem + kOffItems);
     unsigned* wsum = reinterpret_cast<unsigned*>(smem + kOffMisc);
 
+    if (wd.dbg & 256) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = wd.M, S = wd.S, Lq = wd.Lq;
     // launch order: head fastest (block i runs on XCD i % 8: with M = 8 every XCD serves one head), then the batch item, then the
@@ -237,6 +238,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
     }
     __syncthreads();
 
+    if (wd.dbg & 512) return;
     if (same) {
         for (int lt = 0; lt < 4; ++lt) {
             const int Hl = wd.h[lt], Wl = wd.w[lt], Sl = wd.start[lt];
@@ -293,7 +295,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 
             // ---- 2. exclusive prefix sum of the counts, in place (cnt[rows] = number of entries), and the gather's work items: one per
             //         32 entries of a row, so that no half wave is handed a long row alone -------------------------------------------------
-            {
+            if (!(wd.dbg & 1024)) {
                 const int per = (rows + kWThreads) / kWThreads;   // rows + 1 counters over 512 threads: at most 7 each
                 const int r0 = tid * per;
                 unsigned c7[7], sum = 0;   // low half: entries; high half: work items
@@ -301,7 +303,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 for (int i = 0; i < 7; ++i) {
                     const int r = r0 + i;
                     const unsigned n = (i < per && r < rows) ? cnt[r] : 0u;
-                    c7[i] = n | (min((n + 31u) >> 5, 16u) << 16);
+                    c7[i] = n | (min((n + 31u) >> 5, 4u) << 16);
                     sum += c7[i];
                 }
                 unsigned incl = sum;
@@ -321,8 +323,13 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 for (int i = 0; i < 7; ++i) {
                     const int r = r0 + i;
                     if (i < per && r <= rows) cnt[r] = excl & 0xffffu;
-                    const unsigned ni = c7[i] >> 16;
-                    for (unsigned sg = 0; sg < ni; ++sg) items[(excl >> 16) + sg] = (unsigned short)((unsigned)r | (sg << 12));
+                    const unsigned ni = c7[i] >> 16, ib = excl >> 16;
+                    if (ni) items[ib] = (unsigned short)r;
+                    if (ni > 1) {   // long rows (coarse levels): up to three more segments, the last one takes whatever is left
+                        items[ib + 1] = (unsigned short)(r | 0x1000);
+                        if (ni > 2) items[ib + 2] = (unsigned short)(r | 0x2000);
+                        if (ni > 3) items[ib + 3] = (unsigned short)(r | 0x3000);
+                    }
                     excl += c7[i];
                 }
                 if (tid == kWThreads - 1) wsum[8] = excl >> 16;   // number of work items
@@ -354,7 +361,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     const unsigned it = items[k];
                     const unsigned row = it & 0xfffu, sg = it >> 12;
                     const unsigned o0 = cnt[row] + sg * 32u, o1 = cnt[row + 1];
-                    const unsigned len = sg == 15u ? o1 - o0 : min(o1 - o0, 32u);
+                    const unsigned len = sg == 3u ? o1 - o0 : min(o1 - o0, 32u);
                     fl = o0 | (len << 16);
                     const unsigned pix = base_pix + __umul24(row >> 6, (unsigned)Wl) + (row & 63u);
                     return __umul24(pix, pix_b) + lane_b;
@@ -465,7 +472,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 *reinterpret_cast<f32x2_t*>(grad_attn + gidx) = ga;
                 *reinterpret_cast<f32x4*>(grad_loc + 2 * gidx) = gl;
             }
-            for (int r = tid; r <= rows; r += kWThreads) cnt[r] = 0;
+            if (!(wd.dbg & 2048)) for (int r = tid; r <= rows; r += kWThreads) cnt[r] = 0;
             l4 = l4n;
             a2[0] = a2n[0];
             a2[1] = a2n[1];
