@@ -60,6 +60,8 @@ def _declare(lib):
     lib.alo_msda_backward.argtypes = [vp] * 9 + [ip] * 9 + [vp]
     lib.alo_msda_backward_hinted.restype = ip
     lib.alo_msda_backward_hinted.argtypes = [vp] * 9 + [ip] * 9 + [c.POINTER(c.c_int32), vp]
+    lib.alo_msda_backward_path.restype = ip
+    lib.alo_msda_backward_path.argtypes = [ip] * 9 + [c.POINTER(c.c_int32)]
     lib.alo_corr_level_shape.restype = None
     lib.alo_corr_level_shape.argtypes = [ip, ip, ip, c.POINTER(ip), c.POINTER(ip)]
     lib.alo_corr_build_workspace_bytes.restype = sz
@@ -144,8 +146,8 @@ def lib():
         except OSError as e:  # pragma: no cover - depends on the box
             raise HotpathUnavailable(f"cannot load {LIB_PATH}: {e}") from e
         _declare(handle)
-        if handle.alo_abi_version() != 1:
-            raise HotpathUnavailable(f"{LIB_PATH} has ABI version {handle.alo_abi_version()}, expected 1")
+        if handle.alo_abi_version() != 2:
+            raise HotpathUnavailable(f"{LIB_PATH} has ABI version {handle.alo_abi_version()}, expected 2")
         _lib = handle
     return _lib
 

@@ -1966,3 +1966,20 @@ extern "C" int alo_msda_backward_hinted(const void* value, const int32_t* spatia
                          grad_sampling_loc, grad_attn_weight, N, S, M, D, L, Lq, P, value_dtype, loc_dtype,
                          host_spatial_shapes, stream_);
 }
+
+// Which kernel alo_msda_backward[_hinted] takes for a launch of these dimensions (16-byte aligned pointers assumed): the answer the
+// dispatch in backward_impl gives, without enqueuing anything.
+extern "C" int alo_msda_backward_path(int N, int S, int M, int D, int L, int Lq, int P, int value_dtype, int loc_dtype,
+                                      const int32_t* host_spatial_shapes) {
+    const bool pair_ok = (value_dtype == ALO_F32 && loc_dtype == ALO_F32) || (value_dtype == ALO_F64 && loc_dtype == ALO_F64) ||
+                         (value_dtype == ALO_BF16 && loc_dtype == ALO_F32);
+    if (!pair_ok || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return -1;
+    const bool frame32 = (double)S * M * 128 < 4.0e9 && (double)Lq * M * 32 < 2.0e9;
+    if ((value_dtype == ALO_F32 || value_dtype == ALO_BF16) && D == 32 && L == 4 && P == 4 && frame32 && host_spatial_shapes && Lq == S &&
+        bwd_policy() != 1 &&
+        msda_backward_wide(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, S, M, Lq, value_dtype,
+                           host_spatial_shapes, nullptr, true) == ALO_OK)
+        return ALO_MSDA_BWD_WIDE;
+    if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && frame32) return ALO_MSDA_BWD_TILED;
+    return ALO_MSDA_BWD_GENERIC;
+}

@@ -539,9 +539,10 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 // one the block table can describe — the caller then takes msda_bwd_tiled_kernel.
 int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* lstart, const void* loc, const void* attn,
                        const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M, int Lq,
-                       int value_dtype, const int32_t* host_shapes, hipStream_t stream) {
+                       int value_dtype, const int32_t* host_shapes, hipStream_t stream, bool plan_only) {
     if (!host_shapes || Lq != S) return ALO_ERR_UNSUPPORTED;
     if (value_dtype != ALO_F32 && value_dtype != ALO_BF16) return ALO_ERR_UNSUPPORTED;
+    if (S >= (1 << 24) || M >= (1 << 16)) return ALO_ERR_UNSUPPORTED;   // 24-bit multiplies in the gather's address arithmetic
     WideDims wd;
     wd.N = N; wd.S = S; wd.M = M; wd.Lq = Lq;
     long total = 0;
@@ -573,6 +574,7 @@ int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* 
     const long nb = (long)N * blocks * M;
     if (nb >= 0x7fffffffL) return ALO_ERR_UNSUPPORTED;
     wd.nblocks = (unsigned)nb;
+    if (plan_only) return ALO_OK;
     wd.dbg = getenv("ALO_WIDE_DBG") ? atoi(getenv("ALO_WIDE_DBG")) : 0;
     void* args[] = {&value, &shapes, &lstart, &loc, &attn, &grad_out, &grad_value, &grad_loc, &grad_attn, &wd};
     const void* fn = value_dtype == ALO_F32 ? reinterpret_cast<const void*>(msda_bwd_wide_kernel<float>)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ALO_HOTPATH_ABI_VERSION 1
+#define ALO_HOTPATH_ABI_VERSION 2   /* 2: alo_corr_lookup_conv1x1[_kpad] removed (round 5), alo_msda_backward_path added */
 
 typedef enum alo_status {
     ALO_OK = 0,
@@ -174,9 +174,9 @@ int alo_msda_backward(const void* value, const int32_t* spatial_shapes, const in
 
 /*
  * The same operation with a scheduling hint: `host_spatial_shapes` is a HOST copy of spatial_shapes (L x 2 int32, may be NULL).
- * When the queries are the pyramid's own pixels (Lq == S, the encoder's self-attention) the fp32 D = 32, L = P = 4 kernel
- * then groups them as 4x4 blocks of their level instead of runs of 16 consecutive queries, so that the sampling windows of
- * a wave's 16 queries overlap as much as possible (one atomic row per touched pixel per tile).  Results do not depend on
+ * When the queries are the pyramid's own pixels (Lq == S, the encoder's self-attention) the D = 32, L = P = 4 launches (fp32 or
+ * bf16 values) then group them as 16x16 blocks of their level, sort a block's sampling corners by pixel on chip and issue ONE atomic
+ * row per touched pixel per block (msda_bwd_wide.hip); without the hint fp32 takes 4x4 tiles of 16 consecutive queries.  Results do not depend on
  * the hint (up to the order of the floating-point additions, which atomics leave undefined anyway); alo_msda_backward is this
  * call with a NULL hint.
  */
@@ -185,6 +185,18 @@ int alo_msda_backward_hinted(const void* value, const int32_t* spatial_shapes, c
                              void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
                              int N, int S, int M, int D, int L, int Lq, int P,
                              int value_dtype, int loc_dtype, const int32_t* host_spatial_shapes, void* stream);
+
+/*
+ * Which kernel alo_msda_backward_hinted takes for a launch of these dimensions (pointers assumed 16-byte aligned), without
+ * enqueuing anything: ALO_MSDA_BWD_WIDE (16x16 query blocks sorted on chip, one atomic row per touched pixel per block: fp32 / bf16
+ * values, D = 32, L = P = 4, Lq == S and a host copy of the shapes), ALO_MSDA_BWD_TILED (4x4 query tiles on the fp32 matrix cores:
+ * fp32, D = 32, L = P = 4), ALO_MSDA_BWD_GENERIC (one atomic row per corner: everything else); -1 for an unsupported dtype pair.
+ */
+#define ALO_MSDA_BWD_GENERIC 0
+#define ALO_MSDA_BWD_TILED 1
+#define ALO_MSDA_BWD_WIDE 2
+int alo_msda_backward_path(int N, int S, int M, int D, int L, int Lq, int P, int value_dtype, int loc_dtype,
+                           const int32_t* host_spatial_shapes);
 
 /* Size of level l of the correlation pyramid of an (H, W) feature grid: level 0 = (H, W), level l+1 = floor(level l / 2)
  * (F.avg_pool2d(2, stride=2), corr.py:25-27). */

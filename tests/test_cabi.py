@@ -19,7 +19,7 @@ def declared_functions():
 
 def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted(
-        ["alo_abi_version", "alo_last_error", "alo_msda_forward", "alo_msda_forward_fused", "alo_msda_backward", "alo_msda_backward_hinted", "alo_corr_level_shape",
+        ["alo_abi_version", "alo_last_error", "alo_msda_forward", "alo_msda_forward_fused", "alo_msda_backward", "alo_msda_backward_hinted", "alo_msda_backward_path", "alo_corr_level_shape",
          "alo_corr_build_workspace_bytes", "alo_corr_build", "alo_corr_lookup", "alo_corr_lookup_backward", "alo_corr_lookup_backward_coords", "alo_add_layernorm", "alo_bias_act", "alo_msda_forward_fused_hm", "alo_msda_forward_fused_hm_rows", "alo_msda_forward_fused_hm_resident", "alo_msda_resident_levels", "alo_value_head_major", "alo_bias_act_nchw", "alo_gru_gate", "alo_gru_update", "alo_pos_sine_flat", "alo_linear_shortk", "alo_ffn256", "alo_pack_mfma_b", "alo_value_proj_head_major", "alo_conv3x3_nhwc", "alo_conv3x3_workspace_bytes", "alo_stem_conv_pool", "alo_mask_pyramid", "alo_panoptic_onehot", "alo_encoder_reference_points", "alo_linear_packed", "alo_conv1x1_nhwc", "alo_groupnorm_rows", "alo_groupnorm_rows_workspace_bytes", "alo_groupnorm_rows_act", "alo_upsample_add_nhwc", "alo_conv3x3_small_nhwc"]
     )
 
@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = alo_hip.lib()
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} missing from {alo_hip.LIB_PATH}"
-    assert lib.alo_abi_version() == 1
+    assert lib.alo_abi_version() == 2
     assert lib.alo_last_error() is not None
 
 
