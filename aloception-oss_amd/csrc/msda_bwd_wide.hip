@@ -39,6 +39,14 @@ namespace {
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
+// Parts of the kernel can be switched off for timing in a development build (results are then wrong on purpose): 1 no flush, 2 no
+// list walk, 4 no value rows, 8 no insert, 16 no gradient stores, 32 no grad_out rows, 64 no locations, 128 no gather, 1024 no scan.
+#ifdef ALO_WIDE_DBG
+#define ALO_DBG(bit) ((wd.dbg & (bit)) != 0)
+#else
+#define ALO_DBG(bit) (false)
+#endif
+
 constexpr int kSlots = 256;              // query slots of a block (16 x 16 on the fine levels)
 constexpr int kWThreads = 512;           // 8 waves: thread = (query slot, point pair)
 constexpr int kClip = 56;                // window side limit: footprint (<= 32) + 12 px of halo either side
@@ -64,7 +72,7 @@ struct WideDims {
     int nbx[4];         // blocks per row of blocks
     int first[5];       // first block of every level; first[4] = blocks per (batch item, head)
     unsigned nblocks;
-    int dbg;            // timing experiments only (ALO_WIDE_DBG): 1 no flush, 2 no list walk, 4 no value rows, 8 no insert
+    int dbg;            // timing experiments (a build with -DALO_WIDE_DBG reads the environment variable ALO_WIDE_DBG; tools/exp/bwd_wide_dbg.py)
 };
 
 template <typename T>
@@ -164,7 +172,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
     unsigned short* items = reinterpret_cast<unsigned short*>(smem + kOffItems);
     unsigned* wsum = reinterpret_cast<unsigned*>(smem + kOffMisc);
 
-    if (wd.dbg & 256) return;
+    if (ALO_DBG(256)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = wd.M, S = wd.S, Lq = wd.Lq;
     // launch order: head fastest (block i runs on XCD i % 8: with M = 8 every XCD serves one head), then the batch item, then the
@@ -205,7 +213,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
         const int slot = (tid >> 3) + 64 * j, c4 = tid & 7;
         const int q = query_of(slot);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        if (q >= 0 && !(wd.dbg & 32)) g = Row4<T>::load(grad_out + ((bq0 + q) * M + m) * 32 + 4 * c4);
+        if (q >= 0 && !ALO_DBG(32)) g = Row4<T>::load(grad_out + ((bq0 + q) * M + m) * 32 + 4 * c4);
         *reinterpret_cast<f32x4*>(G + slot * 32 + 4 * c4) = g;
     }
     for (int r = tid; r < kCnt; r += kWThreads) cnt[r] = 0;
@@ -230,7 +238,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 
     f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
     float a2[2] = {0.f, 0.f};
-    if (live && same && !(wd.dbg & 64)) {
+    if (live && same && !ALO_DBG(64)) {
         l4 = *reinterpret_cast<const f32x4*>(loc + (qm * 4 + 0) * 8 + ph * 4);
         const f32x2_t av = *reinterpret_cast<const f32x2_t*>(attn + (qm * 4 + 0) * 4 + ph * 2);
         a2[0] = av[0];
@@ -238,7 +246,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
     }
     __syncthreads();
 
-    if (wd.dbg & 512) return;
+    if (ALO_DBG(512)) return;
     if (same) {
         for (int lt = 0; lt < 4; ++lt) {
             const int Hl = wd.h[lt], Wl = wd.w[lt], Sl = wd.start[lt];
@@ -258,7 +266,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 t[j] = make_tap_w(l4[2 * j], l4[2 * j + 1], Hl, Wl, live);
-                if (wd.dbg & 8) t[j].flags = 0;
+                if (ALO_DBG(8)) t[j].flags = 0;
                 // every in-map corner inside the window?  (in-map corners have coordinates in [0, W-1] x [0, H-1])
                 const int xa = max(t[j].w_low, 0), xb = min(t[j].w_low + 1, Wl - 1);
                 const int ya = max(t[j].h_low, 0), yb = min(t[j].h_low + 1, Hl - 1);
@@ -285,7 +293,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
             // the next level's locations and weights travel while this level is sorted and gathered
             f32x4 l4n = {0.f, 0.f, 0.f, 0.f};
             float a2n[2] = {0.f, 0.f};
-            if (live && lt < 3 && !(wd.dbg & 64)) {
+            if (live && lt < 3 && !ALO_DBG(64)) {
                 l4n = *reinterpret_cast<const f32x4*>(loc + (qm * 4 + lt + 1) * 8 + ph * 4);
                 const f32x2_t av = *reinterpret_cast<const f32x2_t*>(attn + (qm * 4 + lt + 1) * 4 + ph * 2);
                 a2n[0] = av[0];
@@ -295,7 +303,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 
             // ---- 2. exclusive prefix sum of the counts, in place (cnt[rows] = number of entries), and the gather's work items: one per
             //         32 entries of a row, so that no half wave is handed a long row alone -------------------------------------------------
-            if (!(wd.dbg & 1024)) {
+            if (!ALO_DBG(1024)) {
                 const int per = (rows + kWThreads) / kWThreads;   // rows + 1 counters over 512 threads: at most 7 each
                 const int r0 = tid * per;
                 unsigned c7[7], sum = 0;   // low half: entries; high half: work items
@@ -350,7 +358,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
             // ---- 4. gather: a half wave per work item (a row, or 32 entries of a long row); 4 lanes x 8 channels per entry, 8 entries a step ----
             {
                 const int hw = tid >> 5, g = (lane >> 2) & 7, c = lane & 3;
-                const int n_items = (wd.dbg & 128) ? 0 : (int)wsum[8];
+                const int n_items = ALO_DBG(128) ? 0 : (int)wsum[8];
                 const unsigned lane_b = (head_elems + 8u * c) * (unsigned)sizeof(T);   // byte offset of the lane's 8 channels inside a pixel
                 const unsigned pix_b = pix_elems * (unsigned)sizeof(T);
                 const unsigned base_pix = (unsigned)(Sl + wy0 * Wl + wx0);
@@ -369,7 +377,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 unsigned fl;
                 unsigned voff = item_of(hw, fl);
                 f32x4 v0, v1;
-                Row4<T>::load8b(v_rsrc, (wd.dbg & 4) ? kDrop : voff, v0, v1);
+                Row4<T>::load8b(v_rsrc, ALO_DBG(4) ? kDrop : voff, v0, v1);
                 const float* Gc = G + 8 * c;
                 const bool t1 = g & 1, t2 = g & 2, t4 = g & 4;
                 const unsigned reg_b = ((t1 ? 4u : 0u) + (t2 ? 2u : 0u) + (t4 ? 1u : 0u)) * 4u;   // the channel (of the lane's eight) it flushes
@@ -378,8 +386,8 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     unsigned fl_n;
                     const unsigned voff_n = item_of(kb + (hw & 1) + 16, fl_n);
                     f32x4 vn0, vn1;
-                    Row4<T>::load8b(v_rsrc, (wd.dbg & 4) ? kDrop : voff_n, vn0, vn1);
-                    const int first = (int)(fl & 0xffffu), len = (wd.dbg & 2) ? 0 : (int)(fl >> 16);
+                    Row4<T>::load8b(v_rsrc, ALO_DBG(4) ? kDrop : voff_n, vn0, vn1);
+                    const int first = (int)(fl & 0xffffu), len = ALO_DBG(2) ? 0 : (int)(fl >> 16);
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
                     const int steps = (max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32)) + 7) >> 3;
                     // (entries past the item's end are other entries, or the zeroed pad behind the list: their weight is forced to 0)
@@ -438,7 +446,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     const float k3 = t4 ? r2b : r2a, s3 = t4 ? r2a : r2b;
                     const float tot = k3 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s3), 0x401F));   // xor 16
                     // value is T, grad_value fp32: the same pixel and channels are at byte offset (voff / sizeof(T)) * 4
-                    const unsigned boff = (voff == kDrop || (wd.dbg & 1)) ? kDrop : voff * (4u / (unsigned)sizeof(T)) + reg_b;
+                    const unsigned boff = (voff == kDrop || ALO_DBG(1)) ? kDrop : voff * (4u / (unsigned)sizeof(T)) + reg_b;
                     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, gv_rsrc, boff, 0, 0);
                     voff = voff_n;
                     fl = fl_n;
@@ -449,7 +457,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
             __syncthreads();
 
             // ---- 5. finish: the sample's owner combines its four d's; the counters are cleared for the next level -------------------------
-            if (live && !(wd.dbg & 16)) {
+            if (live && !ALO_DBG(16)) {
                 f32x4 gl = {0.f, 0.f, 0.f, 0.f};
                 f32x2_t ga = {0.f, 0.f};
 #pragma unroll
@@ -472,7 +480,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 *reinterpret_cast<f32x2_t*>(grad_attn + gidx) = ga;
                 *reinterpret_cast<f32x4*>(grad_loc + 2 * gidx) = gl;
             }
-            if (!(wd.dbg & 2048)) for (int r = tid; r <= rows; r += kWThreads) cnt[r] = 0;
+            if (!ALO_DBG(2048)) for (int r = tid; r <= rows; r += kWThreads) cnt[r] = 0;
             l4 = l4n;
             a2[0] = a2n[0];
             a2[1] = a2n[1];

@@ -29,7 +29,7 @@ Beside it (numbers in the line, the full objects in the sidecar):
                 same bits; ``--no-graph`` launches eagerly); ``inference()`` — the device-to-host hand-over — is eager.
   raft          BASELINE.json configs[2]: RAFT, 32 iterations, 4 synthetic 1280x720 pairs per GPU (fp32), pairs/s.
   train         BASELINE.json configs[3] per-GPU share (fp32, 4 frames): forward + match + loss + alo_msda_backward + AdamW;
-                carries its own roofline entry for msda_bwd_tiled_kernel (HBM-bound, algorithmic bytes SURVEY 8d).
+                carries its own roofline entry for msda_bwd_wide_kernel (HBM-bound, algorithmic bytes SURVEY 8d).
   panoptic      BASELINE.json configs[4] per-GPU share (bf16, 8 frames, 16 kept queries per frame).
   eager         the same detection step with eager launches (no HIP graph), timed right after the headline steps.
   fp32          the same detection workload in fp32 — the mode that meets the north-star's <= 1e-3 bar against the reference op,
@@ -635,6 +635,13 @@ def micro_benchmarks(reps):
         for dt, dn in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
             out[f"msda_fwd[{tag}] {dn} N=8"] = entry(kbench.bench_msda_fwd(8, S, kind, dt, reps))
         out[f"msda_bwd[{tag}] f32 N=4"] = entry(kbench.bench_msda_bwd(4, S, kind, torch.float32, max(3, reps // 2)))
+        if tag in ("ring", "trained"):   # bf16 values / grad_out (gradients fp32): the same wide kernel; and the 4x4 tiled kernel beside it
+            out[f"msda_bwd[{tag}] bf16 N=4"] = entry(kbench.bench_msda_bwd(4, S, kind, torch.bfloat16, max(3, reps // 2)))
+            os.environ["ALO_MSDA_BWD"] = "tiled"
+            try:
+                out[f"msda_bwd[{tag}] f32 N=4 tiled-4x4"] = entry(kbench.bench_msda_bwd(4, S, kind, torch.float32, max(3, reps // 2)))
+            finally:
+                del os.environ["ALO_MSDA_BWD"]
         torch.cuda.empty_cache()
     return out
 
@@ -734,10 +741,11 @@ def live_traffic(a):
 
 def live_traffic_bwd(N):
     """The same for the training leg's kernel: ``tools/kbench.py --which msda_bwd`` (fp32, N = 4, Lq = S = 22223, the ring the
-    random-init model samples).  Coalesced streams of the tiled backward (counted at half by FETCH_SIZE): locations, attention
-    weights and the grad_out rows read as 128-byte rows for the MFMA B operand; the value rows and the second reading of grad_out
-    arrive as 64-byte pieces (counted in full).  WRITE_SIZE includes the write-through of every atomic row; the memset of grad_value
-    (a runtime fill kernel, 91 MB of writes at N = 4) is added as its algorithmic size."""
+    random-init model samples), msda_bwd_wide_kernel.  Coalesced streams (counted at half by FETCH_SIZE): locations, attention
+    weights, the grad_out rows of a block (16 bytes per lane) and one reading of the value rows (32 bytes per lane, 128-byte rows);
+    what FETCH_SIZE holds beyond them (value rows re-read by neighbouring blocks' halos, the per-corner route) is counted in full.
+    WRITE_SIZE includes the write-through of every atomic row; the memset of grad_value (a runtime fill kernel, 91 MB of writes at
+    N = 4) is added as its algorithmic size."""
     import shutil
 
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -745,13 +753,13 @@ def live_traffic_bwd(N):
 
     Lq, M = 22223, 8
     alg = 4.0 * (2 * N * Lq * M * 32 + N * Lq * M * 32) + 4.0 * (N * Lq * M * 16 * 3 * 2)
-    stream_bytes = 4.0 * N * Lq * M * 16 * 3 + 4.0 * N * Lq * M * 32
+    stream_bytes = 4.0 * N * Lq * M * 16 * 3 + 4.0 * N * Lq * M * 32 * 2
     work = None
     try:
         csvs, work = _pmc_passes("msda_bwd")
         if csvs is None:
             return None
-        out = pmc_parse.traffic(csvs, "msda_bwd_tiled_kernel", alg, stream_bytes,
+        out = pmc_parse.traffic(csvs, "msda_bwd_wide_kernel", alg, stream_bytes,
                                 "two rocprofv3 --pmc passes over tools/kbench.py --which msda_bwd, launched by bench.py after its timed legs")
         memset = 4.0 * N * Lq * M * 32
         out["memset_bytes_added"] = memset
@@ -1137,7 +1145,7 @@ def main():
                                 "parallelism": "DDP over RCCL" if (world > 1 or a.force_dist) else "single GPU"}}
             bk = tk.get("msda_bwd/Lq=22223")
             if bk is not None:   # HIP events around the launch (memset of grad_value + the tiled kernel), encoder-size calls only
-                train["roofline"] = {"bound": "hbm", "kernel": "msda_bwd (memset + tiled/wide kernel) enc N=%d Lq=S=22223 f32" % a.train_batch,
+                train["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_wide_kernel<float> (+ memset) enc N=%d Lq=S=22223" % a.train_batch,
                                      "achieved": bk["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": bk["hbm_frac"], "traffic": None,
                                      "alg_bytes_per_launch": bk["alg_bytes"], "ms_per_launch": bk["ms_avg"], "launches": bk["launches"]}
             del tmodel, step_model, tframes, opt
