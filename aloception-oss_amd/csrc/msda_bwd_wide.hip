@@ -9,21 +9,32 @@
 // 4x4 query tile on chip (one row per touched pixel per tile): 6.3 M rows on the random-init ring, but 12-13 M on the survey and
 // trained-like spreads, where neighbouring queries share fewer pixels per tile (profiles/r05_bwd_rows_sim.txt).  A 16x16 block
 // shares 3-4 x more (2.9 / 4.0 / 4.3 M rows).  The sums of a block this wide do not fit a dense A[row][query] matrix, and LDS float
-// atomics are slow (ds_add_f32: 194 clocks per wave instruction, tools/micro/lds_atomic.hip) — so the block SORTS instead:
+// atomics are slow (ds_add_f32: 194 clocks per wave instruction, tools/micro/lds_atomic.hip) — so the block SORTS its corners by
+// destination pixel instead (a counting sort in LDS):
 //
-//   per target level (4 passes over the block's 256 queries x 4 points x 4 corners = 4096 corner entries):
-//   1. insert   thread (query, point pair) turns its two sampling points into taps.  A corner inside the block's WINDOW on that
-//               level (a <= 56 x 56 clip box around the block's own footprint) is pushed on the linked list of its window row:
-//               ds_wrxchg_rtn_b32 on head[row] (integer LDS atomics are fast), next[entry] = previous head, and the scalar
-//               tbl[entry] = bilinear weight x attention weight.  No counting, no prefix sum, no second pass.
-//   2. gather   8 lanes own ONE touched row (8 rows per wave at a time): they hold value[row] (read from memory exactly once per
-//               block) and walk the row's list; per entry ONE 128-byte LDS read of the query's grad_out row feeds both sums:
-//                 grad_value[row] += tbl[entry] * grad_out[q]                  (registers; ONE atomic row per touched row at the end)
-//                 d[entry]         = <value[row], grad_out[q]>                  (3 DPP adds over the 8 lanes; overwrites tbl[entry])
-//   3. finish   the thread that owns the sample reads its four d's back: grad_attn = sum_k w_k d_k, grad_loc = attn * (W, H) * (...)
-//               — the same expressions as msda_bwd_tiled_kernel's stage 3.
-//   A sample with a corner outside the window (far outliers; every sample of a uniform distribution) goes on an overflow list and
+//   per target level (4 passes over the block's 256 queries x 4 points x 4 corners = 4096 corner entries), 512 threads:
+//   1. count    thread (query, point pair) turns its two sampling points into taps.  A corner inside the block's WINDOW on that level
+//               (the block's footprint + 13 px either side, at most 55 x 55 pixels, rows numbered 64 y + x) takes a slot in its window
+//               row: ds_add_rtn_u32 on cnt[row] (integer LDS atomics are fast), and the scalar tbl[entry] = bilinear weight x
+//               attention weight.
+//   2. scan     exclusive prefix sum of the counts in place (DPP wave scan + 8 wave totals), and the gather's WORK ITEMS: one per
+//               touched row, four for rows longer than 96 entries (coarse levels) — no half wave is handed a long row alone.
+//   3. list     list[cnt[row] + slot] = entry: the entries sorted by window row, contiguous per row.
+//   4. gather   a half wave per work item, 4 lanes x 8 channels per entry, 8 entries a step.  The lanes hold value[row] (read from
+//               memory once per block, the next item's row prefetched) and per entry ONE 128-byte LDS read of the query's grad_out row
+//               feeds both sums:
+//                 grad_value[row] += tbl[entry] * grad_out[q]      registers; reduce-scatter over the 8 lane groups (ds_swizzle / DPP),
+//                                                                  then ONE buffer_atomic_add_f32 row per work item
+//                 d[entry]         = <value[row], grad_out[q]>      2 DPP adds over the 4 lanes; overwrites tbl[entry]
+//   5. finish   the thread that owns the sample reads its four d's back: grad_attn = sum_k w_k d_k, grad_loc = attn * (W, H) * (...)
+//               — the same expressions as msda_bwd_tiled_kernel's stage 3 — and stores 16 + 8 contiguous bytes.
+//   A sample with a corner outside the window (far outliers; every sample of a uniform distribution) sets a bit in an overflow mask and
 //   takes the per-corner route of msda_bwd_kernel at the end: same results, old cost.
+//
+// Measured (MI355X, N = 4 encoder call, fp32; tools/exp/bwd_wide_check.py): 0.70 / 0.80 / 0.80 / 3.16 ms on the ring / survey /
+// trained-like / uniform distributions against 0.70 / 1.32 / 1.61 / 4.04 for msda_bwd_tiled_kernel; bf16 values 0.68 / 0.77 against
+// 4.1 / 3.9 for msda_bwd_kernel.  VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 0.6 of the busy cycles): the listed order of the blocks
+// (full blocks of every batch item first, heads round-robin over the XCDs) and a loop-free scan were worth 25 % together.
 //
 // Shapes served: value / grad_out fp32 or bf16 (gradients fp32), D = 32, L = P = 4, queries = the pyramid's own pixels (Lq == S).
 // The host copy of the shapes sizes the grid AND travels by value; a launch whose device shapes differ from it sends every
@@ -49,9 +60,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kSlots = 256;              // query slots of a block (16 x 16 on the fine levels)
 constexpr int kWThreads = 512;           // 8 waves: thread = (query slot, point pair)
-constexpr int kClip = 56;                // window side limit: footprint (<= 32) + 12 px of halo either side
-constexpr int kRowsMax = kClip * kClip;  // 3136 window rows
-constexpr unsigned kNil = 0xffffu;
+constexpr int kClip = 56;                // window side limit (55 in use): footprint (<= 32) + ~12 px of halo either side
 constexpr unsigned kDrop = 0xffffff00u;  // a byte offset past any frame slab: the buffer range check drops the lane
 
 constexpr int kOffG = 0;                              // float  G[256][32]      grad_out rows of the block's queries
@@ -179,7 +188,6 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
     // block — the full 16x16 blocks of the finest level of EVERY item first, the small blocks of the coarse levels fill the tail
     const unsigned lb = blockIdx.x;
     const int m = lb % M;
-    const int nblk = wd.first[4];
     const int b = (int)((lb / M) % (unsigned)wd.N);
     const int blk = (int)(lb / ((unsigned)M * wd.N));
 
@@ -256,7 +264,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
             const int hx = min((fx >> 1) + 13, kClip / 2 - 1), hy = min((fy >> 1) + 13, kClip / 2 - 1);
             const int wx0 = max(cxl - hx, 0), wx1 = min(cxl + hx, Wl - 1);
             const int wy0 = max(cyl - hy, 0), wy1 = min(cyl + hy, Hl - 1);
-            const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+            const int wh = wy1 - wy0 + 1;
             const int rows = wh * 64;   // row numbers in use: 64 * y + x, x < ww <= 55
 
             // ---- 1. count: every in-window corner takes a slot in its row ---------------------------------------------------------

@@ -475,7 +475,7 @@ def test_config5_panoptic_at_per_gpu_size():
     assert boxes[0].shape == (16, 4)
 
 
-def test_bench_gpu_branch_with_two_ranks():
+def test_bench_gpu_branch_with_two_ranks(tmp_path):
     """The N > 1 branch of bench.py ON THE GPU (rank-seeded shards, barrier + synchronize fences, max over ranks, one JSON line
     from rank 0): two ranks share the one GPU of this box (`--share-gpu`: control collectives on gloo, since RCCL wants one
     device per rank).  The whole-job value must count both ranks' frames."""
@@ -488,7 +488,8 @@ def test_bench_gpu_branch_with_two_ranks():
     # started PLAINLY, the way the driver starts it (no torch.distributed environment): bench.py spawns its own two ranks
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
            "--raft-steps", "1", "--raft-warmup", "1", "--raft-batch", "1", "--train-steps", "0", "--panoptic-steps", "1",
-           "--eager-steps", "2", "--fp32-steps", "0", "--micro-reps", "0", "--no-cpu-baseline", "--no-pmc", "--share-gpu"]
+           "--eager-steps", "2", "--fp32-steps", "0", "--micro-reps", "0", "--no-cpu-baseline", "--no-pmc", "--share-gpu",
+           "--detail-out", str(tmp_path / "detail.json")]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, OMP_NUM_THREADS="4"))
     assert out.returncode == 0, out.stderr[-3000:]
@@ -498,10 +499,13 @@ def test_bench_gpu_branch_with_two_ranks():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 4
     assert abs(line["value"] - 2 * 2 * 3 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 1e-3
     assert line["raft"]["value"] > 0 and line["panoptic"]["value"] > 0 and "cpu_baseline" not in line
-    assert line["eager"]["value"] > 0 and line["raft"]["hot_path_ms_per_step"] > 0
+    assert len(lines[0]) < 4096 and line["raft"]["corr_build_ms"] > 0 and line["per_rank"]["ms_per_step"]
+    # the full record (kernel tables, the eager leg, per-leg configuration) is the sidecar file, not the line
+    detail = json.loads((tmp_path / "detail.json").read_text())
+    assert detail["value"] == line["value"] and detail["eager"]["value"] > 0 and detail["raft"]["hot_path_ms_per_step"] > 0
 
 
-def test_bench_rccl_code_path_on_one_rank():
+def test_bench_rccl_code_path_on_one_rank(tmp_path):
     """What a multi-GPU run adds to bench.py, exercised on the one GPU of this box with a ONE-rank RCCL group (`--force-dist`):
     `init_process_group("nccl", device_id=...)`, barriers and the timing all-reduce on device tensors, HIP-graph capture of the
     forward while the communicator exists, and the training step under DistributedDataParallel with RCCL buckets."""
@@ -513,7 +517,7 @@ def test_bench_rccl_code_path_on_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "2",
            "--no-raft", "--train-steps", "2", "--train-batch", "1", "--panoptic-steps", "0", "--no-cpu-baseline", "--no-pmc", "--force-dist",
-           "--eager-steps", "0", "--fp32-steps", "2", "--micro-reps", "0"]
+           "--eager-steps", "0", "--fp32-steps", "2", "--micro-reps", "0", "--detail-out", str(tmp_path / "detail.json")]
     env = dict(os.environ, OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -522,9 +526,10 @@ def test_bench_rccl_code_path_on_one_rank():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert "error" not in line["train"], line["train"]
-    assert line["train"]["config"]["parallelism"] == "DDP over RCCL" and line["train"]["value"] > 0
-    assert "HIP graph" in line["config"]["launch"], line["config"]["launch"]   # capture worked beside the communicator
-    assert line["fp32"]["value"] > 0 and line["fp32"]["roofline"]["frac"] > 0, line["fp32"]
+    detail = json.loads((tmp_path / "detail.json").read_text())
+    assert detail["train"]["config"]["parallelism"] == "DDP over RCCL" and line["train"]["value"] > 0
+    assert "hip-graph" in line["config"]["launch"], line["config"]["launch"]   # capture worked beside the communicator
+    assert line["fp32"]["value"] > 0 and line["fp32"]["frac"] > 0, line["fp32"]
 
 
 # ---- the reference's golden vectors ON THE DEVICE ---------------------------------------------------------------------------------
