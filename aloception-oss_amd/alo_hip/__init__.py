@@ -479,10 +479,10 @@ def _host_spatial_shapes(spatial_shapes):
 
 
 def _tiled_backward_eligible(value, dims, ldt):
-    """The shapes msda_bwd_tiled_kernel covers (csrc/msda.hip, backward_impl): fp32, D = 32, L = P = 4, queries = the pyramid's
-    own pixels.  Only then is the host copy of the shapes worth a device-to-host read."""
+    """The launches msda_bwd_wide_kernel covers (csrc/msda_bwd_wide.hip): fp32 / bf16 values, D = 32 or 64, L = P = 4, queries = the
+    pyramid's own pixels.  Only then is the host copy of the shapes worth a device-to-host read."""
     N, S, M, D, L, Lq, P = dims
-    return value.dtype in (torch.float32, torch.bfloat16) and ldt == ALO_F32 and D == 32 and L == 4 and P == 4 and Lq == S
+    return value.dtype in (torch.float32, torch.bfloat16) and ldt == ALO_F32 and D in (32, 64) and L == 4 and P == 4 and Lq == S
 
 
 def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):

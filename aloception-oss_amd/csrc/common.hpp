@@ -55,9 +55,9 @@ __device__ __forceinline__ unsigned xcd_contiguous_block(unsigned bid, unsigned 
     return start + k;
 }
 
-// msda_bwd_wide.hip: the 16x16-block backward (fp32 / bf16, D = 32, L = P = 4, Lq == S).  ALO_ERR_UNSUPPORTED = nothing enqueued.
+// msda_bwd_wide.hip: the 16x16-block backward (fp32 / bf16, D = 32 or 64, L = P = 4, Lq == S).  ALO_ERR_UNSUPPORTED = nothing enqueued.
 int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* lstart, const void* loc, const void* attn,
-                       const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M, int Lq,
+                       const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M, int D, int Lq,
                        int value_dtype, const int32_t* host_shapes, hipStream_t stream, bool plan_only = false);
 
 // ---- device side ---------------------------------------------------------------------------------------------------

@@ -1886,11 +1886,11 @@ int backward_impl(const void* value, const int32_t* spatial_shapes, const int32_
     const bool all_aligned = aligned && (((uintptr_t)sampling_loc | (uintptr_t)attn_weight | (uintptr_t)grad_value |
                                           (uintptr_t)grad_sampling_loc | (uintptr_t)grad_attn_weight) & 15) == 0;
     const bool frame32 = (double)S * M * 128 < 4.0e9 && (double)Lq * M * 32 < 2.0e9;   // 32-bit byte offsets inside one frame
-    if ((value_dtype == ALO_F32 || value_dtype == ALO_BF16) && D == 32 && L == 4 && P == 4 && all_aligned && frame32 && host_shapes &&
+    if ((value_dtype == ALO_F32 || value_dtype == ALO_BF16) && (D == 32 || D == 64) && L == 4 && P == 4 && all_aligned && frame32 && host_shapes &&
         Lq == S && bwd_policy() != 1) {
         // queries = the pyramid's own pixels: 16x16 query blocks, sorted on chip (msda_bwd_wide.hip)
         const int rc = msda_backward_wide(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
-                                          grad_sampling_loc, grad_attn_weight, N, S, M, Lq, value_dtype, host_shapes, stream);
+                                          grad_sampling_loc, grad_attn_weight, N, S, M, D, Lq, value_dtype, host_shapes, stream);
         if (rc != ALO_ERR_UNSUPPORTED) return rc;
     }
     if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && all_aligned && frame32) {
@@ -1975,9 +1975,9 @@ extern "C" int alo_msda_backward_path(int N, int S, int M, int D, int L, int Lq,
                          (value_dtype == ALO_BF16 && loc_dtype == ALO_F32);
     if (!pair_ok || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return -1;
     const bool frame32 = (double)S * M * 128 < 4.0e9 && (double)Lq * M * 32 < 2.0e9;
-    if ((value_dtype == ALO_F32 || value_dtype == ALO_BF16) && D == 32 && L == 4 && P == 4 && frame32 && host_spatial_shapes && Lq == S &&
+    if ((value_dtype == ALO_F32 || value_dtype == ALO_BF16) && (D == 32 || D == 64) && L == 4 && P == 4 && frame32 && host_spatial_shapes && Lq == S &&
         bwd_policy() != 1 &&
-        msda_backward_wide(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, S, M, Lq, value_dtype,
+        msda_backward_wide(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, S, M, D, Lq, value_dtype,
                            host_spatial_shapes, nullptr, true) == ALO_OK)
         return ALO_MSDA_BWD_WIDE;
     if (value_dtype == ALO_F32 && D == 32 && L == 4 && P == 4 && frame32) return ALO_MSDA_BWD_TILED;

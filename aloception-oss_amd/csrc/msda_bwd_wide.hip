@@ -63,15 +63,15 @@ constexpr int kWThreads = 512;           // 8 waves: thread = (query slot, point
 constexpr int kClip = 56;                // window side limit (55 in use): footprint (<= 32) + ~12 px of halo either side
 constexpr unsigned kDrop = 0xffffff00u;  // a byte offset past any frame slab: the buffer range check drops the lane
 
-constexpr int kOffG = 0;                              // float  G[256][32]      grad_out rows of the block's queries
-constexpr int kOffTbl = kOffG + kSlots * 32 * 4;      // float  tbl[4096]       w * attn per corner entry, then d
 constexpr int kCnt = 55 * 64 + 8;                     // window rows are numbered 64 * y + x (y, x < 55): no division on the way back
+constexpr int kOffTbl = 0;                            // float  tbl[4096]       w * attn per corner entry, then d
 constexpr int kOffCnt = kOffTbl + 4096 * 4;           // u32    cnt[kCnt]       entries per window row, then their exclusive prefix sum
-constexpr int kOffList = kOffCnt + kCnt * 4;          // u16    list[4096]      entries sorted by window row
-constexpr int kOffOvf = kOffList + (4096 + 32) * 2;          // u32    ovf[128]        bit per (level, sample): takes the per-corner route
+constexpr int kOffList = kOffCnt + kCnt * 4;          // u16    list[4096 + 32] entries sorted by window row
+constexpr int kOffOvf = kOffList + (4096 + 32) * 2;   // u32    ovf[128]        bit per (level, sample): takes the per-corner route
 constexpr int kOffItems = kOffOvf + 128 * 4;          // u16    items[3168]     work items of the gather: row | (32-entry segment << 12)
 constexpr int kOffMisc = kOffItems + 3168 * 2;        // u32    wsum[8], total  wave totals of the prefix sum
-constexpr int kWideLds = kOffMisc + 64;               // 76,848 bytes: two workgroups per CU
+constexpr int kOffG = kOffMisc + 64;                  // float  G[256][D]       grad_out rows of the block's queries
+constexpr int wide_lds(int D) { return kOffG + kSlots * D * 4; }   // 78,416 bytes at D = 32 (two workgroups per CU), 111,184 at D = 64 (one)
 
 struct WideDims {
     int N, S, M, Lq;
@@ -97,8 +97,9 @@ struct Row4<float> {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem_off == kDrop ? kDrop : elem_off * 4u, 0, 0));
     }
     // eight channels at a BYTE offset (kDrop, and kDrop + 16, are past the slab: zeros)
+    template <int CH1>   // the second four channels start CH1 channels after the first
     static __device__ __forceinline__ void load8b(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4& lo, f32x4& hi) {
-        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0), y = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u, 0, 0);
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0), y = __builtin_amdgcn_raw_buffer_load_b128(r, off + 4u * CH1, 0, 0);
         lo = f32x4{__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
         hi = f32x4{__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(y.z), __uint_as_float(y.w)};
     }
@@ -116,10 +117,16 @@ struct Row4<bf16_t> {
     static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned elem_off) {
         return bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, elem_off == kDrop ? kDrop : elem_off * 2u, 0, 0));
     }
+    template <int CH1>
     static __device__ __forceinline__ void load8b(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4& lo, f32x4& hi) {
-        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-        lo = widen(u32x2{x.x, x.y});
-        hi = widen(u32x2{x.z, x.w});
+        if constexpr (CH1 == 4) {
+            const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+            lo = widen(u32x2{x.x, x.y});
+            hi = widen(u32x2{x.z, x.w});
+        } else {
+            lo = widen(__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+            hi = widen(__builtin_amdgcn_raw_buffer_load_b64(r, off + 2u * CH1, 0, 0));
+        }
     }
 };
 
@@ -166,8 +173,8 @@ __device__ __forceinline__ Tap make_tap_w(float x, float y, int Hl, int Wl, bool
 
 #define ALO_WAVE_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-template <typename T>
-__global__ void __launch_bounds__(kWThreads, 4)
+template <typename T, int D>
+__global__ void __launch_bounds__(kWThreads, D == 32 ? 4 : 2)
 msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ shapes, const int32_t* __restrict__ lstart,
                      const float* __restrict__ loc, const float* __restrict__ attn, const T* __restrict__ grad_out,
                      float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
@@ -216,13 +223,14 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
     const long bq0 = (long)b * Lq;
 
     // ---- set-up: grad_out rows of the block, empty counters ----------------------------------------------------------------
+    constexpr int CH = D / 4;   // 16-byte chunks of a grad_out row
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int slot = (tid >> 3) + 64 * j, c4 = tid & 7;
+    for (int j = 0; j < kSlots * CH / kWThreads; ++j) {
+        const int slot = tid / CH + (kWThreads / CH) * j, c4 = tid % CH;
         const int q = query_of(slot);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        if (q >= 0 && !ALO_DBG(32)) g = Row4<T>::load(grad_out + ((bq0 + q) * M + m) * 32 + 4 * c4);
-        *reinterpret_cast<f32x4*>(G + slot * 32 + 4 * c4) = g;
+        if (q >= 0 && !ALO_DBG(32)) g = Row4<T>::load(grad_out + ((bq0 + q) * M + m) * D + 4 * c4);
+        *reinterpret_cast<f32x4*>(G + slot * D + 4 * c4) = g;
     }
     for (int r = tid; r < kCnt; r += kWThreads) cnt[r] = 0;
     if (tid < 128) ovf[tid] = same ? 0u : 0xffffffffu;
@@ -235,10 +243,10 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
     const bool live = q_own >= 0;
     const long qm = (bq0 + (live ? q_own : 0)) * M + m;
 
-    const size_t slab = (size_t)b * S * M * 32;
-    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(value + slab, (unsigned)((size_t)S * M * 32 * sizeof(T)));
-    const __amdgpu_buffer_rsrc_t gv_rsrc = make_rsrc(grad_value + slab, (unsigned)((size_t)S * M * 128));
-    const unsigned head_elems = (unsigned)m * 32u, pix_elems = (unsigned)M * 32u;
+    const size_t slab = (size_t)b * S * M * D;
+    const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(value + slab, (unsigned)((size_t)S * M * D * sizeof(T)));
+    const __amdgpu_buffer_rsrc_t gv_rsrc = make_rsrc(grad_value + slab, (unsigned)((size_t)S * M * D * 4));
+    const unsigned head_elems = (unsigned)m * D, pix_elems = (unsigned)M * D;
 
     // normalised centre of the block on its own level: the window of every level is a clip box around it
     const float cxn = ((float)(bx << shq) + 0.5f * (float)(1 << shq)) / (float)Wq;
@@ -365,9 +373,13 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 
             // ---- 4. gather: a half wave per work item (a row, or 32 entries of a long row); 4 lanes x 8 channels per entry, 8 entries a step ----
             {
-                const int hw = tid >> 5, g = (lane >> 2) & 7, c = lane & 3;
+                // K lanes x 8 channels per entry, NG entries of an item a step.  D = 32: lane c holds channels 8c .. 8c+7; D = 64: 4c .. 4c+3
+                // of each 128-byte half of the row (so that a half wave's flush covers one whole line per instruction)
+                constexpr int K = D / 8, NG = 32 / K, CH1 = D == 32 ? 4 : 32;
+                const int hw = tid >> 5, g = (lane / K) & (NG - 1), c = lane & (K - 1);
                 const int n_items = ALO_DBG(128) ? 0 : (int)wsum[8];
-                const unsigned lane_b = (head_elems + 8u * c) * (unsigned)sizeof(T);   // byte offset of the lane's 8 channels inside a pixel
+                const unsigned ch0 = D == 32 ? 8u * c : 4u * c;
+                const unsigned lane_b = (head_elems + ch0) * (unsigned)sizeof(T);   // byte offset of the lane's first 4 channels inside a pixel
                 const unsigned pix_b = pix_elems * (unsigned)sizeof(T);
                 const unsigned base_pix = (unsigned)(Sl + wy0 * Wl + wx0);
                 // item k -> byte offset of (row's pixel, this lane's channels) in `value`; first entry and entry count in `fl`
@@ -385,19 +397,20 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 unsigned fl;
                 unsigned voff = item_of(hw, fl);
                 f32x4 v0, v1;
-                Row4<T>::load8b(v_rsrc, ALO_DBG(4) ? kDrop : voff, v0, v1);
-                const float* Gc = G + 8 * c;
+                Row4<T>::template load8b<CH1>(v_rsrc, ALO_DBG(4) ? kDrop : voff, v0, v1);
+                const float* Gc = G + ch0;
                 const bool t1 = g & 1, t2 = g & 2, t4 = g & 4;
-                const unsigned reg_b = ((t1 ? 4u : 0u) + (t2 ? 2u : 0u) + (t4 ? 1u : 0u)) * 4u;   // the channel (of the lane's eight) it flushes
+                // the channel (of the lane's eight) it flushes.  D = 32: one of eight; D = 64: the same one of four in both halves of the row
+                const unsigned reg_b = D == 32 ? ((t1 ? 4u : 0u) + (t2 ? 2u : 0u) + (t4 ? 1u : 0u)) * 4u : ((t1 ? 2u : 0u) + (t2 ? 1u : 0u)) * 4u;
                 for (int kb = hw & ~1; kb < n_items; kb += 16) {   // wave-uniform bound: the two halves' items are kb and kb + 1
                     // the next item's value row travels while this one is walked
                     unsigned fl_n;
                     const unsigned voff_n = item_of(kb + (hw & 1) + 16, fl_n);
                     f32x4 vn0, vn1;
-                    Row4<T>::load8b(v_rsrc, ALO_DBG(4) ? kDrop : voff_n, vn0, vn1);
+                    Row4<T>::template load8b<CH1>(v_rsrc, ALO_DBG(4) ? kDrop : voff_n, vn0, vn1);
                     const int first = (int)(fl & 0xffffu), len = ALO_DBG(2) ? 0 : (int)(fl >> 16);
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                    const int steps = (max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32)) + 7) >> 3;
+                    const int steps = (max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32)) + NG - 1) / NG;
                     // (entries past the item's end are other entries, or the zeroed pad behind the list: their weight is forced to 0)
                     auto walk = [&](int s0, auto nsteps) {
                         constexpr int NS = decltype(nsteps)::value;
@@ -407,16 +420,16 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                         f32x4 g0[NS], g1[NS];
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {
-                            const int i = (s0 + u) * 8 + g;
+                            const int i = (s0 + u) * NG + g;
                             ok[u] = i < len;
                             e[u] = list[first + i];
                         }
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {
                             w[u] = tbl[e[u]];
-                            const float* gp = Gc + (e[u] >> 4) * 32;
+                            const float* gp = Gc + (e[u] >> 4) * D;
                             g0[u] = *reinterpret_cast<const f32x4*>(gp);
-                            g1[u] = *reinterpret_cast<const f32x4*>(gp + 4);
+                            g1[u] = *reinterpret_cast<const f32x4*>(gp + CH1);
                         }
                         float dp[NS];
 #pragma unroll
@@ -428,6 +441,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                             float d = (pr[0] + pr[1]) + (pr[2] + pr[3]);
                             d += dppc<0xB1>(d);    // quad_perm [1,0,3,2]
                             d += dppc<0x4E>(d);    // quad_perm [2,3,0,1]
+                            if constexpr (K == 8) d += dppc<0x141>(d);   // row_half_mirror: the other quad of the 8 lanes
                             dp[u] = d;
                         }
                         if (c == 0) {
@@ -441,21 +455,33 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     } else {
                         for (int s0 = 0; s0 < steps; s0 += 2) walk(s0, std::integral_constant<int, 2>{});
                     }
-                    // reduce-scatter over the eight groups: every lane ends with the full sum of ONE of its eight channels, the 32 lanes of
-                    // the half wave cover the row's 32 channels: ONE atomic row per work item.  Lane ^ 4 and lane ^ 16 travel on the LDS
-                    // crossbar (ds_swizzle: no memory, no address register), lane ^ 8 on DPP.
-                    const f32x4 keep1 = t1 ? a1 : a0, send1 = t1 ? a0 : a1;
-                    f32x4 r1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        r1[i] = keep1[i] + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send1[i]), 0x101F));   // xor 4
-                    const float k2a = t2 ? r1[2] : r1[0], k2b = t2 ? r1[3] : r1[1], s2a = t2 ? r1[0] : r1[2], s2b = t2 ? r1[1] : r1[3];
-                    const float r2a = k2a + dppc<0x128>(s2a), r2b = k2b + dppc<0x128>(s2b);              // row_ror:8 = lane ^ 8 inside a 16-lane row
-                    const float k3 = t4 ? r2b : r2a, s3 = t4 ? r2a : r2b;
-                    const float tot = k3 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s3), 0x401F));   // xor 16
+                    // reduce-scatter over the lane groups: every lane ends with the full sum of ONE of its channels (two at D = 64), the 32
+                    // lanes of the half wave cover 32 consecutive channels: ONE atomic row per work item and 128 bytes of the row.
+                    // Lane ^ 4 and lane ^ 16 travel on the LDS crossbar (ds_swizzle: no memory, no address register), lane ^ 8 on DPP.
                     // value is T, grad_value fp32: the same pixel and channels are at byte offset (voff / sizeof(T)) * 4
                     const unsigned boff = (voff == kDrop || ALO_DBG(1)) ? kDrop : voff * (4u / (unsigned)sizeof(T)) + reg_b;
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, gv_rsrc, boff, 0, 0);
+                    if constexpr (D == 32) {
+                        const f32x4 keep1 = t1 ? a1 : a0, send1 = t1 ? a0 : a1;
+                        f32x4 r1;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            r1[i] = keep1[i] + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send1[i]), 0x101F));   // xor 4
+                        const float k2a = t2 ? r1[2] : r1[0], k2b = t2 ? r1[3] : r1[1], s2a = t2 ? r1[0] : r1[2], s2b = t2 ? r1[1] : r1[3];
+                        const float r2a = k2a + dppc<0x128>(s2a), r2b = k2b + dppc<0x128>(s2b);          // row_ror:8 = lane ^ 8 inside a 16-lane row
+                        const float k3 = t4 ? r2b : r2a, s3 = t4 ? r2a : r2b;
+                        const float tot = k3 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s3), 0x401F));   // xor 16
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, gv_rsrc, boff, 0, 0);
+                    } else {
+                        // four groups (lane bits 3, 4): first the pair of channels, then the channel — of BOTH halves of the row at once
+                        const float ka = t1 ? a0[2] : a0[0], kb = t1 ? a0[3] : a0[1], kc = t1 ? a1[2] : a1[0], kd = t1 ? a1[3] : a1[1];
+                        const float sa = t1 ? a0[0] : a0[2], sb = t1 ? a0[1] : a0[3], sc = t1 ? a1[0] : a1[2], sd = t1 ? a1[1] : a1[3];
+                        const float pa = ka + dppc<0x128>(sa), pb = kb + dppc<0x128>(sb), pc = kc + dppc<0x128>(sc), pd = kd + dppc<0x128>(sd);
+                        const float k0 = t2 ? pb : pa, k1 = t2 ? pd : pc, x0 = t2 ? pa : pb, x1 = t2 ? pc : pd;
+                        const float tot0 = k0 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x0), 0x401F));
+                        const float tot1 = k1 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x1), 0x401F));
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot0, gv_rsrc, boff, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot1, gv_rsrc, boff == kDrop ? kDrop : boff + 128u, 0, 0);
+                    }
                     voff = voff_n;
                     fl = fl_n;
                     v0 = vn0;
@@ -518,22 +544,25 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     const float x = loc[2 * gidx], y = loc[2 * gidx + 1], at = attn[gidx];
                     const Tap tp = make_tap_w(x, y, Hlv, Wlv, true);
                     if (tp.flags & 16u) {
-                        const float top = G[sl * 32 + ch], tgv = top * at;
                         const float lh = tp.lh, lw = tp.lw, hh = 1.f - lh, hw = 1.f - lw;
                         const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
                         const long pix0 = (long)Slv + (long)tp.h_low * Wlv + tp.w_low;
                         const long px[4] = {pix0, pix0 + 1, pix0 + Wlv, pix0 + Wlv + 1};
-                        float v[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            v[k] = Row4<T>::load1(v_rsrc, (tp.flags >> k) & 1u ? (unsigned)px[k] * pix_elems + head_elems + ch : kDrop);
+                        for (int c0 = 0; c0 < D; c0 += 32) {   // 32 channels per half wave at a time
+                            const float top = G[sl * D + c0 + ch], tgv = top * at;
+                            float v[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
-                                w4[k] * tgv, gv_rsrc, (tp.flags >> k) & 1u ? ((unsigned)px[k] * pix_elems + head_elems + ch) * 4u : kDrop, 0, 0);
-                        s_attn = top * (w4[0] * v[0] + w4[1] * v[1] + w4[2] * v[2] + w4[3] * v[3]);
-                        s_w = tgv * (-hh * v[0] + hh * v[1] - lh * v[2] + lh * v[3]);
-                        s_h = tgv * (-hw * v[0] - lw * v[1] + hw * v[2] + lw * v[3]);
+                            for (int k = 0; k < 4; ++k)
+                                v[k] = Row4<T>::load1(v_rsrc, (tp.flags >> k) & 1u ? (unsigned)px[k] * pix_elems + head_elems + c0 + ch : kDrop);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                                    w4[k] * tgv, gv_rsrc, (tp.flags >> k) & 1u ? ((unsigned)px[k] * pix_elems + head_elems + c0 + ch) * 4u : kDrop, 0, 0);
+                            s_attn += top * (w4[0] * v[0] + w4[1] * v[1] + w4[2] * v[2] + w4[3] * v[3]);
+                            s_w += tgv * (-hh * v[0] + hh * v[1] - lh * v[2] + lh * v[3]);
+                            s_h += tgv * (-hw * v[0] - lw * v[1] + hw * v[2] + lw * v[3]);
+                        }
                     }
                 }
                 s_attn = half_sum(s_attn);
@@ -554,11 +583,12 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
 // Host side of the wide path.  Returns ALO_OK after enqueuing, or ALO_ERR_UNSUPPORTED (nothing enqueued) when the geometry is not
 // one the block table can describe — the caller then takes msda_bwd_tiled_kernel.
 int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* lstart, const void* loc, const void* attn,
-                       const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M, int Lq,
+                       const void* grad_out, void* grad_value, void* grad_loc, void* grad_attn, int N, int S, int M, int D, int Lq,
                        int value_dtype, const int32_t* host_shapes, hipStream_t stream, bool plan_only) {
-    if (!host_shapes || Lq != S) return ALO_ERR_UNSUPPORTED;
+    if (!host_shapes || Lq != S || (D != 32 && D != 64)) return ALO_ERR_UNSUPPORTED;
     if (value_dtype != ALO_F32 && value_dtype != ALO_BF16) return ALO_ERR_UNSUPPORTED;
     if (S >= (1 << 24) || M >= (1 << 16)) return ALO_ERR_UNSUPPORTED;   // 24-bit multiplies in the gather's address arithmetic
+    if ((double)S * M * D * 4 >= 4.0e9) return ALO_ERR_UNSUPPORTED;     // 32-bit byte offsets inside one frame
     WideDims wd;
     wd.N = N; wd.S = S; wd.M = M; wd.Lq = Lq;
     long total = 0;
@@ -593,12 +623,13 @@ int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* 
     if (plan_only) return ALO_OK;
     wd.dbg = getenv("ALO_WIDE_DBG") ? atoi(getenv("ALO_WIDE_DBG")) : 0;
     void* args[] = {&value, &shapes, &lstart, &loc, &attn, &grad_out, &grad_value, &grad_loc, &grad_attn, &wd};
-    const void* fn = value_dtype == ALO_F32 ? reinterpret_cast<const void*>(msda_bwd_wide_kernel<float>)
-                                            : reinterpret_cast<const void*>(msda_bwd_wide_kernel<bf16_t>);
-    static unsigned long long attr_done[2] = {0, 0};   // one bit per device
-    hipError_t ea = ensure_dynamic_lds(fn, kWideLds, &attr_done[value_dtype == ALO_F32 ? 0 : 1]);
+    const int which = (value_dtype == ALO_F32 ? 0 : 1) + (D == 32 ? 0 : 2);
+    const void* fns[4] = {reinterpret_cast<const void*>(msda_bwd_wide_kernel<float, 32>), reinterpret_cast<const void*>(msda_bwd_wide_kernel<bf16_t, 32>),
+                          reinterpret_cast<const void*>(msda_bwd_wide_kernel<float, 64>), reinterpret_cast<const void*>(msda_bwd_wide_kernel<bf16_t, 64>)};
+    static unsigned long long attr_done[4] = {0, 0, 0, 0};   // one bit per device
+    hipError_t ea = ensure_dynamic_lds(fns[which], wide_lds(D), &attr_done[which]);
     if (ea != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward (wide): %s", hipGetErrorString(ea));
-    hipError_t el = hipLaunchKernel(fn, dim3(wd.nblocks), dim3(kWThreads), args, kWideLds, stream);
+    hipError_t el = hipLaunchKernel(fns[which], dim3(wd.nblocks), dim3(kWThreads), args, wide_lds(D), stream);
     if (el != hipSuccess) return fail(ALO_ERR_LAUNCH, "alo_msda_backward (wide): %s", hipGetErrorString(el));
     return check_launch("alo_msda_backward (wide)");
 }

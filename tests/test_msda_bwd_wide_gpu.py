@@ -34,7 +34,7 @@ def pyramid_refs(shapes_l):
     return np.concatenate(refs, 0)
 
 
-def encoder_case(shapes_l, N, M, rng, spread_px, heavy_tail=False):
+def encoder_case(shapes_l, N, M, rng, spread_px, heavy_tail=False, D=32):
     ref = pyramid_refs(shapes_l)
     S = ref.shape[0]
     norm = np.array([[w, h] for h, w in shapes_l], np.float64)[None, None, None, :, None, :]
@@ -43,10 +43,10 @@ def encoder_case(shapes_l, N, M, rng, spread_px, heavy_tail=False):
     else:
         off = rng.uniform(-spread_px, spread_px, (N, S, M, 4, 4, 2))
     loc = (ref[None, :, None, None, None, :] + off / norm).astype(np.float32)
-    value = rng.standard_normal((N, S, M, 32)).astype(np.float32)
+    value = rng.standard_normal((N, S, M, D)).astype(np.float32)
     attn = rng.random((N, S, M, 4, 4)).astype(np.float32)
     attn /= attn.reshape(N, S, M, 16).sum(-1)[..., None, None]
-    go = rng.standard_normal((N, S, M * 32)).astype(np.float32)
+    go = rng.standard_normal((N, S, M * D)).astype(np.float32)
     shapes = np.asarray(shapes_l, np.int32)
     return dict(value=value, shapes=shapes, level_start=level_start(shapes), loc=loc, attn=attn, grad_out=go)
 
@@ -59,9 +59,9 @@ def away_from_pixel_edges(loc, shapes_l, eps=1e-3):
 
 
 def run_and_check(c, shapes_l, dtype=torch.float32, tol=1e-4):
-    N, S, M, _ = c["value"].shape
+    N, S, M, D = c["value"].shape
     vdt = alo_hip.ALO_F32 if dtype == torch.float32 else alo_hip.ALO_BF16
-    assert path_of(N, S, M, 32, S, vdt, shapes_l) == 2, "this launch must take msda_bwd_wide_kernel"
+    assert path_of(N, S, M, D, S, vdt, shapes_l) == 2, "this launch must take msda_bwd_wide_kernel"
     shapes = dev(c["shapes"])
     shapes._alo_shapes = [tuple(int(v) for v in hw) for hw in shapes_l]
     args = [dev(c["value"], dtype), shapes, dev(c["level_start"]), dev(c["loc"]), dev(c["attn"]), dev(c["grad_out"], dtype)]
@@ -88,7 +88,8 @@ def test_which_launches_take_the_wide_kernel():
     assert path_of(4, S, 8, 32, S, alo_hip.ALO_F32, None) == 1             # no host copy of the shapes: 4x4 tiles of 16 consecutive queries
     assert path_of(4, S, 8, 32, 300, alo_hip.ALO_F32, DETR_SHAPES) == 1    # decoder cross-attention (Lq != S)
     assert path_of(4, S, 8, 32, S, alo_hip.ALO_BF16, None) == 0
-    assert path_of(4, S, 8, 64, S, alo_hip.ALO_F32, DETR_SHAPES) == 0
+    assert path_of(4, S, 8, 64, S, alo_hip.ALO_F32, DETR_SHAPES) == 2     # D = 64 (d_model 512 at 8 heads): one workgroup per CU
+    assert path_of(4, S, 8, 128, S, alo_hip.ALO_F32, DETR_SHAPES) == 0 and path_of(4, S, 8, 64, S, alo_hip.ALO_F32, None) == 0
     assert path_of(4, S, 8, 32, S, alo_hip.ALO_F32, [(100, 167), (50, 84), (25, 42), (13, 20)]) == 1   # host shapes that do not add up to S
     os.environ["ALO_MSDA_BWD"] = "tiled"
     try:
@@ -129,6 +130,15 @@ def test_wide_backward_bf16_values():
     shapes_l = [(37, 53), (19, 27), (10, 14), (5, 7)]
     rng = np.random.default_rng(5)
     run_and_check(encoder_case(shapes_l, 2, 8, rng, 3.0, True), shapes_l, dtype=torch.bfloat16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("spread,heavy", [(1.0, False), (3.0, True), (30.0, False)])
+def test_wide_backward_with_64_channels_per_head(dtype, spread, heavy):
+    """D = 64: 8 lanes per entry, both 128-byte halves of a row flushed by the same half wave."""
+    shapes_l = [(37, 53), (19, 27), (10, 14), (5, 7)]
+    rng = np.random.default_rng(64 + int(spread))
+    run_and_check(encoder_case(shapes_l, 2, 4, rng, spread, heavy, D=64), shapes_l, dtype=dtype)
 
 
 def test_wide_backward_with_nan_inf_and_huge_locations():

@@ -27,12 +27,15 @@ def main():
     ap.add_argument("--kinds", default="ring,survey,trained,uniform")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--D", type=int, default=32)
     a = ap.parse_args()
     dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
     S = sum(h * w for h, w in kbench.DETR_SHAPES)
     for kind in a.kinds.split(","):
         value, shapes, start, loc, attn = kbench.msda_inputs(a.N, S, "encoder" if kind == "ring" else kind, dtype)
-        go = torch.randn(a.N, S, 256, device="cuda").to(dtype)
+        if a.D != 32:
+            value = torch.randn(a.N, S, 8, a.D, device="cuda").to(dtype)
+        go = torch.randn(a.N, S, 8 * a.D, device="cuda").to(dtype)
         args = (value, shapes, start, loc, attn, go)
         ref = run("tiled", args)
         got = run("wide", args)
