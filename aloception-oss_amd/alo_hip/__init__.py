@@ -9,6 +9,7 @@ current torch stream.
 There is NO fallback: if the library is missing or a tensor lives on the CPU these functions raise ``RuntimeError``.
 """
 import ctypes
+import warnings
 import os
 import subprocess
 
@@ -23,6 +24,7 @@ RESIDENT_AUTO, RESIDENT_ALWAYS = 0, 1   # ALO_RESIDENT_* of include/alo_hotpath.
 _DTYPE_CODE = {torch.float32: ALO_F32, torch.float64: ALO_F64, torch.bfloat16: ALO_BF16}
 
 _lib = None
+_warned_inference_tensor = False
 
 
 def tensor_version(t):
@@ -31,7 +33,16 @@ def tensor_version(t):
     inference mode with their ``data_ptr`` unchanged — so for them the key is a fresh object that equals nothing, itself of an
     earlier call included: whatever is derived from an inference tensor is re-derived on every use instead of being cached
     (round-4 advisor finding: a constant there made stale packed weights / host shapes possible)."""
-    return object() if t.is_inference() else t._version
+    if t.is_inference():
+        global _warned_inference_tensor
+        if not _warned_inference_tensor:
+            _warned_inference_tensor = True
+            warnings.warn("alo_hip: a parameter / shape tensor created under torch.inference_mode() carries no version counter, so what is "
+                          "derived from it (packed MFMA weights, folded convolutions, the host copy of spatial_shapes) is re-derived on "
+                          "every call instead of being cached — results are right, the forward is slower.  Build / load the model outside "
+                          "inference_mode() (torch.no_grad() is enough for inference).", RuntimeWarning, stacklevel=3)
+        return object()
+    return None if t.is_inference() else t._version
 
 
 class HotpathUnavailable(RuntimeError):

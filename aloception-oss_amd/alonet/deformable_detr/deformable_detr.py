@@ -8,6 +8,8 @@ TensorRT / TorchScript tracing mode is not provided.
 import copy
 import math
 
+import threading
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -318,17 +320,19 @@ class DeformableDETR(nn.Module):
     def _to_host_pinned(self, packed):
         """The step's one device-to-host hand-over (B x Q x 6 floats) through a page-locked buffer kept with the model: the copy is
         a DMA straight into it (a pageable ``.cpu()`` stages through the runtime's own bounce buffer under a process-wide lock —
-        with eight ranks on one host at 9 ms per step that is the first place weak scaling is lost).  The buffer is overwritten by the
-        next call; everything inference() returns is copied out of it (boolean selection)."""
+        with eight ranks on one host at 9 ms per step that is the first place weak scaling is lost).  One buffer per host THREAD
+        (two threads calling inference() on one model must not overwrite each other's detections: round-5 advisor finding), and what
+        is returned is a copy of it (B x Q x 6 floats: nothing next to the DMA), so a ``get_outs_filter`` override that keeps views of
+        its input never aliases the next call's detections."""
         if not packed.is_cuda:
             return packed
-        buf = self.__dict__.get("_alo_host_detections")
+        slot = self.__dict__.setdefault("_alo_host_detections", threading.local())
+        buf = getattr(slot, "buf", None)
         if buf is None or buf.shape != packed.shape or buf.dtype != packed.dtype:
-            buf = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
-            self.__dict__["_alo_host_detections"] = buf
+            buf = slot.buf = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
         buf.copy_(packed, non_blocking=True)
         torch.cuda.current_stream(packed.device).synchronize()
-        return buf
+        return buf.clone()
 
     def get_outs_labels(self, m_outputs=None, activation_fn=None):
         assert m_outputs is not None

@@ -27,6 +27,8 @@ Without gradients nothing of this exists: ``CorrBlock`` is two kernel calls.
 """
 import math
 
+import warnings
+
 import torch
 import torch.nn.functional as F
 
@@ -79,6 +81,15 @@ def _needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+# The per-pass bookkeeping below stands on two private hooks of the autograd engine; they are resolved HERE, at import, so that a torch
+# build without them fails with a clear message instead of an AttributeError in the middle of a backward pass.
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_queue_callback = getattr(getattr(torch.autograd.Variable, "_execution_engine", None), "queue_callback", None)
+if _graph_task_id is None or _queue_callback is None:
+    raise ImportError("alonet.raft.corr needs torch._C._current_graph_task_id and the autograd engine's queue_callback "
+                      f"(present in torch 2.x; this is torch {torch.__version__})")
+
+
 class _PyramidState:
     """What the build node and the lookup nodes of one CorrBlock share: the pyramid and, during a backward pass, the gradient maps
     the lookups accumulate into."""
@@ -91,7 +102,7 @@ class _PyramidState:
     @staticmethod
     def _current_pass():
         """Identity of the autograd pass that is running (the engine's graph-task id; -1 outside a backward)."""
-        return torch._C._current_graph_task_id()
+        return _graph_task_id()
 
     def grad_maps(self):
         """The maps of the backward pass that is running.  They belong to THAT pass: the first lookup backward of a pass creates
@@ -103,14 +114,20 @@ class _PyramidState:
         if self.grad is None or self.grad_pass != now:
             self.grad = [torch.zeros_like(p) for p in self.pyramid]
             self.grad_pass = now
-            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
+            _queue_callback(self._end_of_pass)
         return self.grad
 
     def take_grad_maps(self):
         """What the lookups of the running pass accumulated (None if none did); the state is left empty."""
         maps, tag = self.grad, self.grad_pass
         self.grad = self.grad_pass = None
-        return maps if tag == self._current_pass() else None
+        if maps is not None and tag != self._current_pass():
+            # lookups ran in another pass than the build node (a nested / re-entrant backward): their maps are not this pass's
+            warnings.warn("CorrBlock: gradient maps accumulated by another autograd pass were discarded; the feature-map gradients of "
+                          "this pass do not include those lookups (re-entrant backward through a CorrBlock is not supported)",
+                          RuntimeWarning, stacklevel=2)
+            return None
+        return maps
 
     def _end_of_pass(self):
         self.grad = self.grad_pass = None

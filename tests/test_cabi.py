@@ -118,3 +118,19 @@ def test_resident_forward_plan_is_host_logic():
     assert lib.alo_msda_resident_levels(host, 8, 22222, 8, 4, 22222, alo_hip.RESIDENT_ALWAYS) == 0
     assert lib.alo_msda_resident_levels(host, 8, 22223, 8, 3, 22223, alo_hip.RESIDENT_ALWAYS) == 0
     assert lib.alo_msda_resident_levels(None, 8, 22223, 8, 4, 22223, alo_hip.RESIDENT_ALWAYS) == 0
+
+
+def test_backward_dispatch_table_without_a_gpu():
+    """alo_msda_backward_path is pure host logic: which backward kernel a launch takes (csrc/msda.hip backward_impl)."""
+    lib = alo_hip.lib()
+    shapes = [(100, 167), (50, 84), (25, 42), (13, 21)]
+    S = sum(h * w for h, w in shapes)
+    hint = (ctypes.c_int32 * 8)(*[v for hw in shapes for v in hw])
+    f32, f64, bf16 = alo_hip.ALO_F32, alo_hip.ALO_F64, alo_hip.ALO_BF16
+    path = lambda D, Lq, vdt, ldt, h, L=4, P=4: lib.alo_msda_backward_path(4, S, 8, D, L, Lq, P, vdt, ldt, h)  # noqa: E731
+    assert path(32, S, f32, f32, hint) == 2 and path(32, S, bf16, f32, hint) == 2 and path(64, S, f32, f32, hint) == 2
+    assert path(32, S, f32, f32, None) == 1 and path(32, 300, f32, f32, hint) == 1
+    assert path(32, S, f64, f64, hint) == 0 and path(128, S, f32, f32, hint) == 0 and path(32, S, f32, f32, hint, P=8) == 0
+    assert path(32, S, f32, f64, hint) == -1     # not a supported dtype pair
+    wrong = (ctypes.c_int32 * 8)(100, 167, 50, 84, 25, 42, 13, 20)   # does not add up to S: no block table
+    assert path(32, S, f32, f32, wrong) == 1
