@@ -340,6 +340,10 @@ def main():
             res = [bench_msda_fwd(a.N, S, "trained", dt, a.reps) for dt in dts] + [bench_msda_bwd(4, S, "trained", torch.float32, max(3, a.reps // 4))]
         elif w == "msda_bwd_rand":
             res = [bench_msda_bwd(4, S, "uniform", torch.float32, max(3, a.reps // 4))]
+        elif w == "msda_bwd_bf16":   # bf16 values / grad_out (gradients fp32): ring and trained-like
+            res = [bench_msda_bwd(4, S, k, torch.bfloat16, max(3, a.reps // 4)) for k in ("encoder", "trained")]
+        elif w == "msda_bwd_all":    # the four distributions, fp32 (ALO_MSDA_BWD=tiled in the environment: the 4x4 tiled kernel)
+            res = [bench_msda_bwd(4, S, k, torch.float32, max(3, a.reps // 4)) for k in ("encoder", "survey", "trained", "uniform")]
         elif w == "corr_build":
             res = [bench_corr_build(a.B, max(3, a.reps // 4))]
         elif w == "corr_lookup_bwd":
