@@ -4,7 +4,8 @@ tests/).  Random pyramids, batch sizes, query counts, location spreads (inside, 
     python tools/exp/fuzz_msda.py [--seconds 120] [--seed 0]
 
 Checks per case: (1) generic forward fp32 vs oracle; (2) fused head-major bf16 forward, plain vs LDS-resident (ALWAYS) bit-equal and
-vs the oracle on the bf16-rounded inputs; (3) backward fp32 (tiled kernel when D = 32, L = P = 4) vs oracle.  Prints the first failure.
+vs the oracle on the bf16-rounded inputs; (3) backward fp32 vs oracle (the wide kernel for encoder-shaped launches, 4x4 tiles otherwise);
+(4) backward with bf16 values vs fp32 on the rounded operands; (5) backward at D = 64 vs oracle.  Prints the first failure.
 """
 import argparse
 import os
@@ -119,6 +120,30 @@ def run_case(c):
     d = np.abs((gl - rgl) * ok[..., None]).max()
     if not d <= 3e-4 * max(1.0, np.abs(rgl).max()):
         return f"grad_loc: {d:.4g} of {np.abs(rgl).max():.4g}"
+    # --- backward with bf16 values / grad_out (gradients fp32: the wide kernel for encoder-shaped launches, the generic one otherwise),
+    #     against the fp32 result on the same bf16-rounded operands
+    vbf, gobf = v32.bfloat16(), go.bfloat16()
+    gvb, glb, gab = alo_hip.msda_backward(vbf, shapes, start, loc32.bfloat16(), attn32.bfloat16(), gobf, 64)
+    gvr, glr, gar = alo_hip.msda_backward(vbf.float(), shapes, start, loc32.bfloat16().float(), attn32.bfloat16().float(), gobf.float(), 64)
+    if not (gvb.float() - gvr).abs().max().item() <= 1e-2 * max(1.0, gvr.abs().max().item()):   # the wrapper narrows grad_value to bf16
+        return "bf16 backward: grad_value"
+    if not (gab.float() - gar).abs().max().item() <= 1e-2 * max(1.0, gar.abs().max().item()):
+        return "bf16 backward: grad_attn"
+    if not (glb.float() - glr).abs().max().item() <= 1e-2 * max(1.0, glr.abs().max().item()):
+        return "bf16 backward: grad_loc"
+    # --- backward at D = 64 (two value tensors side by side): each 32-channel half must reproduce the D = 32 sums of its own half
+    if c["encoder"] and c["N"] <= 2:
+        v64 = torch.cat([v32, v32.flip(-1) * 0.5], -1).contiguous()
+        go64 = torch.cat([go.view(N, Lq, 8, 32), go.view(N, Lq, 8, 32).flip(-1) * 0.25], -1).reshape(N, Lq, 512).contiguous()
+        gv64, gl64, ga64 = (x.cpu().numpy() for x in alo_hip.msda_backward(v64, shapes, start, loc32, attn32, go64, 64))
+        r64 = O.msda_backward(v64.double().cpu().numpy(), shapes_np, start_np, loc32.double().cpu().numpy(),
+                              attn32.double().cpu().numpy(), go64.double().cpu().numpy())
+        if not np.abs(gv64 - r64[0]).max() <= 3e-4 * max(1.0, np.abs(r64[0]).max()):
+            return "D = 64 backward: grad_value"
+        if not np.abs(ga64 - r64[2]).max() <= 3e-4 * max(1.0, np.abs(r64[2]).max()):
+            return "D = 64 backward: grad_attn"
+        if not np.abs((gl64 - r64[1]) * ok[..., None]).max() <= 3e-4 * max(1.0, np.abs(r64[1]).max()):
+            return "D = 64 backward: grad_loc"
     return None
 
 
