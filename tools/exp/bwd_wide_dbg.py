@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Timing of the wide backward with parts switched off (ALO_WIDE_DBG bits; results are wrong on purpose).
 
-Needs a development build of the library:  touch csrc/msda_bwd_wide.hip && make -C aloception-oss_amd/csrc FLAGS+=-DALO_WIDE_DBG"""
+Needs a development build of the library:  touch csrc/msda_bwd_wide.hip && make -C aloception-oss_amd/csrc EXTRA=-DALO_WIDE_DBG"""
 import os, sys, json
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
