@@ -587,7 +587,7 @@ int msda_backward_wide(const void* value, const int32_t* shapes, const int32_t* 
                        int value_dtype, const int32_t* host_shapes, hipStream_t stream, bool plan_only) {
     if (!host_shapes || Lq != S || (D != 32 && D != 64)) return ALO_ERR_UNSUPPORTED;
     if (value_dtype != ALO_F32 && value_dtype != ALO_BF16) return ALO_ERR_UNSUPPORTED;
-    if (S >= (1 << 24) || M >= (1 << 16)) return ALO_ERR_UNSUPPORTED;   // 24-bit multiplies in the gather's address arithmetic
+    if (S >= (1 << 24) || (long)M * D * 4 >= (1L << 24)) return ALO_ERR_UNSUPPORTED;   // 24-bit multiplies in the gather's address arithmetic
     if ((double)S * M * D * 4 >= 4.0e9) return ALO_ERR_UNSUPPORTED;     // 32-bit byte offsets inside one frame
     WideDims wd;
     wd.N = N; wd.S = S; wd.M = M; wd.Lq = Lq;
