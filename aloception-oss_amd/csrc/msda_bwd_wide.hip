@@ -411,7 +411,8 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     const int first = (int)(fl & 0xffffu), len = ALO_DBG(2) ? 0 : (int)(fl >> 16);
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
                     const int steps = (max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32)) + NG - 1) / NG;
-                    // (entries past the item's end are other entries, or the zeroed pad behind the list: their weight is forced to 0)
+                    // (a slot past the item's end re-reads the row's OWN first entry with weight 0: a non-finite grad_out row of some other
+                    // query can then never reach this row — 0 x inf would — exactly as in the reference, where it touches only its own pixels)
                     auto walk = [&](int s0, auto nsteps) {
                         constexpr int NS = decltype(nsteps)::value;
                         unsigned e[NS];
@@ -422,7 +423,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                         for (int u = 0; u < NS; ++u) {
                             const int i = (s0 + u) * NG + g;
                             ok[u] = i < len;
-                            e[u] = list[first + i];
+                            e[u] = list[first + (ok[u] ? i : 0)];   // idle slots re-read the item's first entry (weight forced to 0)
                         }
 #pragma unroll
                         for (int u = 0; u < NS; ++u) {

@@ -186,3 +186,43 @@ def test_wide_and_tiled_agree_at_full_size():
         del os.environ["ALO_MSDA_BWD"]
     for a, b in zip(wide, tiled):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+def test_a_non_finite_grad_out_row_reaches_only_the_pixels_its_query_samples():
+    """The reference adds w * attn * grad_out[q] to the four corners of q's samples and to nothing else (cuh:301-403), so an inf / NaN row
+    of grad_out poisons exactly q's footprint.  The sorted gather multiplies idle slots by weight 0 — they must then re-read an entry of
+    their OWN row, or 0 x inf from some other query's row would leak in."""
+    shapes_l = [(21, 30), (11, 15), (6, 8), (3, 4)]
+    rng = np.random.default_rng(41)
+    c = encoder_case(shapes_l, 1, 8, rng, 2.0)
+    S = c["loc"].shape[1]
+    bad = [17, 400, S - 3]
+    clean = run_and_check(dict(c), shapes_l)[0]
+    go = c["grad_out"].copy()
+    go[0, bad[0]] = np.inf
+    go[0, bad[1]] = np.nan
+    go[0, bad[2], :32] = -np.inf          # head 0 only
+    shapes = dev(c["shapes"])
+    shapes._alo_shapes = [tuple(hw) for hw in shapes_l]
+    gv = alo_hip.msda_backward(dev(c["value"]), shapes, dev(c["level_start"]), dev(c["loc"]), dev(c["attn"]), dev(go))[0].cpu().numpy()
+    # footprint of the three queries (per head for the last one)
+    hit = np.zeros((S, 8), bool)
+    st = level_start(c["shapes"])
+    for q in bad:
+        for lvl, (h, w) in enumerate(shapes_l):
+            x = c["loc"][0, q, :, lvl, :, 0] * np.float32(w) - np.float32(0.5)
+            y = c["loc"][0, q, :, lvl, :, 1] * np.float32(h) - np.float32(0.5)
+            valid = (y > -1) & (x > -1) & (y < h) & (x < w)
+            x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    yy, xx = y0 + dy, x0 + dx
+                    ok = valid & (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+                    heads = np.broadcast_to(np.arange(8)[:, None], x.shape)
+                    if q == bad[2]:
+                        ok = ok & (heads == 0)
+                    hit[int(st[lvl]) + yy[ok] * w + xx[ok], heads[ok]] = True
+    assert hit.any() and not hit.all()
+    untouched = ~hit
+    assert np.isfinite(gv[0][untouched]).all(), "a non-finite grad_out row leaked outside its query's footprint"
+    assert np.abs(gv[0][untouched] - clean[0][untouched]).max() <= 1e-5 * max(1.0, np.abs(clean).max())
