@@ -18,7 +18,8 @@
 //               row: ds_add_rtn_u32 on cnt[row] (integer LDS atomics are fast), and the scalar tbl[entry] = bilinear weight x
 //               attention weight.
 //   2. scan     exclusive prefix sum of the counts in place (DPP wave scan + 8 wave totals), and the gather's WORK ITEMS: one per
-//               touched row, four for rows longer than 96 entries (coarse levels) — no half wave is handed a long row alone.
+//               touched row, up to four for rows longer than 128 entries — no half wave is handed a very long row alone (splitting at 32 cost
+//               40 % more atomic rows on the ring: the items are dealt round-robin, which balances the coarse levels by itself).
 //   3. list     list[cnt[row] + slot] = entry: the entries sorted by window row, contiguous per row.
 //   4. gather   a half wave per work item, 4 lanes x 8 channels per entry, 8 entries a step.  The lanes hold value[row] (read from
 //               memory once per block, the next item's row prefetched) and per entry ONE 128-byte LDS read of the query's grad_out row
@@ -60,6 +61,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kSlots = 256;              // query slots of a block (16 x 16 on the fine levels)
 constexpr int kWThreads = 512;           // 8 waves: thread = (query slot, point pair)
+constexpr int kSeg = 128;                 // entries of a row one work item walks: 32 / 64 / 128 / 512 measured 0.68 / 0.640 / 0.640 / 0.639 ms (ring)
 constexpr int kClip = 56;                // window side limit (55 in use): footprint (<= 32) + ~12 px of halo either side
 constexpr unsigned kDrop = 0xffffff00u;  // a byte offset past any frame slab: the buffer range check drops the lane
 
@@ -68,7 +70,7 @@ constexpr int kOffTbl = 0;                            // float  tbl[4096]       
 constexpr int kOffCnt = kOffTbl + 4096 * 4;           // u32    cnt[kCnt]       entries per window row, then their exclusive prefix sum
 constexpr int kOffList = kOffCnt + kCnt * 4;          // u16    list[4096 + 32] entries sorted by window row
 constexpr int kOffOvf = kOffList + (4096 + 32) * 2;   // u32    ovf[128]        bit per (level, sample): takes the per-corner route
-constexpr int kOffItems = kOffOvf + 128 * 4;          // u16    items[3168]     work items of the gather: row | (32-entry segment << 12)
+constexpr int kOffItems = kOffOvf + 128 * 4;          // u16    items[3168]     work items of the gather: row | (segment << 12)
 constexpr int kOffMisc = kOffItems + 3168 * 2;        // u32    wsum[8], total  wave totals of the prefix sum
 constexpr int kOffG = kOffMisc + 64;                  // float  G[256][D]       grad_out rows of the block's queries
 constexpr int wide_lds(int D) { return kOffG + kSlots * D * 4; }   // 78,416 bytes at D = 32 (two workgroups per CU), 111,184 at D = 64 (one)
@@ -318,7 +320,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
             __syncthreads();
 
             // ---- 2. exclusive prefix sum of the counts, in place (cnt[rows] = number of entries), and the gather's work items: one per
-            //         32 entries of a row, so that no half wave is handed a long row alone -------------------------------------------------
+            //         kSeg entries of a row, so that no half wave is handed a very long row alone -------------------------------------------------
             if (!ALO_DBG(1024)) {
                 const int per = (rows + kWThreads) / kWThreads;   // rows + 1 counters over 512 threads: at most 7 each
                 const int r0 = tid * per;
@@ -327,7 +329,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 for (int i = 0; i < 7; ++i) {
                     const int r = r0 + i;
                     const unsigned n = (i < per && r < rows) ? cnt[r] : 0u;
-                    c7[i] = n | (min((n + 31u) >> 5, 4u) << 16);
+                    c7[i] = n | (min((n + (unsigned)kSeg - 1u) / (unsigned)kSeg, 4u) << 16);
                     sum += c7[i];
                 }
                 unsigned incl = sum;
@@ -371,7 +373,7 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 }
             __syncthreads();
 
-            // ---- 4. gather: a half wave per work item (a row, or 32 entries of a long row); 4 lanes x 8 channels per entry, 8 entries a step ----
+            // ---- 4. gather: a half wave per work item (a row, or kSeg entries of a very long row); 4 lanes x 8 channels per entry, 8 entries a step ----
             {
                 // K lanes x 8 channels per entry, NG entries of an item a step.  D = 32: lane c holds channels 8c .. 8c+7; D = 64: 4c .. 4c+3
                 // of each 128-byte half of the row (so that a half wave's flush covers one whole line per instruction)
@@ -388,8 +390,8 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     if (k >= n_items) return kDrop;
                     const unsigned it = items[k];
                     const unsigned row = it & 0xfffu, sg = it >> 12;
-                    const unsigned o0 = cnt[row] + sg * 32u, o1 = cnt[row + 1];
-                    const unsigned len = sg == 3u ? o1 - o0 : min(o1 - o0, 32u);
+                    const unsigned o0 = cnt[row] + sg * (unsigned)kSeg, o1 = cnt[row + 1];
+                    const unsigned len = sg == 3u ? o1 - o0 : min(o1 - o0, (unsigned)kSeg);
                     fl = o0 | (len << 16);
                     const unsigned pix = base_pix + __umul24(row >> 6, (unsigned)Wl) + (row & 63u);
                     return __umul24(pix, pix_b) + lane_b;
