@@ -136,6 +136,15 @@ template <int CTRL>
 __device__ __forceinline__ float dppc(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
+// the value of lane ^ X (X = 4, 8, 16)
+template <int X>
+__device__ __forceinline__ float lane_xor(float v) {
+    if constexpr (X == 8) {
+        return dppc<0x128>(v);   // row_ror:8 inside a 16-lane row
+    } else {
+        return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), X == 4 ? 0x101F : 0x401F));   // xor_mask << 10 | and_mask 0x1f
+    }
+}
 // sum over aligned groups of 8 lanes, valid in every lane of the group
 __device__ __forceinline__ float sum8(float v) {
     v += dppc<0xB1>(v);    // quad_perm [1,0,3,2]
@@ -373,14 +382,17 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                 }
             __syncthreads();
 
-            // ---- 4. gather: a half wave per work item (a row, or kSeg entries of a very long row); 4 lanes x 8 channels per entry, 8 entries a step ----
+            // ---- 4. gather: LPI lanes per work item (a row, or kSeg entries of a very long row): a quarter wave at D = 32, a half wave at
+            //         D = 64; K lanes x 8 channels per entry, 4 entries of an item a step -------------------------------------------------
             {
-                // K lanes x 8 channels per entry, NG entries of an item a step.  D = 32: lane c holds channels 8c .. 8c+7; D = 64: 4c .. 4c+3
-                // of each 128-byte half of the row (so that a half wave's flush covers one whole line per instruction)
-                constexpr int K = D / 8, NG = 32 / K, CH1 = D == 32 ? 4 : 32;
-                const int hw = tid >> 5, g = (lane / K) & (NG - 1), c = lane & (K - 1);
+                // Lane c of an entry's K lanes holds channels 4c .. 4c+3 of EACH half of the row: after the reduce-scatter over the item's
+                // four lane groups every lane owns one channel of each half, and each of the two flush instructions covers a contiguous
+                // 64 bytes (D = 32) / 128 bytes (D = 64) per row — which costs what a whole-row instruction costs (tools/micro/atomic_split.hip:
+                // 10.4 G rows/s either way; the same dwords spread over the whole row: half of it)
+                constexpr int K = D / 8, NG = 4, LPI = K * NG, IPW = 64 / LPI, CH1 = D / 2;
+                const int sub = lane / LPI, g = (lane / K) & (NG - 1), c = lane & (K - 1);
                 const int n_items = ALO_DBG(128) ? 0 : (int)wsum[8];
-                const unsigned ch0 = D == 32 ? 8u * c : 4u * c;
+                const unsigned ch0 = 4u * c;
                 const unsigned lane_b = (head_elems + ch0) * (unsigned)sizeof(T);   // byte offset of the lane's first 4 channels inside a pixel
                 const unsigned pix_b = pix_elems * (unsigned)sizeof(T);
                 const unsigned base_pix = (unsigned)(Sl + wy0 * Wl + wx0);
@@ -397,22 +409,23 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     return __umul24(pix, pix_b) + lane_b;
                 };
                 unsigned fl;
-                unsigned voff = item_of(hw, fl);
+                unsigned voff = item_of(wave * IPW + sub, fl);
                 f32x4 v0, v1;
                 Row4<T>::template load8b<CH1>(v_rsrc, ALO_DBG(4) ? kDrop : voff, v0, v1);
                 const float* Gc = G + ch0;
-                const bool t1 = g & 1, t2 = g & 2, t4 = g & 4;
-                // the channel (of the lane's eight) it flushes.  D = 32: one of eight; D = 64: the same one of four in both halves of the row
-                const unsigned reg_b = D == 32 ? ((t1 ? 4u : 0u) + (t2 ? 2u : 0u) + (t4 ? 1u : 0u)) * 4u : ((t1 ? 2u : 0u) + (t2 ? 1u : 0u)) * 4u;
-                for (int kb = hw & ~1; kb < n_items; kb += 16) {   // wave-uniform bound: the two halves' items are kb and kb + 1
+                const bool t1 = g & 1, t2 = g & 2;
+                const unsigned reg_b = ((t1 ? 2u : 0u) + (t2 ? 1u : 0u)) * 4u;   // the channel (of its four per half) the lane flushes
+                for (int kb = wave * IPW; kb < n_items; kb += 8 * IPW) {   // wave-uniform bound: the wave's items are kb .. kb + IPW - 1
                     // the next item's value row travels while this one is walked
                     unsigned fl_n;
-                    const unsigned voff_n = item_of(kb + (hw & 1) + 16, fl_n);
+                    const unsigned voff_n = item_of(kb + sub + 8 * IPW, fl_n);
                     f32x4 vn0, vn1;
                     Row4<T>::template load8b<CH1>(v_rsrc, ALO_DBG(4) ? kDrop : voff_n, vn0, vn1);
                     const int first = (int)(fl & 0xffffu), len = ALO_DBG(2) ? 0 : (int)(fl >> 16);
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                    const int steps = (max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32)) + NG - 1) / NG;
+                    int longest = max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 32));
+                    if constexpr (IPW == 4) longest = max(longest, max(__builtin_amdgcn_readlane(len, 16), __builtin_amdgcn_readlane(len, 48)));
+                    const int steps = (longest + NG - 1) / NG;   // wave-uniform
                     // (a slot past the item's end re-reads the row's OWN first entry with weight 0: a non-finite grad_out row of some other
                     // query can then never reach this row — 0 x inf would — exactly as in the reference, where it touches only its own pixels)
                     auto walk = [&](int s0, auto nsteps) {
@@ -463,27 +476,19 @@ msda_bwd_wide_kernel(const T* __restrict__ value, const int32_t* __restrict__ sh
                     // Lane ^ 4 and lane ^ 16 travel on the LDS crossbar (ds_swizzle: no memory, no address register), lane ^ 8 on DPP.
                     // value is T, grad_value fp32: the same pixel and channels are at byte offset (voff / sizeof(T)) * 4
                     const unsigned boff = (voff == kDrop || ALO_DBG(1)) ? kDrop : voff * (4u / (unsigned)sizeof(T)) + reg_b;
-                    if constexpr (D == 32) {
-                        const f32x4 keep1 = t1 ? a1 : a0, send1 = t1 ? a0 : a1;
-                        f32x4 r1;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            r1[i] = keep1[i] + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send1[i]), 0x101F));   // xor 4
-                        const float k2a = t2 ? r1[2] : r1[0], k2b = t2 ? r1[3] : r1[1], s2a = t2 ? r1[0] : r1[2], s2b = t2 ? r1[1] : r1[3];
-                        const float r2a = k2a + dppc<0x128>(s2a), r2b = k2b + dppc<0x128>(s2b);          // row_ror:8 = lane ^ 8 inside a 16-lane row
-                        const float k3 = t4 ? r2b : r2a, s3 = t4 ? r2a : r2b;
-                        const float tot = k3 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s3), 0x401F));   // xor 16
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot, gv_rsrc, boff, 0, 0);
-                    } else {
-                        // four groups (lane bits 3, 4): first the pair of channels, then the channel — of BOTH halves of the row at once
-                        const float ka = t1 ? a0[2] : a0[0], kb = t1 ? a0[3] : a0[1], kc = t1 ? a1[2] : a1[0], kd = t1 ? a1[3] : a1[1];
+                    {
+                        // four groups: first the pair of channels, then the channel — of BOTH halves of the row at once.  The partner groups
+                        // are K and 2 K lanes away: lane ^ 4 / lane ^ 16 travel on the LDS crossbar (ds_swizzle: no memory, no address
+                        // register), lane ^ 8 on DPP (row_ror:8 inside a 16-lane row)
+                        auto xchg1 = [](float x) { return lane_xor<K>(x); };
+                        auto xchg2 = [](float x) { return lane_xor<2 * K>(x); };
+                        const float ka = t1 ? a0[2] : a0[0], kb2 = t1 ? a0[3] : a0[1], kc = t1 ? a1[2] : a1[0], kd = t1 ? a1[3] : a1[1];
                         const float sa = t1 ? a0[0] : a0[2], sb = t1 ? a0[1] : a0[3], sc = t1 ? a1[0] : a1[2], sd = t1 ? a1[1] : a1[3];
-                        const float pa = ka + dppc<0x128>(sa), pb = kb + dppc<0x128>(sb), pc = kc + dppc<0x128>(sc), pd = kd + dppc<0x128>(sd);
+                        const float pa = ka + xchg1(sa), pb = kb2 + xchg1(sb), pc = kc + xchg1(sc), pd = kd + xchg1(sd);
                         const float k0 = t2 ? pb : pa, k1 = t2 ? pd : pc, x0 = t2 ? pa : pb, x1 = t2 ? pc : pd;
-                        const float tot0 = k0 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x0), 0x401F));
-                        const float tot1 = k1 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x1), 0x401F));
+                        const float tot0 = k0 + xchg2(x0), tot1 = k1 + xchg2(x1);
                         __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot0, gv_rsrc, boff, 0, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot1, gv_rsrc, boff == kDrop ? kDrop : boff + 128u, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tot1, gv_rsrc, boff == kDrop ? kDrop : boff + 4u * CH1, 0, 0);
                     }
                     voff = voff_n;
                     fl = fl_n;
