@@ -21,21 +21,22 @@
 //               touched row, up to four for rows longer than 128 entries — no half wave is handed a very long row alone (splitting at 32 cost
 //               40 % more atomic rows on the ring: the items are dealt round-robin, which balances the coarse levels by itself).
 //   3. list     list[cnt[row] + slot] = entry: the entries sorted by window row, contiguous per row.
-//   4. gather   a half wave per work item, 4 lanes x 8 channels per entry, 8 entries a step.  The lanes hold value[row] (read from
-//               memory once per block, the next item's row prefetched) and per entry ONE 128-byte LDS read of the query's grad_out row
-//               feeds both sums:
-//                 grad_value[row] += tbl[entry] * grad_out[q]      registers; reduce-scatter over the 8 lane groups (ds_swizzle / DPP),
-//                                                                  then ONE buffer_atomic_add_f32 row per work item
-//                 d[entry]         = <value[row], grad_out[q]>      2 DPP adds over the 4 lanes; overwrites tbl[entry]
+//   4. gather   a QUARTER wave per work item at D = 32 (a half wave at D = 64): four lane groups x K lanes x 8 channels, four entries a
+//               step.  The lanes hold value[row] (read from memory once per block, the next item's row prefetched) and per entry ONE
+//               D-channel LDS read of the query's grad_out row feeds both sums:
+//                 grad_value[row] += tbl[entry] * grad_out[q]      registers; reduce-scatter over the 4 lane groups (ds_swizzle / DPP),
+//                                                                  then two buffer_atomic_add_f32 per row, each a contiguous half row
+//                                                                  (costs what one whole-row instruction costs: tools/micro/atomic_split.hip)
+//                 d[entry]         = <value[row], grad_out[q]>      2-3 DPP adds over the K lanes; overwrites tbl[entry]
 //   5. finish   the thread that owns the sample reads its four d's back: grad_attn = sum_k w_k d_k, grad_loc = attn * (W, H) * (...)
 //               — the same expressions as msda_bwd_tiled_kernel's stage 3 — and stores 16 + 8 contiguous bytes.
 //   A sample with a corner outside the window (far outliers; every sample of a uniform distribution) sets a bit in an overflow mask and
 //   takes the per-corner route of msda_bwd_kernel at the end: same results, old cost.
 //
-// Measured (MI355X, N = 4 encoder call, fp32; tools/exp/bwd_wide_check.py): 0.70 / 0.80 / 0.80 / 3.16 ms on the ring / survey /
-// trained-like / uniform distributions against 0.70 / 1.32 / 1.61 / 4.04 for msda_bwd_tiled_kernel; bf16 values 0.68 / 0.77 against
-// 4.1 / 3.9 for msda_bwd_kernel.  VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 0.6 of the busy cycles): the listed order of the blocks
-// (full blocks of every batch item first, heads round-robin over the XCDs) and a loop-free scan were worth 25 % together.
+// Measured (MI355X, N = 4 encoder call, fp32; tools/exp/bwd_wide_check.py): 0.58 / 0.66 / 0.66 / 3.15 ms on the ring / survey /
+// trained-like / uniform distributions against 0.70 / 1.32 / 1.61 / 4.04 for msda_bwd_tiled_kernel; bf16 values 0.59 / 0.67 against
+// 4.1 / 3.9 for msda_bwd_kernel; D = 64 1.36 / 1.55 against 8.4 / 7.8.  VALU-issue bound (67 % of the SIMD time): the build log with every
+// intermediate number is docs/experiments.md R6.1.
 //
 // Shapes served: value / grad_out fp32 or bf16 (gradients fp32), D = 32, L = P = 4, queries = the pyramid's own pixels (Lq == S).
 // The host copy of the shapes sizes the grid AND travels by value; a launch whose device shapes differ from it sends every
