@@ -5,6 +5,7 @@
 //   B  2 instructions / row: 4 rows x 16 lanes, each a contiguous 64-byte half row
 //   C  2 instructions / row: 4 rows x 16 lanes, every other dword of the whole row
 //   D  4 instructions / row: 8 rows x 8 lanes, every fourth dword (the first version of the wide kernel)
+//   E  4 instructions / row: 8 rows x 8 lanes, each a contiguous 32-byte quarter row
 //   hipcc --offload-arch=gfx950 -O2 -munsafe-fp-atomics -w -o tools/micro/atomic_split tools/micro/atomic_split.hip && tools/micro/atomic_split
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,7 +15,7 @@ __global__ void __launch_bounds__(64) k(float* buf, unsigned nrows, int rows_per
     const unsigned lane = threadIdx.x;
     unsigned s = blockIdx.x * 2654435761u + 12345u;
     const unsigned win0 = (blockIdx.x * 97u) % (nrows - 4096u);
-    constexpr int LANES = MODE == 0 ? 32 : (MODE == 3 ? 8 : 16), ROWS = 64 / LANES, INSTR = 32 / LANES;
+    constexpr int LANES = MODE == 0 ? 32 : (MODE >= 3 ? 8 : 16), ROWS = 64 / LANES, INSTR = 32 / LANES;
     const unsigned sub = lane / LANES, l = lane % LANES;
     for (int i = 0; i < rows_per_wave; i += ROWS) {
         s = s * 1664525u + 1013904223u;
@@ -22,7 +23,7 @@ __global__ void __launch_bounds__(64) k(float* buf, unsigned nrows, int rows_per
         float* row = buf + (size_t)r * 32;
 #pragma unroll
         for (int j = 0; j < INSTR; ++j) {
-            const unsigned ch = MODE == 0 ? l : (MODE == 1 ? 16u * j + l : (MODE == 2 ? 2u * l + j : 4u * l + j));
+            const unsigned ch = MODE == 0 ? l : (MODE == 1 ? 16u * j + l : (MODE == 2 ? 2u * l + j : (MODE == 3 ? 4u * l + j : 8u * j + l)));
             atomicAdd(row + ch, 1.0f);
         }
     }
@@ -50,5 +51,6 @@ int main() {
     run(k<1>, "B  2 instructions / row (4 rows x 16 lanes, contiguous 64-byte halves)");
     run(k<2>, "C  2 instructions / row (4 rows x 16 lanes, every other dword)");
     run(k<3>, "D  4 instructions / row (8 rows x 8 lanes, every fourth dword)");
+    run(k<4>, "E  4 instructions / row (8 rows x 8 lanes, contiguous 32-byte quarters)");
     return 0;
 }
