@@ -226,3 +226,29 @@ def test_a_non_finite_grad_out_row_reaches_only_the_pixels_its_query_samples():
     untouched = ~hit
     assert np.isfinite(gv[0][untouched]).all(), "a non-finite grad_out row leaked outside its query's footprint"
     assert np.abs(gv[0][untouched] - clean[0][untouched]).max() <= 1e-5 * max(1.0, np.abs(clean).max())
+
+
+def test_autograd_function_in_bf16_takes_the_wide_kernel_and_matches_fp32_on_the_rounded_operands():
+    """bf16 training of the encoder's self-attention: MSDeformAttnFunction.apply with bf16 value / locations / weights, backward through
+    the dispatcher op; every gradient comes back in its input's dtype and equals the fp32 run on the same (rounded) operands to bf16
+    rounding of the result."""
+    from alonet.deformable_detr.ops.functions import MSDeformAttnFunction
+
+    shapes_l = [(37, 53), (19, 27), (10, 14), (5, 7)]
+    rng = np.random.default_rng(12)
+    c = encoder_case(shapes_l, 2, 8, rng, 2.0, True)
+    shapes = dev(c["shapes"])
+    shapes._alo_shapes = [tuple(hw) for hw in shapes_l]
+    start = dev(c["level_start"])
+    outs = {}
+    for dtype in (torch.bfloat16, torch.float32):
+        v = dev(c["value"]).bfloat16().to(dtype).requires_grad_(True)
+        loc = dev(c["loc"]).bfloat16().to(dtype).requires_grad_(True)
+        attn = dev(c["attn"]).bfloat16().to(dtype).requires_grad_(True)
+        out = MSDeformAttnFunction.apply(v, shapes, start, loc, attn, 64)
+        out.backward(dev(c["grad_out"]).bfloat16().to(dtype))
+        assert v.grad.dtype == dtype and loc.grad.dtype == dtype and attn.grad.dtype == dtype
+        outs[dtype] = (out.detach().float(), v.grad.float(), loc.grad.float(), attn.grad.float())
+    for got, ref in zip(outs[torch.bfloat16], outs[torch.float32]):
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
